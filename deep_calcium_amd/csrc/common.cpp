@@ -1,0 +1,39 @@
+// Error reporting, version and HIP-event timing helpers of libdcunet.
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void dc_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int dc_version(void) { return 100; }
+extern "C" const char* dc_last_error(void) { return g_err; }
+
+extern "C" int dc_event_create(void** ev) {
+  DC_REQUIRE(ev, DC_EINVAL, "dc_event_create: null");
+  hipEvent_t e;
+  hipError_t rc = hipEventCreate(&e);
+  DC_REQUIRE(rc == hipSuccess, DC_EHIP, "hipEventCreate: %s", hipGetErrorString(rc));
+  *ev = (void*)e;
+  return DC_OK;
+}
+extern "C" int dc_event_record(void* ev, dc_stream_t stream) {
+  hipError_t rc = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
+  DC_REQUIRE(rc == hipSuccess, DC_EHIP, "hipEventRecord: %s", hipGetErrorString(rc));
+  return DC_OK;
+}
+extern "C" int dc_event_elapsed_ms(void* start, void* stop, float* ms) {
+  hipError_t rc = hipEventSynchronize((hipEvent_t)stop);
+  DC_REQUIRE(rc == hipSuccess, DC_EHIP, "hipEventSynchronize: %s", hipGetErrorString(rc));
+  rc = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+  DC_REQUIRE(rc == hipSuccess, DC_EHIP, "hipEventElapsedTime: %s", hipGetErrorString(rc));
+  return DC_OK;
+}
+extern "C" int dc_event_destroy(void* ev) {
+  (void)hipEventDestroy((hipEvent_t)ev);
+  return DC_OK;
+}

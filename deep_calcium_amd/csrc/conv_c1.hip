@@ -1,0 +1,166 @@
+// First UNet2DS layer: Conv2D(nfb,(3,3),'same') on the 1-channel image
+// (/root/reference/deepcalcium/models/neurons/unet_2d_summary.py:170-172: expand_dims + conv_layer(nfb)).
+// K = 9: no matrix shape to speak of and 4.4 flop/byte -- an HBM-bound streaming kernel (the 128-B output
+// row per pixel dominates), written on the vector ALU: Cout/4 lanes per pixel, float4 stores so one
+// pixel's channels form one contiguous segment, 3x3 taps + bias held in registers.
+#include "common.h"
+
+struct C1Params {
+  const float* x;
+  const float* w;  // HWIO (3,3,1,Cout)
+  const float* bias;
+  float* z;
+  float* stats;
+  const float* scale;
+  const float* shift;
+  int N, H, W, Cout, relu;
+  long pixels, zLd;
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+__global__ __launch_bounds__(256) void conv_c1_fwd_kernel(C1Params p) {
+  __shared__ f32x4 sm1[256], sm2[256];
+  const int C4 = p.Cout >> 2, PPB = 256 / C4;
+  const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
+  f32x4 w[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w[t] = ld4(p.w + t * p.Cout + 4 * q);
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+  const f32x4 b = p.bias ? ld4(p.bias + 4 * q) : z4;
+  const f32x4 sc = p.scale ? ld4(p.scale + 4 * q) : one4;
+  const f32x4 sh = p.shift ? ld4(p.shift + 4 * q) : z4;
+  f32x4 s1 = z4, s2 = z4;
+  const long HW = (long)p.H * p.W;
+  for (long pix = (long)blockIdx.x * PPB + pl; pix < p.pixels; pix += (long)gridDim.x * PPB) {
+    const long img = pix / HW;
+    const int rem = (int)(pix - img * HW);
+    const int y = rem / p.W, x = rem - y * p.W;
+    const float* xi = p.x + img * HW;
+    f32x4 v = b;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y + dy - 1;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = x + dx - 1;
+        const float xv = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? xi[yy * p.W + xx] : 0.f;
+        v += xv * w[dy * 3 + dx];
+      }
+    }
+    s1 += v;
+    s2 += v * v;
+    if (p.scale) v = v * sc + sh;
+    if (p.relu) {
+      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(p.z + pix * p.zLd + 4 * q) = v;
+  }
+  if (p.stats) {
+    sm1[tid] = s1;
+    sm2[tid] = s2;
+    __syncthreads();
+    if (pl == 0) {
+      for (int k = 1; k < PPB; ++k) {
+        s1 += sm1[k * C4 + q];
+        s2 += sm2[k * C4 + q];
+      }
+      float* dst = p.stats + ((long)blockIdx.x * p.Cout + 4 * q) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dst[2 * e] = s1[e];
+        dst[2 * e + 1] = s2[e];
+      }
+    }
+  }
+}
+
+// dW[tap][co] partial per block = sum_p x[p+tap] * dz[p][co]
+__global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                            float* __restrict__ partial, int N, int H, int W, int Cout,
+                                                            long pixels) {
+  __shared__ f32x4 sm[256];
+  const int C4 = Cout >> 2, PPB = 256 / C4;
+  const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = z4;
+  const long HW = (long)H * W;
+  for (long pix = (long)blockIdx.x * PPB + pl; pix < pixels; pix += (long)gridDim.x * PPB) {
+    const long img = pix / HW;
+    const int rem = (int)(pix - img * HW);
+    const int y = rem / W, xq = rem - y * W;
+    const float* xi = x + img * HW;
+    const f32x4 g = ld4(dz + pix * Cout + 4 * q);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y + dy - 1;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = xq + dx - 1;
+        const float xv = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xi[yy * W + xx] : 0.f;
+        acc[dy * 3 + dx] += xv * g;
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    sm[tid] = acc[t];
+    __syncthreads();
+    if (pl == 0) {
+      f32x4 s = acc[t];
+      for (int k = 1; k < PPB; ++k) s += sm[k * C4 + q];
+      *reinterpret_cast<f32x4*>(partial + ((long)blockIdx.x * 9 + t) * Cout + 4 * q) = s;
+    }
+    __syncthreads();
+  }
+}
+
+static int c1_blocks(long pixels, int Cout) {
+  const int PPB = 256 / (Cout / 4);
+  long b = (pixels + PPB - 1) / PPB;
+  return (int)(b > 2048 ? 2048 : b);
+}
+
+extern "C" int dc_conv3x3_c1_tiles(int N, int H, int W, int Cout) { return c1_blocks((long)N * H * W, Cout); }
+
+static int check_c1(const char* fn, int N, int H, int W, int Cout) {
+  DC_REQUIRE(N > 0 && H > 0 && W > 0, DC_EINVAL, "%s: non-positive dimension", fn);
+  DC_REQUIRE(Cout >= 4 && Cout <= 1024 && dc_is_pow2(Cout), DC_EUNSUP, "%s: Cout=%d must be a power of two in [4,1024]", fn, Cout);
+  return DC_OK;
+}
+
+extern "C" int dc_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, float* z, long z_ld, float* stats,
+                                 const float* scale, const float* shift, int relu, int N, int H, int W, int Cout,
+                                 dc_stream_t stream) {
+  DC_REQUIRE(x && w && z, DC_EINVAL, "dc_conv3x3_c1_fwd: null pointer");
+  DC_REQUIRE(dc_aligned16(w) && dc_aligned16(z), DC_EINVAL, "dc_conv3x3_c1_fwd: w and z must be 16-byte aligned");
+  DC_REQUIRE((scale == nullptr) == (shift == nullptr), DC_EINVAL, "dc_conv3x3_c1_fwd: scale and shift go together");
+  int rc = check_c1("dc_conv3x3_c1_fwd", N, H, W, Cout);
+  if (rc) return rc;
+  C1Params p;
+  p.x = x; p.w = w; p.bias = bias; p.z = z; p.stats = stats; p.scale = scale; p.shift = shift;
+  p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.pixels = (long)N * H * W; p.zLd = z_ld;
+  DC_REQUIRE(z_ld >= Cout && z_ld % 4 == 0, DC_EINVAL, "dc_conv3x3_c1_fwd: bad z_ld");
+  hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3(c1_blocks(p.pixels, Cout)), dim3(256), 0, (hipStream_t)stream, p);
+  DC_CHECK_LAUNCH("dc_conv3x3_c1_fwd");
+  return DC_OK;
+}
+
+long dc_conv3x3_c1_wgrad_ws(int N, int H, int W, int Cout) {
+  const long L = 9L * Cout;
+  return (long)c1_blocks((long)N * H * W, Cout) * L + 32 * L;
+}
+
+int dc_conv3x3_c1_wgrad(const float* x, const float* dz, float* dw, float* ws, int N, int H, int W, int Cout,
+                        hipStream_t st) {
+  int rc = check_c1("dc_conv3x3_wgrad(Cin=1)", N, H, W, Cout);
+  if (rc) return rc;
+  const long pixels = (long)N * H * W;
+  const int blocks = c1_blocks(pixels, Cout);
+  hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, dz, ws, N, H, W, Cout, pixels);
+  DC_CHECK_LAUNCH("dc_conv3x3_wgrad(Cin=1)");
+  const long L = 9L * Cout;
+  return dc_reduce_partials(ws, blocks, L, 1.0f, dw, ws + (long)blocks * L, (dc_stream_t)st);
+}

@@ -1,0 +1,608 @@
+// HBM-bound kernels of the UNet2DS path: BatchNorm statistics / apply / backward, ReLU, dropout,
+// 2x2 max-pool (bit-exact first-max argmax), softmax head + Keras-form BCE + metric sums, Adam, reductions.
+// Reference call sites: /root/reference/deepcalcium/models/neurons/unet_2d_summary.py:158-159,:166-167
+// (BatchNormalization+relu), :176-216 (MaxPooling2D, Dropout), :221-222 (head), :398-399 (loss+metrics),
+// :335 (Adam); op semantics SURVEY.md Appendix A.
+// All of them are float4 (16 B/lane) streaming kernels with the channel quad fixed per thread
+// (256 % (C/4) == 0), so per-channel parameters live in registers and per-channel sums need no atomics:
+// partials per block are combined by a fixed-order second stage (bit-reproducible).
+#include "common.h"
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+static const int kMaxBlocks = 2048;
+
+static int chan_check(const char* fn, int C) {
+  DC_REQUIRE(C >= 4 && C <= 1024 && dc_is_pow2(C), DC_EUNSUP, "%s: C=%d must be a power of two in [4,1024]", fn, C);
+  return DC_OK;
+}
+static int ew_blocks(long pixels, int C) {
+  const int PPB = 256 / (C / 4);
+  long b = (pixels + PPB - 1) / PPB;
+  return (int)(b > kMaxBlocks ? kMaxBlocks : (b < 1 ? 1 : b));
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN statistics finalize: one block per channel, double accumulation over all partials.
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int parts, int groups,
+                                                               int C, double count, float eps, float momentum,
+                                                               float* mean, float* invstd, float* mmean, float* mvar) {
+  __shared__ double sh1[256], sh2[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int Ct = groups * C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = tid; i < parts * groups; i += 256) {
+    const int pt = i / groups, g = i - pt * groups;
+    const float* src = partial + ((long)pt * Ct + g * C + c) * 2;
+    s1 += (double)src[0];
+    s2 += (double)src[1];
+  }
+  sh1[tid] = s1; sh2[tid] = s2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { sh1[tid] += sh1[tid + s]; sh2[tid] += sh2[tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double mu = sh1[0] / count;
+    double var = sh2[0] / count - mu * mu;  // population (biased) variance, Keras 2.0.6 / tf.nn.moments
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (momentum >= 0.f && mmean && mvar) {
+      mmean[c] = (float)((double)mmean[c] * momentum + mu * (1.0 - (double)momentum));
+      mvar[c] = (float)((double)mvar[c] * momentum + var * (1.0 - (double)momentum));
+    }
+  }
+}
+
+extern "C" int dc_bn_stats_finalize(const float* partial, int parts, int groups, int C, double count, float eps,
+                                    float momentum, float* mean, float* invstd, float* moving_mean, float* moving_var,
+                                    dc_stream_t stream) {
+  DC_REQUIRE(partial && mean && invstd, DC_EINVAL, "dc_bn_stats_finalize: null pointer");
+  DC_REQUIRE(parts > 0 && groups > 0 && C > 0 && count > 0, DC_EINVAL, "dc_bn_stats_finalize: bad sizes");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C,
+                     count, eps, momentum, mean, invstd, moving_mean, moving_var);
+  DC_CHECK_LAUNCH("dc_bn_stats_finalize");
+  return DC_OK;
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mmean, const float* mvar,
+                               const float* bias, float eps, float* scale, float* shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float s = gamma[c] / sqrtf(mvar[c] + eps);
+    scale[c] = s;
+    shift[c] = beta[c] + ((bias ? bias[c] : 0.f) - mmean[c]) * s;
+  }
+}
+extern "C" int dc_bn_fold(const float* gamma, const float* beta, const float* mmean, const float* mvar,
+                          const float* bias, float eps, float* scale, float* shift, int C, dc_stream_t stream) {
+  DC_REQUIRE(gamma && beta && mmean && mvar && scale && shift && C > 0, DC_EINVAL, "dc_bn_fold: bad arguments");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(dc_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, mmean,
+                     mvar, bias, eps, scale, shift, C);
+  DC_CHECK_LAUNCH("dc_bn_fold");
+  return DC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct BnParams {
+  const float* da; long da_ld;
+  const float* z;
+  const float* mean; const float* invstd; const float* gamma; const float* beta;
+  const uint8_t* mask; float keep; uint64_t seed;
+  const float* dgamma; const float* dbeta;
+  float* out; long out_ld;
+  float* partial;
+  long pixels; int C;
+};
+
+// dropout keep-factor (0 or 1/keep) for the 4 channels of element quad `e4` (element index = pix*C + c)
+__device__ __forceinline__ f32x4 drop_factor(const BnParams& p, long elem, float inv_keep) {
+  f32x4 f;
+  if (p.mask) {
+    const uchar4 m = *reinterpret_cast<const uchar4*>(p.mask + elem);
+    f[0] = m.x ? inv_keep : 0.f; f[1] = m.y ? inv_keep : 0.f; f[2] = m.z ? inv_keep : 0.f; f[3] = m.w ? inv_keep : 0.f;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = dc_keep_factor(p.seed, (uint64_t)(elem + e), p.keep, inv_keep);
+  }
+  return f;
+}
+
+__global__ __launch_bounds__(256) void bn_relu_drop_fwd_kernel(BnParams p) {
+  const int C4 = p.C >> 2, PPB = 256 / C4;
+  const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
+  const f32x4 mu = ld4(p.mean + 4 * q), is = ld4(p.invstd + 4 * q), ga = ld4(p.gamma + 4 * q), be = ld4(p.beta + 4 * q);
+  const bool drop = p.keep < 1.f;
+  const float inv_keep = drop ? 1.f / p.keep : 1.f;
+  for (long pix = (long)blockIdx.x * PPB + pl; pix < p.pixels; pix += (long)gridDim.x * PPB) {
+    const long elem = pix * p.C + 4 * q;
+    const f32x4 z = ld4(p.z + elem);
+    f32x4 y = (z - mu) * is * ga + be;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+    if (drop) y *= drop_factor(p, elem, inv_keep);
+    st4(p.out + pix * p.out_ld + 4 * q, y);
+  }
+}
+
+extern "C" int dc_bn_relu_drop_fwd(const float* z, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, const uint8_t* mask, float keep, uint64_t seed, float* out,
+                                   long out_ld, long pixels, int C, dc_stream_t stream) {
+  DC_REQUIRE(z && mean && invstd && gamma && beta && out, DC_EINVAL, "dc_bn_relu_drop_fwd: null pointer");
+  DC_REQUIRE(pixels > 0 && out_ld >= C && out_ld % 4 == 0 && keep > 0.f, DC_EINVAL, "dc_bn_relu_drop_fwd: bad sizes");
+  int rc = chan_check("dc_bn_relu_drop_fwd", C);
+  if (rc) return rc;
+  BnParams p{};
+  p.z = z; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.mask = mask; p.keep = keep;
+  p.seed = seed; p.out = out; p.out_ld = out_ld; p.pixels = pixels; p.C = C;
+  hipLaunchKernelGGL(bn_relu_drop_fwd_kernel, dim3(ew_blocks(pixels, C)), dim3(256), 0, (hipStream_t)stream, p);
+  DC_CHECK_LAUNCH("dc_bn_relu_drop_fwd");
+  return DC_OK;
+}
+
+// dy = da * [y > 0] * dropfactor ; xhat = (z - mean) * invstd
+__device__ __forceinline__ void bn_bwd_elem(const BnParams& p, long pix, int q, const f32x4& mu, const f32x4& is,
+                                            const f32x4& ga, const f32x4& be, bool drop, float inv_keep, f32x4& dy,
+                                            f32x4& xh) {
+  const long elem = pix * p.C + 4 * q;
+  const f32x4 z = ld4(p.z + elem);
+  const f32x4 da = ld4(p.da + pix * p.da_ld + 4 * q);
+  xh = (z - mu) * is;
+  const f32x4 y = xh * ga + be;
+  dy = da;
+  if (drop) dy *= drop_factor(p, elem, inv_keep);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) dy[e] = (y[e] > 0.f) ? dy[e] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnParams p) {
+  __shared__ f32x4 sm1[256], sm2[256];
+  const int C4 = p.C >> 2, PPB = 256 / C4;
+  const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
+  const f32x4 mu = ld4(p.mean + 4 * q), is = ld4(p.invstd + 4 * q), ga = ld4(p.gamma + 4 * q), be = ld4(p.beta + 4 * q);
+  const bool drop = p.keep < 1.f;
+  const float inv_keep = drop ? 1.f / p.keep : 1.f;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  for (long pix = (long)blockIdx.x * PPB + pl; pix < p.pixels; pix += (long)gridDim.x * PPB) {
+    f32x4 dy, xh;
+    bn_bwd_elem(p, pix, q, mu, is, ga, be, drop, inv_keep, dy, xh);
+    s1 += dy;
+    s2 += dy * xh;
+  }
+  sm1[tid] = s1; sm2[tid] = s2;
+  __syncthreads();
+  if (pl == 0) {
+    for (int k = 1; k < PPB; ++k) { s1 += sm1[k * C4 + q]; s2 += sm2[k * C4 + q]; }
+    float* dst = p.partial + ((long)blockIdx.x * p.C + 4 * q) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dst[2 * e] = s1[e]; dst[2 * e + 1] = s2[e]; }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnParams p) {
+  __shared__ f32x4 sm1[256];
+  const int C4 = p.C >> 2, PPB = 256 / C4;
+  const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
+  const f32x4 mu = ld4(p.mean + 4 * q), is = ld4(p.invstd + 4 * q), ga = ld4(p.gamma + 4 * q), be = ld4(p.beta + 4 * q);
+  const float invM = 1.f / (float)p.pixels;
+  const f32x4 mdy = ld4(p.dbeta + 4 * q) * invM, mdyx = ld4(p.dgamma + 4 * q) * invM;
+  const f32x4 gs = ga * is;
+  const bool drop = p.keep < 1.f;
+  const float inv_keep = drop ? 1.f / p.keep : 1.f;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+  for (long pix = (long)blockIdx.x * PPB + pl; pix < p.pixels; pix += (long)gridDim.x * PPB) {
+    f32x4 dy, xh;
+    bn_bwd_elem(p, pix, q, mu, is, ga, be, drop, inv_keep, dy, xh);
+    const f32x4 dz = gs * (dy - mdy - xh * mdyx);
+    s1 += dz;
+    st4(p.out + pix * p.out_ld + 4 * q, dz);
+  }
+  if (p.partial) {
+    sm1[tid] = s1;
+    __syncthreads();
+    if (pl == 0) {
+      for (int k = 1; k < PPB; ++k) s1 += sm1[k * C4 + q];
+      st4(p.partial + (long)blockIdx.x * p.C + 4 * q, s1);
+    }
+  }
+}
+
+extern "C" int dc_bn_bwd_blocks(long pixels, int C) { return ew_blocks(pixels, C); }
+
+extern "C" int dc_bn_bwd_reduce(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
+                                float* partial, long pixels, int C, dc_stream_t stream) {
+  DC_REQUIRE(da && z && mean && invstd && gamma && beta && partial, DC_EINVAL, "dc_bn_bwd_reduce: null pointer");
+  DC_REQUIRE(pixels > 0 && da_ld >= C && da_ld % 4 == 0 && keep > 0.f, DC_EINVAL, "dc_bn_bwd_reduce: bad sizes");
+  int rc = chan_check("dc_bn_bwd_reduce", C);
+  if (rc) return rc;
+  BnParams p{};
+  p.da = da; p.da_ld = da_ld; p.z = z; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
+  p.mask = mask; p.keep = keep; p.seed = seed; p.partial = partial; p.pixels = pixels; p.C = C;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ew_blocks(pixels, C)), dim3(256), 0, (hipStream_t)stream, p);
+  DC_CHECK_LAUNCH("dc_bn_bwd_reduce");
+  return DC_OK;
+}
+
+extern "C" int dc_bn_bwd_apply(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
+                               const float* dgamma, const float* dbeta, float* dz, float* dbias_partial, long pixels,
+                               int C, dc_stream_t stream) {
+  DC_REQUIRE(da && z && mean && invstd && gamma && beta && dgamma && dbeta && dz, DC_EINVAL,
+             "dc_bn_bwd_apply: null pointer");
+  DC_REQUIRE(pixels > 0 && da_ld >= C && da_ld % 4 == 0 && keep > 0.f, DC_EINVAL, "dc_bn_bwd_apply: bad sizes");
+  int rc = chan_check("dc_bn_bwd_apply", C);
+  if (rc) return rc;
+  BnParams p{};
+  p.da = da; p.da_ld = da_ld; p.z = z; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
+  p.mask = mask; p.keep = keep; p.seed = seed; p.dgamma = dgamma; p.dbeta = dbeta; p.out = dz; p.out_ld = C;
+  p.partial = dbias_partial; p.pixels = pixels; p.C = C;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(pixels, C)), dim3(256), 0, (hipStream_t)stream, p);
+  DC_CHECK_LAUNCH("dc_bn_bwd_apply");
+  return DC_OK;
+}
+
+// dbeta[c] = sum_p partial[p][c][0], dgamma[c] = sum_p partial[p][c][1]
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int P, int C,
+                                                             float* dgamma, float* dbeta) {
+  __shared__ double sh1[256], sh2[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = tid; i < P; i += 256) {
+    s1 += (double)partial[((long)i * C + c) * 2];
+    s2 += (double)partial[((long)i * C + c) * 2 + 1];
+  }
+  sh1[tid] = s1; sh2[tid] = s2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { sh1[tid] += sh1[tid + s]; sh2[tid] += sh2[tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) { dbeta[c] = (float)sh1[0]; dgamma[c] = (float)sh2[0]; }
+}
+extern "C" int dc_bn_bwd_finalize(const float* partial, int P, int C, float* dgamma, float* dbeta, dc_stream_t stream) {
+  DC_REQUIRE(partial && dgamma && dbeta && P > 0 && C > 0, DC_EINVAL, "dc_bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, P, C, dgamma, dbeta);
+  DC_CHECK_LAUNCH("dc_bn_bwd_finalize");
+  return DC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPooling2D(2,2): first max in row-major window order (strict '>' keeps the earliest on ties).
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ in, long in_ld, float* __restrict__ out,
+                                                         uint8_t* __restrict__ idx, int N, int H, int W, int C) {
+  const int C4 = C >> 2, h2 = H >> 1, w2 = W >> 1;
+  const long total = (long)N * h2 * w2 * C4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int q = (int)(i % C4);
+    long r = i / C4;
+    const int x = (int)(r % w2); r /= w2;
+    const int y = (int)(r % h2);
+    const long n = r / h2;
+    const float* base = in + ((n * H + 2 * y) * W + 2 * x) * in_ld + 4 * q;
+    const f32x4 v0 = ld4(base), v1 = ld4(base + in_ld), v2 = ld4(base + (long)W * in_ld), v3 = ld4(base + (long)(W + 1) * in_ld);
+    f32x4 m = v0;
+    uchar4 k = make_uchar4(0, 0, 0, 0);
+    uint8_t* kk = reinterpret_cast<uint8_t*>(&k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (v1[e] > m[e]) { m[e] = v1[e]; kk[e] = 1; }
+      if (v2[e] > m[e]) { m[e] = v2[e]; kk[e] = 2; }
+      if (v3[e] > m[e]) { m[e] = v3[e]; kk[e] = 3; }
+    }
+    st4(out + i * 4, m);
+    if (idx) *reinterpret_cast<uchar4*>(idx + i * 4) = k;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                         const float* __restrict__ skip, long skip_ld,
+                                                         float* __restrict__ dx, int N, int H, int W, int C) {
+  const int C4 = C >> 2, h2 = H >> 1, w2 = W >> 1;
+  const long total = (long)N * h2 * w2 * C4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int q = (int)(i % C4);
+    long r = i / C4;
+    const int x = (int)(r % w2); r /= w2;
+    const int y = (int)(r % h2);
+    const long n = r / h2;
+    const f32x4 g = ld4(dy + i * 4);
+    const uchar4 k = *reinterpret_cast<const uchar4*>(idx + i * 4);
+    const uint8_t* kk = reinterpret_cast<const uint8_t*>(&k);
+    const long pix00 = (n * H + 2 * y) * W + 2 * x;
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+      const long pix = pix00 + (pos >> 1) * (long)W + (pos & 1);
+      f32x4 v = skip ? ld4(skip + pix * skip_ld + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += (kk[e] == pos) ? g[e] : 0.f;
+      st4(dx + pix * C + 4 * q, v);
+    }
+  }
+}
+
+static int pool_check(const char* fn, int N, int H, int W, int C) {
+  DC_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, DC_EINVAL, "%s: H and W must be positive and even", fn);
+  DC_REQUIRE(C >= 4 && C % 4 == 0, DC_EUNSUP, "%s: C=%d must be a multiple of 4", fn, C);
+  return DC_OK;
+}
+extern "C" int dc_maxpool2x2_fwd(const float* in, long in_ld, float* out, uint8_t* idx, int N, int H, int W, int C,
+                                 dc_stream_t stream) {
+  DC_REQUIRE(in && out && in_ld >= C && in_ld % 4 == 0, DC_EINVAL, "dc_maxpool2x2_fwd: bad arguments");
+  int rc = pool_check("dc_maxpool2x2_fwd", N, H, W, C);
+  if (rc) return rc;
+  const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, in_ld, out, idx, N, H, W, C);
+  DC_CHECK_LAUNCH("dc_maxpool2x2_fwd");
+  return DC_OK;
+}
+extern "C" int dc_maxpool2x2_bwd(const float* dy, const uint8_t* idx, const float* skip, long skip_ld, float* dx, int N,
+                                 int H, int W, int C, dc_stream_t stream) {
+  DC_REQUIRE(dy && idx && dx && (!skip || (skip_ld >= C && skip_ld % 4 == 0)), DC_EINVAL, "dc_maxpool2x2_bwd: bad arguments");
+  int rc = pool_check("dc_maxpool2x2_bwd", N, H, W, C);
+  if (rc) return rc;
+  const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, idx, skip, skip_ld, dx, N, H, W, C);
+  DC_CHECK_LAUNCH("dc_maxpool2x2_bwd");
+  return DC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head: C/4 lanes per pixel, xor-shuffle the two partial logits, lane q==0 finishes the pixel.
+__device__ __forceinline__ float round_half_even(float x) { return rintf(x); }  // default RN mode = half to even
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ a, const float* __restrict__ kh,
+                                                      const float* __restrict__ bh, const uint8_t* __restrict__ y,
+                                                      float* __restrict__ p, float* __restrict__ partial, long pixels,
+                                                      int C) {
+  __shared__ float sm[256][8];
+  const int C4 = C >> 2, PPB = 256 / C4;
+  const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
+  float k0[4], k1[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { k0[e] = kh[(4 * q + e) * 2]; k1[e] = kh[(4 * q + e) * 2 + 1]; }
+  const float b0 = bh[0], b1 = bh[1];
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const long iters = (pixels + (long)gridDim.x * PPB - 1) / ((long)gridDim.x * PPB);
+  for (long it = 0; it < iters; ++it) {  // uniform trip count: the shuffles below need every lane
+    const long pix = (it * gridDim.x + blockIdx.x) * PPB + pl;
+    const bool ok = pix < pixels;
+    f32x4 v = ok ? ld4(a + pix * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float z0 = v[0] * k0[0] + v[1] * k0[1] + v[2] * k0[2] + v[3] * k0[3];
+    float z1 = v[0] * k1[0] + v[1] * k1[1] + v[2] * k1[2] + v[3] * k1[3];
+    for (int s = 1; s < C4; s <<= 1) { z0 += __shfl_xor(z0, s); z1 += __shfl_xor(z1, s); }
+    if (ok && q == 0) {
+      z0 += b0; z1 += b1;
+      // 2-way softmax, max-subtracted, class 1
+      const float m = fmaxf(z0, z1);
+      const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+      const float pr = e1 / (e0 + e1);
+      p[pix] = pr;
+      if (y) {
+        const float yt = (float)y[pix];
+        // Keras/TF binary_crossentropy (A.10): clip, logit, stable sigmoid-BCE
+        const float pc = fminf(fmaxf(pr, 1e-7f), 1.f - 1e-7f);
+        const float x = logf(pc / (1.f - pc));
+        acc[0] += fmaxf(x, 0.f) - x * yt + log1pf(expf(-fabsf(x)));
+        const float rp = round_half_even(pr);
+        acc[1] += rp * yt;
+        acc[2] += rp;
+        acc[3] += fminf(fmaxf(yt - rp, 0.f), 1.f);
+        acc[4] += yt;
+        acc[5] += yt * pr;
+        acc[6] += pr * pr;
+        acc[7] += yt * yt;
+      }
+    }
+  }
+  if (partial) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sm[tid][k] = (q == 0) ? acc[k] : 0.f;
+    __syncthreads();
+    if (tid < 8) {
+      double s = 0.0;
+      for (int t = 0; t < 256; ++t) s += (double)sm[t][tid];
+      partial[(long)blockIdx.x * 8 + tid] = (float)s;
+    }
+  }
+}
+
+// s = dL/dlogit1 = (p - y)/M where the clip is inactive, else 0 ; dlogit0 = -s
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ a, const float* __restrict__ p,
+                                                      const uint8_t* __restrict__ y, const float* __restrict__ kh,
+                                                      float* __restrict__ da, float* __restrict__ partial, long pixels,
+                                                      int C) {
+  __shared__ f32x4 sm[256];
+  __shared__ float sms[256];
+  const int C4 = C >> 2, PPB = 256 / C4;
+  const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
+  f32x4 kd;  // kh[c][1] - kh[c][0]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) kd[e] = kh[(4 * q + e) * 2 + 1] - kh[(4 * q + e) * 2];
+  const float invM = 1.f / (float)pixels;
+  f32x4 sa = {0.f, 0.f, 0.f, 0.f};
+  float ss = 0.f;
+  for (long pix = (long)blockIdx.x * PPB + pl; pix < pixels; pix += (long)gridDim.x * PPB) {
+    const float pr = p[pix];
+    const bool inside = pr > 1e-7f && pr < 1.f - 1e-7f;
+    const float s = inside ? (pr - (float)y[pix]) * invM : 0.f;
+    const f32x4 v = ld4(a + pix * C + 4 * q);
+    st4(da + pix * C + 4 * q, kd * s);
+    sa += v * s;
+    if (q == 0) ss += s;
+  }
+  sm[tid] = sa;
+  sms[tid] = (q == 0) ? ss : 0.f;
+  __syncthreads();
+  if (pl == 0) {
+    for (int k = 1; k < PPB; ++k) sa += sm[k * C4 + q];
+    st4(partial + (long)blockIdx.x * (C + 4) + 4 * q, sa);
+  }
+  if (tid == 0) {
+    float s = 0.f;
+    for (int k = 0; k < PPB; ++k) s += sms[k * C4];
+    partial[(long)blockIdx.x * (C + 4) + C] = s;
+  }
+}
+
+// partial rows are padded to C+4 floats to keep float4 alignment
+__global__ void head_grad_finalize_kernel(const float* __restrict__ partial, int blocks, int C, float* dkh, float* dbh) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > C) return;
+  double s = 0.0;
+  for (int b = 0; b < blocks; ++b) s += (double)partial[(long)b * (C + 4) + c];
+  if (c < C) { dkh[2 * c] = (float)(-s); dkh[2 * c + 1] = (float)s; }
+  else { dbh[0] = (float)(-s); dbh[1] = (float)s; }
+}
+
+static int head_blocks(long pixels) {
+  long b = (pixels + 255) / 256;
+  return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+extern "C" int dc_head_blocks(long pixels) { return head_blocks(pixels); }
+
+extern "C" int dc_head_fwd(const float* a, const float* kh, const float* bh, const uint8_t* y, float* p, float* partial,
+                           long pixels, int C, dc_stream_t stream) {
+  DC_REQUIRE(a && kh && bh && p && pixels > 0, DC_EINVAL, "dc_head_fwd: bad arguments");
+  DC_REQUIRE(!y || partial, DC_EINVAL, "dc_head_fwd: y given without a partial buffer");
+  int rc = chan_check("dc_head_fwd", C);
+  if (rc) return rc;
+  DC_REQUIRE(C <= 256, DC_EUNSUP, "dc_head_fwd: C=%d > 256 (the C/4 lanes of a pixel must fit one wave)", C);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(head_blocks(pixels)), dim3(256), 0, (hipStream_t)stream, a, kh, bh, y, p,
+                     y ? partial : nullptr, pixels, C);
+  DC_CHECK_LAUNCH("dc_head_fwd");
+  return DC_OK;
+}
+extern "C" int dc_head_bwd(const float* a, const float* p, const uint8_t* y, const float* kh, float* da, float* partial,
+                           long pixels, int C, dc_stream_t stream) {
+  DC_REQUIRE(a && p && y && kh && da && partial && pixels > 0, DC_EINVAL, "dc_head_bwd: bad arguments");
+  int rc = chan_check("dc_head_bwd", C);
+  if (rc) return rc;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(head_blocks(pixels)), dim3(256), 0, (hipStream_t)stream, a, p, y, kh, da,
+                     partial, pixels, C);
+  DC_CHECK_LAUNCH("dc_head_bwd");
+  return DC_OK;
+}
+extern "C" int dc_head_grad_finalize(const float* partial, int blocks, int C, float* dkh, float* dbh, dc_stream_t stream) {
+  DC_REQUIRE(partial && dkh && dbh && blocks > 0 && C > 0, DC_EINVAL, "dc_head_grad_finalize: bad arguments");
+  hipLaunchKernelGGL(head_grad_finalize_kernel, dim3(dc_cdiv(C + 1, 256)), dim3(256), 0, (hipStream_t)stream, partial,
+                     blocks, C, dkh, dbh);
+  DC_CHECK_LAUNCH("dc_head_grad_finalize");
+  return DC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deterministic partial-sum reductions.
+// stage 1: grid (ceil(L/64), PY): block = 64 l x 4 p-lanes, each thread strides its p-chunk; stage 2 sums PY rows.
+__global__ __launch_bounds__(256) void reduce_stage1_kernel(const float* __restrict__ in, int P, long L, int chunk,
+                                                           float scale, float* __restrict__ out) {
+  __shared__ double sm[4][64];
+  const int lx = threadIdx.x & 63, pz = threadIdx.x >> 6;
+  const long l = (long)blockIdx.x * 64 + lx;
+  const int p0 = blockIdx.y * chunk, p1 = min(p0 + chunk, P);
+  double s = 0.0;
+  if (l < L)
+    for (int p = p0 + pz; p < p1; p += 4) s += (double)in[(long)p * L + l];
+  sm[pz][lx] = s;
+  __syncthreads();
+  if (pz == 0 && l < L) {
+    s = sm[0][lx] + sm[1][lx] + sm[2][lx] + sm[3][lx];
+    out[(long)blockIdx.y * L + l] = (float)(s * (gridDim.y == 1 ? (double)scale : 1.0));
+  }
+}
+__global__ __launch_bounds__(256) void reduce_stage2_kernel(const float* __restrict__ tmp, int PY, long L, float scale,
+                                                           float* __restrict__ out) {
+  const long l = blockIdx.x * 256L + threadIdx.x;
+  if (l >= L) return;
+  double s = 0.0;
+  for (int p = 0; p < PY; ++p) s += (double)tmp[(long)p * L + l];
+  out[l] = (float)(s * (double)scale);
+}
+
+extern "C" int dc_reduce_partials(const float* in, int P, long L, float scale, float* out, float* tmp,
+                                  dc_stream_t stream) {
+  DC_REQUIRE(in && out && P > 0 && L > 0, DC_EINVAL, "dc_reduce_partials: bad arguments");
+  int PY = P >= 64 ? 32 : 1;
+  DC_REQUIRE(PY == 1 || tmp, DC_EINVAL, "dc_reduce_partials: tmp scratch required for P >= 64");
+  const int chunk = dc_cdiv(P, PY);
+  PY = dc_cdiv(P, chunk);
+  dim3 grid((unsigned)dc_cdiv(L, 64), (unsigned)PY);
+  hipLaunchKernelGGL(reduce_stage1_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, P, L, chunk, scale,
+                     PY == 1 ? out : tmp);
+  DC_CHECK_LAUNCH("dc_reduce_partials");
+  if (PY > 1) {
+    hipLaunchKernelGGL(reduce_stage2_kernel, dim3(dc_cdiv(L, 256)), dim3(256), 0, (hipStream_t)stream, tmp, PY, L, scale, out);
+    DC_CHECK_LAUNCH("dc_reduce_partials(2)");
+  }
+  return DC_OK;
+}
+
+__global__ void reduce_f64_kernel(const float* __restrict__ in, int P, int L, double* __restrict__ out) {
+  __shared__ double sm[256];
+  const int l = blockIdx.x, tid = threadIdx.x;
+  double s = 0.0;
+  for (int p = tid; p < P; p += 256) s += (double)in[(long)p * L + l];
+  sm[tid] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (tid < k) sm[tid] += sm[tid + k];
+    __syncthreads();
+  }
+  if (tid == 0) out[l] = sm[0];
+}
+extern "C" int dc_reduce_partials_f64(const float* in, int P, int L, double* out, dc_stream_t stream) {
+  DC_REQUIRE(in && out && P > 0 && L > 0, DC_EINVAL, "dc_reduce_partials_f64: bad arguments");
+  hipLaunchKernelGGL(reduce_f64_kernel, dim3(L), dim3(256), 0, (hipStream_t)stream, in, P, L, out);
+  DC_CHECK_LAUNCH("dc_reduce_partials_f64");
+  return DC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Keras-2.0.6 Adam: eps outside the bias correction (lr_t carries the correction).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, long n, float lr_t, float b1, float b2, float eps,
+                                                  float gscale) {
+  const long n4 = n >> 2;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += gridDim.x * 256L) {
+    const f32x4 gg = ld4(g + 4 * i) * gscale;
+    f32x4 mm = ld4(m + 4 * i), vv = ld4(v + 4 * i), pp = ld4(p + 4 * i);
+    mm = b1 * mm + (1.f - b1) * gg;
+    vv = b2 * vv + (1.f - b2) * gg * gg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pp[e] -= lr_t * mm[e] / (sqrtf(vv[e]) + eps);
+    st4(m + 4 * i, mm); st4(v + 4 * i, vv); st4(p + 4 * i, pp);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (n4 << 2) + threadIdx.x;
+    const float gg = g[i] * gscale;
+    const float mm = b1 * m[i] + (1.f - b1) * gg, vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm; v[i] = vv;
+    p[i] -= lr_t * mm / (sqrtf(vv) + eps);
+  }
+}
+extern "C" int dc_adam_step_flat(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
+                                 float eps, float gscale, dc_stream_t stream) {
+  DC_REQUIRE(p && g && m && v && n > 0, DC_EINVAL, "dc_adam_step_flat: bad arguments");
+  DC_REQUIRE(dc_aligned16(p) && dc_aligned16(g) && dc_aligned16(m) && dc_aligned16(v), DC_EINVAL,
+             "dc_adam_step_flat: pointers must be 16-byte aligned");
+  const long n4 = (n + 3) / 4;
+  const int blocks = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, b1, b2, eps, gscale);
+  DC_CHECK_LAUNCH("dc_adam_step_flat");
+  return DC_OK;
+}
+
+__global__ void fill_kernel(float* p, long n, float value) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) p[i] = value;
+}
+extern "C" int dc_fill(float* p, long n, float value, dc_stream_t stream) {
+  DC_REQUIRE(p && n > 0, DC_EINVAL, "dc_fill: bad arguments");
+  const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, value);
+  DC_CHECK_LAUNCH("dc_fill");
+  return DC_OK;
+}

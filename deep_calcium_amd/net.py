@@ -1,0 +1,552 @@
+"""UNet2DS execution engine: orchestrates the libdcunet HIP kernels for one GPU.
+
+Mirrors the graph built by unet() at
+/root/reference/deepcalcium/models/neurons/unet_2d_summary.py:123-224 (topology, layer order, dropout
+placement, skip-concat order) -- the arithmetic itself is entirely in include/dcunet.h entry points.
+torch is used only as the device-memory container (torch.empty / data_ptr) and for the current stream.
+
+Memory plan (sized for 288 GB HBM: nothing is recomputed, nothing is pooled):
+  * all trainable parameters live in ONE flat fp32 buffer `pflat` in Keras get_weights() order
+    (kernel, bias, gamma, beta per layer) with matching flat `gflat` / Adam `mflat`,`vflat`, so the
+    optimizer is one launch and data-parallel training all-reduces one 31 MB message;
+  * skip-concat is free: the encoder block and the up-conv block of a level write straight into the two
+    channel halves of one `cat` buffer through the kernels' pixel-stride (ld) arguments;
+  * training keeps z (pre-BN) and the block outputs for backward; inference folds BN into the conv epilogue.
+"""
+import numpy as np
+import torch
+
+from ._lib import lib, DcunetError
+
+BN_EPS = 1e-3
+
+
+def _ptr(t, offset_floats=0):
+    return t.data_ptr() + 4 * offset_floats
+
+
+class LayerSpec(object):
+    __slots__ = ('name', 'kind', 'cin', 'cout', 'mom', 'lvl', 'drop', 'off', 'soff', 'index')
+
+    def __init__(self, name, kind, cin, cout, mom, lvl, drop, index):
+        self.name, self.kind, self.cin, self.cout, self.mom, self.lvl, self.drop, self.index = \
+            name, kind, cin, cout, mom, lvl, drop, index
+        self.off = {}    # trainable: 'k','b','gamma','beta' -> (offset, shape) in pflat
+        self.soff = {}   # moving stats: 'mmean','mvar' -> offset in sflat
+
+    @property
+    def kshape(self):
+        if self.kind == 'conv':
+            return (3, 3, self.cin, self.cout)
+        if self.kind == 'convT':
+            return (2, 2, self.cout, self.cin)
+        return (1, 1, self.cin, self.cout)
+
+
+def build_layer_table(nfb=32, drp=0.25):
+    """Weighted layers in graph-creation order (= Keras get_weights order), unet_2d_summary.py:172-221."""
+    enc = [nfb << i for i in range(5)]
+    rates = {'e1b': drp, 'e2b': 2 * drp, 'e3b': 2 * drp, 'u3': 2 * drp, 'u2': 2 * drp, 'u1': 2 * drp, 'u0': drp}
+    L = []
+    cin = 1
+    for lvl, c in enumerate(enc):
+        tag = 'b' if lvl == 4 else 'e%d' % lvl
+        for sfx, ci in (('a', cin), ('b', c)):
+            L.append(LayerSpec(tag + sfx, 'conv', ci, c, 0.99, lvl, rates.get(tag + sfx, 0.0), len(L)))
+        cin = c
+    for lvl in (3, 2, 1, 0):
+        c = enc[lvl]
+        L.append(LayerSpec('u%d' % lvl, 'convT', 2 * c, c, 0.5, lvl, rates.get('u%d' % lvl, 0.0), len(L)))
+        L.append(LayerSpec('d%da' % lvl, 'conv', 2 * c, c, 0.99, lvl, 0.0, len(L)))
+        L.append(LayerSpec('d%db' % lvl, 'conv', c, c, 0.99, lvl, 0.0, len(L)))
+    L.append(LayerSpec('out', 'head', nfb, 2, None, 0, 0.0, len(L)))
+    return L
+
+
+class UNetEngine(object):
+    def __init__(self, window_shape, nb_filters_base=32, prop_dropout_base=0.25, device=None, seed=7535):
+        H, W = window_shape
+        if H % 16 or W % 16:
+            raise ValueError('window_shape must be a multiple of 16 (4 max-pools), got %r' % (window_shape,))
+        nfb = nb_filters_base
+        if nfb < 4 or nfb & (nfb - 1) or nfb > 64:
+            raise ValueError('nb_filters_base must be a power of two in [4, 64]')
+        if not torch.cuda.is_available():
+            raise DcunetError('no GPU visible: the UNet2DS engine has no CPU fallback')
+        self.L = lib()
+        self.H, self.W, self.nfb, self.drp = H, W, nfb, float(prop_dropout_base)
+        self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        self.layers = build_layer_table(nfb, self.drp)
+        self.by_name = {l.name: l for l in self.layers}
+        # ---- flat parameter layout -----------------------------------------------------------------
+        off = 0
+        soff = 0
+        for l in self.layers:
+            l.off['k'] = (off, l.kshape); off += int(np.prod(l.kshape))
+            l.off['b'] = (off, (l.cout,)); off += l.cout
+            if l.kind != 'head':
+                l.off['gamma'] = (off, (l.cout,)); off += l.cout
+                l.off['beta'] = (off, (l.cout,)); off += l.cout
+                l.soff['mmean'] = soff; soff += l.cout
+                l.soff['mvar'] = soff; soff += l.cout
+        self.n_train = off
+        self.n_stats = soff
+        npad = (off + 3) // 4 * 4
+        dev = self.device
+        self.pflat = torch.zeros(npad, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(npad, dtype=torch.float32, device=dev)
+        self.mflat = torch.zeros(npad, dtype=torch.float32, device=dev)
+        self.vflat = torch.zeros(npad, dtype=torch.float32, device=dev)
+        self.sflat = torch.zeros(soff, dtype=torch.float32, device=dev)
+        # per-layer batch statistics / folded affine (scale, shift), each [cout]
+        self.bstat = torch.zeros(4 * soff // 2 + 8, dtype=torch.float32, device=dev)
+        self._stat_off = {}
+        o = 0
+        for l in self.layers:
+            if l.kind != 'head':
+                self._stat_off[l.name] = o   # mean, invstd, scale, shift : 4 * cout
+                o += 4 * l.cout
+        # packed weights
+        self.wp_fwd, self.wp_dgrad = {}, {}
+        for l in self.layers:
+            if l.kind == 'head' or (l.kind == 'conv' and l.cin == 1):
+                continue
+            n = int(np.prod(l.kshape))
+            self.wp_fwd[l.name] = torch.empty(n, dtype=torch.float32, device=dev)
+            self.wp_dgrad[l.name] = torch.empty(n, dtype=torch.float32, device=dev)
+        self._bufs = {}
+        self._packed_dirty = True
+        self._fold_dirty = True
+        self.iterations = 0
+        self.drop_seed = 0x5eed0000 + seed
+        self.set_weights(self.initial_weights(seed))
+
+    # ---- parameters ---------------------------------------------------------------------------------
+    def initial_weights(self, seed=7535):
+        """he_normal (truncated, fan_in) conv kernels, glorot-uniform head, BN identity."""
+        rs = np.random.RandomState(seed)
+
+        def tn(shape, std):
+            out = rs.standard_normal(shape)
+            bad = np.abs(out) > 2
+            while bad.any():
+                out[bad] = rs.standard_normal(int(bad.sum()))
+                bad = np.abs(out) > 2
+            return (out * std).astype(np.float32)
+
+        W = []
+        for l in self.layers:
+            if l.kind == 'conv':
+                W.append(tn(l.kshape, np.sqrt(2.0 / (9 * l.cin))))
+            elif l.kind == 'convT':
+                W.append(tn(l.kshape, np.sqrt(2.0 / (4 * l.cout))))   # Keras fan_in quirk for (2,2,Cout,Cin)
+            else:
+                lim = np.sqrt(6.0 / (l.cin + l.cout))
+                W.append(rs.uniform(-lim, lim, l.kshape).astype(np.float32))
+            W.append(np.zeros(l.cout, np.float32))
+            if l.kind != 'head':
+                W += [np.ones(l.cout, np.float32), np.zeros(l.cout, np.float32),
+                      np.zeros(l.cout, np.float32), np.ones(l.cout, np.float32)]
+        return W
+
+    def weight_shapes(self):
+        out = []
+        for l in self.layers:
+            out += [l.kshape, (l.cout,)]
+            if l.kind != 'head':
+                out += [(l.cout,)] * 4
+        return out
+
+    def get_weights(self):
+        """Keras get_weights(): 134 arrays, [kernel, bias, gamma, beta, moving_mean, moving_variance] per layer."""
+        p = self.pflat.cpu().numpy()
+        s = self.sflat.cpu().numpy()
+        out = []
+        for l in self.layers:
+            for key in ('k', 'b', 'gamma', 'beta'):
+                if key in l.off:
+                    o, shp = l.off[key]
+                    out.append(p[o:o + int(np.prod(shp))].reshape(shp).copy())
+            if l.kind != 'head':
+                out.append(s[l.soff['mmean']:l.soff['mmean'] + l.cout].copy())
+                out.append(s[l.soff['mvar']:l.soff['mvar'] + l.cout].copy())
+        return out
+
+    def set_weights(self, weights):
+        shapes = self.weight_shapes()
+        if len(weights) != len(shapes):
+            raise ValueError('expected %d weight arrays, got %d' % (len(shapes), len(weights)))
+        p = np.zeros(self.pflat.numel(), np.float32)
+        s = np.zeros(self.n_stats, np.float32)
+        i = 0
+        for l in self.layers:
+            for key in ('k', 'b', 'gamma', 'beta'):
+                if key in l.off:
+                    o, shp = l.off[key]
+                    w = np.asarray(weights[i], np.float32)
+                    if tuple(w.shape) != tuple(shp):
+                        raise ValueError('weight %d (%s.%s): shape %r != %r' % (i, l.name, key, w.shape, shp))
+                    p[o:o + w.size] = w.ravel()
+                    i += 1
+            if l.kind != 'head':
+                for key in ('mmean', 'mvar'):
+                    w = np.asarray(weights[i], np.float32)
+                    s[l.soff[key]:l.soff[key] + l.cout] = w.ravel()
+                    i += 1
+        self.pflat.copy_(torch.from_numpy(p))
+        self.sflat.copy_(torch.from_numpy(s))
+        self._packed_dirty = True
+        self._fold_dirty = True
+
+    def pview(self, flat, l, key):
+        o, shp = l.off[key]
+        return _ptr(flat, o)
+
+    def sview(self, l, key):
+        return _ptr(self.sflat, l.soff[key])
+
+    def stat_ptr(self, l, which):
+        """which: 0 mean, 1 invstd, 2 scale, 3 shift"""
+        return _ptr(self.bstat, self._stat_off[l.name] + which * l.cout)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def buf(self, name, numel, dtype=torch.float32):
+        t = self._bufs.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = torch.empty(int(numel), dtype=dtype, device=self.device)
+            self._bufs[name] = t
+        return t
+
+    def repack(self):
+        """HWIO / (2,2,Cout,Cin) kernels -> the [tap][K/4][N][4] layouts of the implicit-GEMM kernels."""
+        if not self._packed_dirty:
+            return
+        L, st = self.L, self._stream()
+        for l in self.layers:
+            if l.name not in self.wp_fwd:
+                continue
+            src = self.pview(self.pflat, l, 'k')
+            ci, co = l.cin, l.cout
+            if l.kind == 'conv':
+                L.dc_pack_weights(src, _ptr(self.wp_fwd[l.name]), 9, ci, co, ci * co, co, 1, 0, st)
+                L.dc_pack_weights(src, _ptr(self.wp_dgrad[l.name]), 9, co, ci, ci * co, 1, co, 1, st)
+            else:
+                L.dc_pack_weights(src, _ptr(self.wp_fwd[l.name]), 1, ci, 4 * co, 0, 1, ci, 0, st)
+                L.dc_pack_weights(src, _ptr(self.wp_dgrad[l.name]), 4, co, ci, co * ci, ci, 1, 0, st)
+        self._packed_dirty = False
+
+    def refold(self):
+        if not self._fold_dirty:
+            return
+        L, st = self.L, self._stream()
+        for l in self.layers:
+            if l.kind == 'head':
+                continue
+            L.dc_bn_fold(self.pview(self.pflat, l, 'gamma'), self.pview(self.pflat, l, 'beta'),
+                         self.sview(l, 'mmean'), self.sview(l, 'mvar'), self.pview(self.pflat, l, 'b'),
+                         BN_EPS, self.stat_ptr(l, 2), self.stat_ptr(l, 3), l.cout, st)
+        self._fold_dirty = False
+
+    # ---- geometry helpers --------------------------------------------------------------------------------
+    def _hw(self, lvl):
+        return self.H >> lvl, self.W >> lvl
+
+    def _acts(self, N):
+        """Activation tensors for batch size N (allocated once per N)."""
+        key = ('acts', N)
+        A = self._bufs.get(key)
+        if A is not None:
+            return A
+        A = {}
+        nfb = self.nfb
+        dev = self.device
+
+        def new(*shape, dtype=torch.float32):
+            return torch.empty(shape, dtype=dtype, device=dev)
+
+        for lvl in range(5):
+            h, w = self._hw(lvl)
+            c = nfb << lvl
+            tag = 'b' if lvl == 4 else 'e%d' % lvl
+            A[tag + 'a'] = new(N, h, w, c)
+            if lvl < 4:
+                A['cat%d' % lvl] = new(N, h, w, 2 * c)      # [up path | skip]  (unet_2d_summary.py:200)
+                A['pool%d' % lvl] = new(N, h // 2, w // 2, c)
+                A['idx%d' % lvl] = new(N, h // 2, w // 2, c, dtype=torch.uint8)
+                A['d%da' % lvl] = new(N, h, w, c)
+                A['d%db' % lvl] = new(N, h, w, c)
+            else:
+                A['bb'] = new(N, h, w, c)
+        A['p'] = new(N, self.H, self.W)
+        self._bufs[key] = A
+        return A
+
+    def _plan(self, A):
+        """(layer, input tensor, output tensor, output channel offset, output ld, h, w) in execution order."""
+        plan = []
+        nfb = self.nfb
+        prev = None
+        for lvl in range(5):
+            h, w = self._hw(lvl)
+            c = nfb << lvl
+            tag = 'b' if lvl == 4 else 'e%d' % lvl
+            la, lb = self.by_name[tag + 'a'], self.by_name[tag + 'b']
+            plan.append(('block', la, prev, A[tag + 'a'], 0, c, h, w))
+            if lvl < 4:
+                plan.append(('block', lb, A[tag + 'a'], A['cat%d' % lvl], c, 2 * c, h, w))
+                plan.append(('pool', lvl, A['cat%d' % lvl], c, 2 * c, h, w))
+                prev = A['pool%d' % lvl]
+            else:
+                plan.append(('block', lb, A[tag + 'a'], A['bb'], 0, c, h, w))
+                prev = A['bb']
+        for lvl in (3, 2, 1, 0):
+            h, w = self._hw(lvl)
+            c = nfb << lvl
+            lu, la, lb = self.by_name['u%d' % lvl], self.by_name['d%da' % lvl], self.by_name['d%db' % lvl]
+            plan.append(('block', lu, prev, A['cat%d' % lvl], 0, 2 * c, h, w))   # convT: h,w are OUTPUT dims
+            plan.append(('block', la, A['cat%d' % lvl], A['d%da' % lvl], 0, c, h, w))
+            plan.append(('block', lb, A['d%da' % lvl], A['d%db' % lvl], 0, c, h, w))
+            prev = A['d%db' % lvl]
+        return plan
+
+    # ---- inference ---------------------------------------------------------------------------------------
+    def forward_infer(self, x_dev):
+        """x_dev: float32 cuda tensor (N,H,W) -> p: (N,H,W) probabilities (BN folded into the conv epilogue)."""
+        N = x_dev.shape[0]
+        assert tuple(x_dev.shape[1:]) == (self.H, self.W) and x_dev.dtype == torch.float32 and x_dev.is_contiguous()
+        L, st = self.L, self._stream()
+        self.repack()
+        self.refold()
+        A = self._acts(N)
+        for step in self._plan(A):
+            if step[0] == 'pool':
+                _, lvl, src, coff, ld, h, w = step
+                L.dc_maxpool2x2_fwd(_ptr(src, coff), ld, _ptr(A['pool%d' % lvl]), None, N, h, w, self.nfb << lvl, st)
+                continue
+            _, l, src, dst, coff, ld, h, w = step
+            sc, sh = self.stat_ptr(l, 2), self.stat_ptr(l, 3)
+            if l.kind == 'conv' and l.cin == 1:
+                L.dc_conv3x3_c1_fwd(_ptr(x_dev), self.pview(self.pflat, l, 'k'), None, _ptr(dst, coff), ld, None,
+                                    sc, sh, 1, N, h, w, l.cout, st)
+            elif l.kind == 'conv':
+                L.dc_conv3x3_fwd(_ptr(src), _ptr(self.wp_fwd[l.name]), None, _ptr(dst, coff), ld, None, sc, sh, 1,
+                                 N, h, w, l.cin, l.cout, st)
+            else:
+                L.dc_convT2x2_fwd(_ptr(src), _ptr(self.wp_fwd[l.name]), None, _ptr(dst, coff), ld, None, sc, sh, 1,
+                                  N, h // 2, w // 2, l.cin, l.cout, st)
+        lo = self.by_name['out']
+        L.dc_head_fwd(_ptr(A['d0b']), self.pview(self.pflat, lo, 'k'), self.pview(self.pflat, lo, 'b'), None,
+                      _ptr(A['p']), None, N * self.H * self.W, self.nfb, st)
+        return A['p']
+
+    # ---- training ----------------------------------------------------------------------------------------
+    def _train_bufs(self, N):
+        key = ('train', N)
+        T = self._bufs.get(key)
+        if T is not None:
+            return T
+        L = self.L
+        T = {}
+        dev = self.device
+        nfb = self.nfb
+        ws_floats, stats_floats, part_floats = 0, 0, 0
+        for l in self.layers:
+            if l.kind == 'head':
+                continue
+            h, w = self._hw(l.lvl)
+            T['z_' + l.name] = torch.empty((N, h, w, l.cout), dtype=torch.float32, device=dev)
+            if l.kind == 'conv':
+                tiles = L.dc_conv3x3_c1_tiles(N, h, w, l.cout) if l.cin == 1 else L.dc_conv3x3_tiles(N, h, w, l.cout)
+                stats_floats = max(stats_floats, tiles * l.cout * 2)
+                ws_floats = max(ws_floats, L.dc_conv3x3_wgrad_ws_floats(N, h, w, l.cin, l.cout))
+            else:
+                tiles = L.dc_convT2x2_tiles(N, h // 2, w // 2, l.cout)
+                stats_floats = max(stats_floats, tiles * 4 * l.cout * 2)
+                ws_floats = max(ws_floats, L.dc_convT2x2_wgrad_ws_floats(N, h // 2, w // 2, l.cin, l.cout))
+            blocks = L.dc_bn_bwd_blocks(N * h * w, l.cout)
+            part_floats = max(part_floats, blocks * l.cout * 2)
+        hb = L.dc_head_blocks(N * self.H * self.W)
+        part_floats = max(part_floats, hb * (nfb + 4), hb * 8)
+        T['stats_ws'] = torch.empty(stats_floats, dtype=torch.float32, device=dev)
+        T['part_ws'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
+        T['part_ws2'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
+        T['red_tmp'] = torch.empty(32 * 1024, dtype=torch.float32, device=dev)
+        T['wgrad_ws'] = torch.empty(ws_floats, dtype=torch.float32, device=dev)
+        T['sums'] = torch.zeros(8, dtype=torch.float64, device=dev)
+        big = N * self.H * self.W * nfb
+        T['dz'] = torch.empty(big, dtype=torch.float32, device=dev)
+        T['gA'] = torch.empty(big, dtype=torch.float32, device=dev)
+        T['gB'] = torch.empty(big, dtype=torch.float32, device=dev)
+        for lvl in range(4):
+            h, w = self._hw(lvl)
+            T['dcat%d' % lvl] = torch.empty(N * h * w * 2 * (nfb << lvl), dtype=torch.float32, device=dev)
+        self._bufs[key] = T
+        return T
+
+    def _drop_args(self, l, masks, step_seed):
+        if l.drop <= 0.0:
+            return None, 1.0, 0
+        keep = 1.0 - l.drop
+        if masks is not None:
+            m = masks[l.name]
+            assert m.dtype == torch.uint8 and m.is_contiguous()
+            return m.data_ptr(), keep, 0
+        return None, keep, (step_seed * 1000003 + l.index * 7919) & 0xFFFFFFFFFFFFFFFF
+
+    def forward_train(self, x_dev, y_dev, masks=None, update_moving=True):
+        """Training-mode forward (batch statistics, dropout).  Returns p; loss/metric sums land in T['sums']."""
+        N = x_dev.shape[0]
+        L, st = self.L, self._stream()
+        self.repack()
+        A, T = self._acts(N), self._train_bufs(N)
+        step_seed = self.drop_seed + self.iterations
+        self._last = (N, masks, step_seed, x_dev, y_dev)
+        for step in self._plan(A):
+            if step[0] == 'pool':
+                _, lvl, src, coff, ld, h, w = step
+                L.dc_maxpool2x2_fwd(_ptr(src, coff), ld, _ptr(A['pool%d' % lvl]), A['idx%d' % lvl].data_ptr(),
+                                    N, h, w, self.nfb << lvl, st)
+                continue
+            _, l, src, dst, coff, ld, h, w = step
+            z = T['z_' + l.name]
+            bias = self.pview(self.pflat, l, 'b')
+            stats = _ptr(T['stats_ws'])
+            groups = 1
+            if l.kind == 'conv' and l.cin == 1:
+                tiles = L.dc_conv3x3_c1_tiles(N, h, w, l.cout)
+                L.dc_conv3x3_c1_fwd(_ptr(x_dev), self.pview(self.pflat, l, 'k'), bias, _ptr(z), l.cout, stats,
+                                    None, None, 0, N, h, w, l.cout, st)
+            elif l.kind == 'conv':
+                tiles = L.dc_conv3x3_tiles(N, h, w, l.cout)
+                L.dc_conv3x3_fwd(_ptr(src), _ptr(self.wp_fwd[l.name]), bias, _ptr(z), l.cout, stats, None, None, 0,
+                                 N, h, w, l.cin, l.cout, st)
+            else:
+                tiles = L.dc_convT2x2_tiles(N, h // 2, w // 2, l.cout)
+                groups = 4
+                L.dc_convT2x2_fwd(_ptr(src), _ptr(self.wp_fwd[l.name]), bias, _ptr(z), l.cout, stats, None, None, 0,
+                                  N, h // 2, w // 2, l.cin, l.cout, st)
+            pixels = N * h * w
+            mom = l.mom if update_moving else -1.0
+            L.dc_bn_stats_finalize(stats, tiles, groups, l.cout, float(pixels), BN_EPS, mom,
+                                   self.stat_ptr(l, 0), self.stat_ptr(l, 1), self.sview(l, 'mmean'),
+                                   self.sview(l, 'mvar'), st)
+            mptr, keep, seed = self._drop_args(l, masks, step_seed)
+            L.dc_bn_relu_drop_fwd(_ptr(z), self.stat_ptr(l, 0), self.stat_ptr(l, 1),
+                                  self.pview(self.pflat, l, 'gamma'), self.pview(self.pflat, l, 'beta'),
+                                  mptr, keep, seed, _ptr(dst, coff), ld, pixels, l.cout, st)
+        if update_moving:
+            self._fold_dirty = True
+        lo = self.by_name['out']
+        pixels = N * self.H * self.W
+        hb = L.dc_head_blocks(pixels)
+        L.dc_head_fwd(_ptr(A['d0b']), self.pview(self.pflat, lo, 'k'), self.pview(self.pflat, lo, 'b'),
+                      y_dev.data_ptr(), _ptr(A['p']), _ptr(T['part_ws']), pixels, self.nfb, st)
+        L.dc_reduce_partials_f64(_ptr(T['part_ws']), hb, 8, T['sums'].data_ptr(), st)
+        return A['p']
+
+    def backward(self):
+        """Backward of the last forward_train: fills gflat (same layout as pflat)."""
+        N, masks, step_seed, x_dev, y_dev = self._last
+        L, st = self.L, self._stream()
+        A, T = self._acts(N), self._train_bufs(N)
+        nfb = self.nfb
+        pixels0 = N * self.H * self.W
+        lo = self.by_name['out']
+        hb = L.dc_head_blocks(pixels0)
+        L.dc_head_bwd(_ptr(A['d0b']), _ptr(A['p']), y_dev.data_ptr(), self.pview(self.pflat, lo, 'k'),
+                      _ptr(T['gA']), _ptr(T['part_ws']), pixels0, nfb, st)
+        L.dc_head_grad_finalize(_ptr(T['part_ws']), hb, nfb, self.pview(self.gflat, lo, 'k'),
+                                self.pview(self.gflat, lo, 'b'), st)
+
+        def block_bwd(l, x_in, da_ptr, da_ld, dx_ptr):
+            """da (strided) -> grads of l; dx written to dx_ptr (dense [.., cin]) unless None."""
+            h, w = self._hw(l.lvl)
+            pixels = N * h * w
+            z = T['z_' + l.name]
+            mptr, keep, seed = self._drop_args(l, masks, step_seed)
+            mean, invstd = self.stat_ptr(l, 0), self.stat_ptr(l, 1)
+            gamma, beta = self.pview(self.pflat, l, 'gamma'), self.pview(self.pflat, l, 'beta')
+            dgamma, dbeta = self.pview(self.gflat, l, 'gamma'), self.pview(self.gflat, l, 'beta')
+            blocks = L.dc_bn_bwd_blocks(pixels, l.cout)
+            L.dc_bn_bwd_reduce(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed,
+                               _ptr(T['part_ws']), pixels, l.cout, st)
+            L.dc_bn_bwd_finalize(_ptr(T['part_ws']), blocks, l.cout, dgamma, dbeta, st)
+            L.dc_bn_bwd_apply(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed, dgamma, dbeta,
+                              _ptr(T['dz']), _ptr(T['part_ws2']), pixels, l.cout, st)
+            L.dc_reduce_partials(_ptr(T['part_ws2']), blocks, l.cout, 1.0, self.pview(self.gflat, l, 'b'),
+                                 _ptr(T['red_tmp']), st)
+            dk = self.pview(self.gflat, l, 'k')
+            if l.kind == 'conv':
+                L.dc_conv3x3_wgrad(x_in, _ptr(T['dz']), dk, _ptr(T['wgrad_ws']), N, h, w, l.cin, l.cout, st)
+                if dx_ptr is not None:
+                    L.dc_conv3x3_dgrad(_ptr(T['dz']), _ptr(self.wp_dgrad[l.name]), dx_ptr, N, h, w, l.cin, l.cout, st)
+            else:
+                L.dc_convT2x2_wgrad(x_in, _ptr(T['dz']), dk, _ptr(T['wgrad_ws']), N, h // 2, w // 2, l.cin, l.cout, st)
+                if dx_ptr is not None:
+                    L.dc_convT2x2_dgrad(_ptr(T['dz']), _ptr(self.wp_dgrad[l.name]), dx_ptr, N, h // 2, w // 2,
+                                        l.cin, l.cout, st)
+
+        g, other = T['gA'], T['gB']      # g holds the gradient w.r.t. the current block's output
+        for lvl in (0, 1, 2, 3):
+            c = nfb << lvl
+            cat, dcat = A['cat%d' % lvl], T['dcat%d' % lvl]
+            block_bwd(self.by_name['d%db' % lvl], _ptr(A['d%da' % lvl]), _ptr(g), c, _ptr(other))
+            g, other = other, g
+            block_bwd(self.by_name['d%da' % lvl], _ptr(cat), _ptr(g), c, _ptr(dcat))
+            x_up = A['bb'] if lvl == 3 else A['d%db' % (lvl + 1)]
+            block_bwd(self.by_name['u%d' % lvl], _ptr(x_up), _ptr(dcat), 2 * c, _ptr(g))
+        for lvl in (4, 3, 2, 1, 0):
+            c = nfb << lvl
+            h, w = self._hw(lvl)
+            tag = 'b' if lvl == 4 else 'e%d' % lvl
+            if lvl < 4:
+                # g = d(pool output); route through the argmax and add the skip gradient (second half of dcat)
+                L.dc_maxpool2x2_bwd(_ptr(g), A['idx%d' % lvl].data_ptr(), _ptr(T['dcat%d' % lvl], c), 2 * c,
+                                    _ptr(other), N, h, w, c, st)
+                g, other = other, g
+            block_bwd(self.by_name[tag + 'b'], _ptr(A[tag + 'a']), _ptr(g), c, _ptr(other))
+            g, other = other, g
+            if lvl == 0:
+                block_bwd(self.by_name['e0a'], _ptr(x_dev), _ptr(g), c, None)
+            else:
+                block_bwd(self.by_name[tag + 'a'], _ptr(A['pool%d' % (lvl - 1)]), _ptr(g), c, _ptr(other))
+                g, other = other, g
+
+    def adam_step(self, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-8, grad_scale=1.0):
+        """Keras-2.0.6 Adam over the flat buffers; `iterations` counts completed steps."""
+        t = self.iterations + 1
+        lr_t = lr * np.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t)
+        self.L.dc_adam_step_flat(_ptr(self.pflat), _ptr(self.gflat), _ptr(self.mflat), _ptr(self.vflat),
+                                 self.n_train, float(lr_t), beta_1, beta_2, epsilon, float(grad_scale), self._stream())
+        self.iterations = t
+        self._packed_dirty = True
+        self._fold_dirty = True
+
+    def read_sums(self):
+        """Host copy of the 8 loss/metric sums of the last forward_train (synchronises the stream)."""
+        N = self._last[0]
+        return self._train_bufs(N)['sums'].cpu().numpy().copy()
+
+    def grads(self):
+        """gflat split per layer: {name: [dk, db, dgamma, dbeta]} (host numpy)."""
+        g = self.gflat.cpu().numpy()
+        out = {}
+        for l in self.layers:
+            out[l.name] = []
+            for key in ('k', 'b', 'gamma', 'beta'):
+                if key in l.off:
+                    o, shp = l.off[key]
+                    out[l.name].append(g[o:o + int(np.prod(shp))].reshape(shp).copy())
+        return out
+
+    def batch_stats(self):
+        """Last training forward's (mean, invstd) per layer (host numpy)."""
+        b = self.bstat.cpu().numpy()
+        out = {}
+        for l in self.layers:
+            if l.kind != 'head':
+                o = self._stat_off[l.name]
+                out[l.name] = (b[o:o + l.cout].copy(), b[o + l.cout:o + 2 * l.cout].copy())
+        return out

