@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""bench.py -- 512x512 summary images/sec for one UNet2DS train step (fwd + BCE + bwd + Adam) on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Workload = BASELINE.json configs[2] per GPU (batch 16 of 512x512, fp32), i.e. configs[3] (global batch 128) at
+8 GPUs: weak scaling, one process per GPU, gradients all-reduced over RCCL.  Inputs are synthetic
+(x ~ N(0,1), y ~ Bernoulli(0.126)), random-init weights, resident in HBM before the timed region.
+Rank 0 prints ONE JSON line: metric/value (whole-job images/s) + `roofline` for the dominant kernel
+(measured live with HIP events on the launch stream) + `cpu_baseline` (oracle port timed on the host cores).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+BATCH_PER_GPU = 16
+H = W = 512
+NFB = 32
+
+
+class KernelTimer(object):
+    """Proxy around the C-ABI library that brackets every launch of ONE kernel symbol with HIP events
+    (recorded on the stream the kernel is launched on) and tallies its algorithmic FLOPs."""
+
+    # the conv3x3 implicit-GEMM instantiation igemm_kernel<3,3,1,1,32,4,2,2,16> (256 px x 64 cols tiles) is what
+    # dc_conv3x3_fwd / dc_conv3x3_dgrad launch whenever W > 16 and the output has > 32 columns (csrc/igemm_conv.hip)
+    KERNEL = 'igemm_kernel<3,3,1,1,TW=32,WAVES_M=4,MB=2,NB=2,CK=16> (conv3x3 fwd+dgrad, 256px x 64col tiles)'
+
+    def __init__(self, lib):
+        self._lib = lib
+        self.records = []
+        self.enabled = False
+
+    def _is_dominant(self, name, args):
+        if name == 'dc_conv3x3_fwd':
+            N, Hh, Ww, Cin, Cout = args[9:14]
+            return Ww > 16 and Cout > 32, 2.0 * 9 * Cin * Cout * N * Hh * Ww
+        if name == 'dc_conv3x3_dgrad':
+            N, Hh, Ww, Cin, Cout = args[3:8]
+            return Ww > 16 and Cin > 32, 2.0 * 9 * Cin * Cout * N * Hh * Ww
+        return False, 0.0
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name not in ('dc_conv3x3_fwd', 'dc_conv3x3_dgrad'):
+            return fn
+
+        def wrapped(*args):
+            hit, flops = self._is_dominant(name, args) if self.enabled else (False, 0.0)
+            if not hit:
+                return fn(*args)
+            e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+            self._lib.dc_event_create(ctypes.byref(e0))
+            self._lib.dc_event_create(ctypes.byref(e1))
+            stream = args[-1]
+            self._lib.dc_event_record(e0, stream)
+            rc = fn(*args)
+            self._lib.dc_event_record(e1, stream)
+            self.records.append((e0, e1, flops))
+            return rc
+        return wrapped
+
+    def summarize(self):
+        tot_ms, tot_flops = 0.0, 0.0
+        for e0, e1, flops in self.records:
+            ms = ctypes.c_float()
+            self._lib.dc_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+            tot_ms += ms.value
+            tot_flops += flops
+            self._lib.dc_event_destroy(e0)
+            self._lib.dc_event_destroy(e1)
+        n = len(self.records)
+        self.records = []
+        return n, tot_ms, tot_flops
+
+
+def cpu_baseline():
+    """The oracle port (oracle/unet_torch.py: torch-CPU fp32, all host threads, same graph/optimizer) on a bounded
+    sample of the same workload: 2 train steps at batch 4 of 512x512 after a batch-1 warm-up."""
+    import torch
+    from oracle import unet_numpy as on
+    from oracle.unet_torch import UNetTorch
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    Wt = on.init_weights(NFB)
+    net = UNetTorch(Wt, NFB, dtype=torch.float32)
+    state = dict(it=0, m={}, v={})
+    bs = 4
+    x, y = on.synthetic_batch(bs, H, W)
+    masks = on.make_drop_masks(NFB, bs, H, W)
+    net.train_step(x[:1], y[:1], state, {k: v[:1] for k, v in masks.items()})
+    steps = 2
+    t0 = time.time()
+    for _ in range(steps):
+        net.train_step(x, y, state, masks)
+    dt = time.time() - t0
+    return {'value': round(steps * bs / dt, 4), 'unit': 'images/s', 'cores': int(torch.get_num_threads()),
+            'kind': 'port',
+            'sample': '%d train steps (fwd+bwd+Keras-Adam), batch %d of 512x512 fp32, oracle/unet_torch.py on torch-CPU/oneDNN '
+                      '(Keras 2.0.6/TF 1.2.1 not installable offline); %.1f s' % (steps, bs, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='per-GPU batch (default 16 = BASELINE config)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    from deep_calcium_amd import parallel
+    from deep_calcium_amd.model import Model, Adam
+    from oracle import unet_numpy as on
+
+    rank, world = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    B = args.batch
+    model = Model((H, W), NFB, device=dev)
+    model.compile(Adam(0.002), 'binary_crossentropy')
+    eng = model.engine
+    parallel.broadcast_params(eng.pflat, eng.sflat)
+    # synthetic shard of the global batch, resident in HBM (SURVEY 8d seeds, offset per rank)
+    x, y = on.synthetic_batch(B, H, W, seed_x=865 + 1000 * rank, seed_y=866 + 1000 * rank)
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+
+    timer = KernelTimer(eng.L)
+    eng.L = timer
+
+    for _ in range(args.warmup):
+        model.train_on_device_batch(xd, yd)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        vals = model.train_on_device_batch(xd, yd)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    parallel.all_reduce_max(tmax)
+    dt = float(tmax.item())
+
+    # ---- roofline of the dominant kernel: 2 instrumented steps outside the timed region --------------------
+    timer.enabled = True
+    for _ in range(2):
+        model.train_on_device_batch(xd, yd)
+    torch.cuda.synchronize()
+    n_launch, k_ms, k_flops = timer.summarize()
+    timer.enabled = False
+
+    if rank == 0:
+        achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get('bytes_per_launch')
+            except Exception:
+                traffic = None
+        out = {
+            'metric': '512x512 summary images/sec (train step)', 'value': round(world * B * args.steps / dt, 3),
+            'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'UNet2DS train step (fwd+BCE+bwd+Keras-Adam), batch=%d 512x512 per GPU, nfb=32 '
+                                   '(BASELINE.json configs[2]; configs[3] at 8 GPUs)' % B,
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'bn': 'local',
+                       'loss': float(vals[0])},
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                         'kernel': KernelTimer.KERNEL, 'launches': n_launch,
+                         'avg_launch_ms': round(k_ms / max(n_launch, 1), 4),
+                         'algorithmic_flops_per_launch': round(k_flops / max(n_launch, 1))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,387 @@
+"""Keras-`Model`-shaped front end over the HIP UNet2DS engine.
+
+This is the object the reference's plug-point expects: `UNet2DSummary(net_builder_func=...)` calls
+`net_builder_func(window_shape)` (/root/reference/deepcalcium/models/neurons/unet_2d_summary.py:316-318,
+:392-393) and then drives the result only through the Keras duck-type listed in SURVEY 8(b):
+summary / compile / fit_generator / predict / input_shape / get_weights / set_weights / save, callbacks with a
+shared mutable `logs` dict, `model.optimizer.lr`.  `unet_hip` has the signature of the reference's `unet()`
+(:123-124).  Behaviour restated from Keras 2.0.6 (un-vendored).
+"""
+from __future__ import division, print_function
+
+import csv
+import json
+import os
+import queue
+import threading
+import time
+
+import numpy as np
+import torch
+
+from .net import UNetEngine
+from . import parallel
+
+K_EPS = 1e-7
+METRIC_NAMES = ['F1', 'prec', 'reca', 'dice', 'dicesq', 'posyt', 'posyp']
+
+
+def metrics_from_sums(s, count):
+    """The loss + 7 compile() metrics (deepcalcium/utils/neurons.py:32-50,70-75,86-90,97-106) from the head
+    kernel's 8 sums {bce, tp, sum round(p), fn, sum y, sum y*p, sum p^2, sum y^2} over `count` pixels."""
+    bce, tp, spr, fn, sy, syp, sp2, sy2 = [float(v) for v in s]
+    prec = tp / (spr + K_EPS)
+    reca = tp / (tp + fn + K_EPS)
+    return {
+        'loss': bce / count,
+        'F1': 2 * prec * reca / (prec + reca + K_EPS),
+        'prec': prec,
+        'reca': reca,
+        'dice': 2 * tp / (sy + spr + 1e-7),
+        'dicesq': 2 * syp / (sy2 + sp2 + K_EPS),
+        'posyt': sy / (count + K_EPS),
+        'posyp': spr / (count + K_EPS),
+    }
+
+
+class Adam(object):
+    """keras.optimizers.Adam(lr) state holder; the update itself is dc_adam_step_flat (Keras-2.0.6 form)."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-8, decay=0.0):
+        if decay:
+            raise NotImplementedError('Adam(decay != 0) is not used by the reference path')
+        self.lr, self.beta_1, self.beta_2, self.epsilon = float(lr), beta_1, beta_2, epsilon
+
+    def get_config(self):
+        return dict(lr=self.lr, beta_1=self.beta_1, beta_2=self.beta_2, epsilon=self.epsilon)
+
+
+# ---- callbacks (keras.callbacks protocol) -----------------------------------------------------------------
+class Callback(object):
+    def __init__(self):
+        self.model = None
+        self.params = {}
+
+    def set_model(self, model):
+        self.model = model
+
+    def set_params(self, params):
+        self.params = params
+
+    def on_train_begin(self, logs=None): pass
+    def on_train_end(self, logs=None): pass
+    def on_epoch_begin(self, epoch, logs=None): pass
+    def on_epoch_end(self, epoch, logs=None): pass
+    def on_batch_begin(self, batch, logs=None): pass
+    def on_batch_end(self, batch, logs=None): pass
+
+
+class History(Callback):
+    def on_train_begin(self, logs=None):
+        self.epoch, self.history = [], {}
+
+    def on_epoch_end(self, epoch, logs=None):
+        self.epoch.append(epoch)
+        for k, v in (logs or {}).items():
+            self.history.setdefault(k, []).append(v)
+
+
+class CSVLogger(Callback):
+    def __init__(self, filename, separator=',', append=False):
+        super(CSVLogger, self).__init__()
+        self.filename, self.sep, self.append = filename, separator, append
+        self.keys = None
+        self.fp = None
+
+    def on_train_begin(self, logs=None):
+        self.fp = open(self.filename, 'a' if self.append else 'w')
+
+    def on_epoch_end(self, epoch, logs=None):
+        logs = logs or {}
+        if self.keys is None:
+            self.keys = sorted(logs.keys())
+            self.writer = csv.DictWriter(self.fp, fieldnames=['epoch'] + self.keys, delimiter=self.sep)
+            self.writer.writeheader()
+        row = {'epoch': epoch}
+        row.update((k, logs.get(k, 'NA')) for k in self.keys)
+        self.writer.writerow(row)
+        self.fp.flush()
+
+    def on_train_end(self, logs=None):
+        if self.fp:
+            self.fp.close()
+            self.fp = None
+
+
+class ModelCheckpoint(Callback):
+    def __init__(self, filepath, monitor='val_loss', verbose=0, save_best_only=False, mode='auto', period=1):
+        super(ModelCheckpoint, self).__init__()
+        self.filepath, self.monitor, self.verbose, self.save_best_only = filepath, monitor, verbose, save_best_only
+        self.cmp = np.greater if (mode == 'max' or (mode == 'auto' and ('acc' in monitor or monitor.startswith('fmeasure')))) else np.less
+        self.best = -np.inf if self.cmp is np.greater else np.inf
+
+    def on_epoch_end(self, epoch, logs=None):
+        logs = logs or {}
+        path = self.filepath.format(epoch=epoch, **logs)
+        if self.save_best_only:
+            cur = logs.get(self.monitor)
+            if cur is None or not self.cmp(cur, self.best):
+                return
+            self.best = cur
+        if self.verbose:
+            print('Epoch %05d: saving model to %s' % (epoch, path))
+        self.model.save(path)
+
+
+class ReduceLROnPlateau(Callback):
+    """Keras 2.0.6 semantics: improvement iff monitor beats best by `epsilon`; after `patience`
+    non-improving epochs lr <- max(lr*factor, min_lr); cooldown 0.  Writes logs['lr']."""
+
+    def __init__(self, monitor='val_loss', factor=0.1, patience=10, verbose=0, mode='auto', epsilon=1e-4,
+                 cooldown=0, min_lr=0):
+        super(ReduceLROnPlateau, self).__init__()
+        self.monitor, self.factor, self.patience, self.verbose = monitor, factor, patience, verbose
+        self.epsilon, self.cooldown, self.min_lr = epsilon, cooldown, min_lr
+        maximize = mode == 'max' or (mode == 'auto' and 'acc' in monitor)
+        if maximize:
+            self.better = lambda a, b: a > b + self.epsilon
+            self.best = -np.inf
+        else:
+            self.better = lambda a, b: a < b - self.epsilon
+            self.best = np.inf
+        self.wait = 0
+        self.cooldown_counter = 0
+
+    def on_epoch_end(self, epoch, logs=None):
+        logs = logs if logs is not None else {}
+        logs['lr'] = self.model.optimizer.lr
+        cur = logs.get(self.monitor)
+        if cur is None:
+            return
+        if self.cooldown_counter > 0:
+            self.cooldown_counter -= 1
+            self.wait = 0
+        if self.better(cur, self.best):
+            self.best = cur
+            self.wait = 0
+        elif self.cooldown_counter <= 0:
+            if self.wait >= self.patience:
+                old = self.model.optimizer.lr
+                if old > self.min_lr + self.min_lr * 1e-4:
+                    self.model.optimizer.lr = max(old * self.factor, self.min_lr)
+                    if self.verbose:
+                        print('Epoch %05d: reducing learning rate to %s.' % (epoch, self.model.optimizer.lr))
+                    self.cooldown_counter = self.cooldown
+                    self.wait = 0
+            self.wait += 1
+
+
+# ---- the model --------------------------------------------------------------------------------------------
+class Model(object):
+    def __init__(self, window_shape, nb_filters_base=32, conv_kernel_init='he_normal', prop_dropout_base=0.25,
+                 upsampling_or_transpose='transpose', device=None, seed=7535):
+        if conv_kernel_init != 'he_normal':
+            raise NotImplementedError("only conv_kernel_init='he_normal' (the reference default) is built")
+        if upsampling_or_transpose != 'transpose':
+            raise NotImplementedError("the UpSampling2D branch (unet_2d_summary.py:160-161) is a 'next' row (SURVEY 8f)")
+        self.config = dict(window_shape=tuple(int(v) for v in window_shape), nb_filters_base=int(nb_filters_base),
+                           prop_dropout_base=float(prop_dropout_base))
+        self.engine = UNetEngine(self.config['window_shape'], nb_filters_base, prop_dropout_base, device=device, seed=seed)
+        self.optimizer = None
+        self.loss = None
+        self.metrics_names = ['loss']
+        self.stop_training = False
+        self.history = None
+
+    # -- Keras surface ------------------------------------------------------------------------------------
+    @property
+    def input_shape(self):
+        return (None,) + self.config['window_shape']
+
+    output_shape = input_shape
+
+    def count_params(self):
+        return self.engine.n_train + self.engine.n_stats
+
+    def summary(self):
+        e = self.engine
+        print('UNet2DS (HIP/gfx950)  input %r  nb_filters_base %d' % (self.input_shape, e.nfb))
+        for l in e.layers:
+            print('  %-4s %-5s %4d -> %-4d  params %d' % (l.name, l.kind, l.cin, l.cout,
+                                                          int(np.prod(l.kshape)) + l.cout * (5 if l.kind != 'head' else 1)))
+        print('Total params: %d (trainable %d)' % (self.count_params(), e.n_train))
+
+    def compile(self, optimizer, loss='binary_crossentropy', metrics=None):
+        name = loss if isinstance(loss, str) else getattr(loss, '__name__', str(loss))
+        if name != 'binary_crossentropy':
+            raise NotImplementedError("loss %r: only the default 'binary_crossentropy' is built; the alternates "
+                                      "(utils/neurons.py:13-29,78-94) are a 'next' row (SURVEY 8f)" % name)
+        self.optimizer = optimizer if optimizer is not None else Adam(0.002)
+        self.loss = name
+        self.metrics_names = ['loss'] + list(METRIC_NAMES)
+
+    def get_weights(self):
+        return self.engine.get_weights()
+
+    def set_weights(self, weights):
+        self.engine.set_weights(weights)
+
+    def predict(self, x, batch_size=32, verbose=0):
+        """x: (N,H,W) float32 -> (N,H,W) float32 probabilities (learning phase 0: moving stats, no dropout)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 3 or tuple(x.shape[1:]) != self.config['window_shape']:
+            raise ValueError('expected input of shape (N,%d,%d), got %r' % (self.config['window_shape'] + (x.shape,)))
+        out = np.empty(x.shape, np.float32)
+        for i in range(0, x.shape[0], batch_size):
+            xb = torch.from_numpy(x[i:i + batch_size]).to(self.engine.device)
+            out[i:i + batch_size] = self.engine.forward_infer(xb).cpu().numpy()[:xb.shape[0]]
+        return out
+
+    def train_on_batch(self, x, y, drop_masks=None):
+        """One optimizer step; returns [loss, F1, prec, reca, dice, dicesq, posyt, posyp] (Keras order).
+        Under torch.distributed (one process per GPU) every rank is handed the SAME global batch and trains on
+        its contiguous slice; gradients and metric sums are all-reduced over RCCL."""
+        if self.optimizer is None:
+            raise RuntimeError('compile() the model first')
+        eng = self.engine
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.uint8)
+        sl = parallel.shard_slice(x.shape[0])
+        xd = torch.from_numpy(x[sl]).to(eng.device)
+        yd = torch.from_numpy(y[sl]).to(eng.device)
+        masks = None
+        if drop_masks is not None:
+            masks = {k: torch.from_numpy(np.ascontiguousarray(v[sl])).to(eng.device) for k, v in drop_masks.items()}
+        return self.train_on_device_batch(xd, yd, masks)
+
+    def train_on_device_batch(self, xd, yd, masks=None):
+        """train_on_batch for a LOCAL shard already resident in HBM (xd float32 (n,H,W), yd uint8 (n,H,W)):
+        forward + BCE + backward + (RCCL all-reduce of the flat gradient and of the 8 metric sums) + Adam."""
+        if self.optimizer is None:
+            raise RuntimeError('compile() the model first')
+        eng = self.engine
+        eng.forward_train(xd, yd, masks)
+        eng.backward()
+        world = parallel.world_size()
+        sums = eng._train_bufs(xd.shape[0])['sums']
+        if world > 1:
+            parallel.all_reduce_sum(eng.gflat)
+            parallel.all_reduce_sum(sums)
+        o = self.optimizer
+        eng.adam_step(o.lr, o.beta_1, o.beta_2, o.epsilon, grad_scale=1.0 / world)
+        m = metrics_from_sums(sums.cpu().numpy(), float(world * xd.shape[0] * xd.shape[1] * xd.shape[2]))
+        return [m[k] for k in self.metrics_names]
+
+    def fit_generator(self, generator, steps_per_epoch, epochs=1, verbose=1, callbacks=None, max_queue_size=10,
+                      initial_epoch=0):
+        """Keras 2.0.6 fit_generator: one background generator THREAD feeding a queue of depth
+        `max_queue_size`; per-epoch logs are batch-size-weighted means; callbacks' on_epoch_end run in list order
+        on the caller's thread sharing ONE mutable logs dict; History last."""
+        self.history = History()
+        cbs = list(callbacks or []) + [self.history]
+        for cb in cbs:
+            cb.set_model(self)
+            cb.set_params(dict(epochs=epochs, steps=steps_per_epoch, verbose=verbose, metrics=self.metrics_names))
+        q = queue.Queue(maxsize=max(1, max_queue_size))
+        stop = threading.Event()
+
+        def producer():
+            try:
+                while not stop.is_set():
+                    item = next(generator)
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+            except Exception as e:      # surfaced on the consumer side
+                q.put(e)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        self.stop_training = False
+        for cb in cbs:
+            cb.on_train_begin({})
+        try:
+            for epoch in range(initial_epoch, epochs):
+                for cb in cbs:
+                    cb.on_epoch_begin(epoch, {})
+                totals = dict((k, 0.0) for k in self.metrics_names)
+                seen = 0
+                tic = time.time()
+                for step in range(steps_per_epoch):
+                    item = q.get()
+                    if isinstance(item, Exception):
+                        raise item
+                    xb, yb = item[0], item[1]
+                    blogs = {'batch': step, 'size': len(xb)}
+                    for cb in cbs:
+                        cb.on_batch_begin(step, blogs)
+                    vals = self.train_on_batch(xb, yb)
+                    for k, v in zip(self.metrics_names, vals):
+                        blogs[k] = v
+                        totals[k] += v * len(xb)
+                    seen += len(xb)
+                    for cb in cbs:
+                        cb.on_batch_end(step, blogs)
+                logs = dict((k, totals[k] / max(seen, 1)) for k in self.metrics_names)
+                if verbose and parallel.rank() == 0:
+                    print('Epoch %d/%d - %.1fs - %s' % (epoch + 1, epochs, time.time() - tic,
+                                                        ' - '.join('%s: %.4f' % (k, logs[k]) for k in self.metrics_names)))
+                for cb in cbs:
+                    cb.on_epoch_end(epoch, logs)
+                if self.stop_training:
+                    break
+        finally:
+            stop.set()
+            for cb in cbs:
+                cb.on_train_end({})
+        return self.history
+
+    # -- checkpoint (own .npz container; Keras-HDF5 import/export is SURVEY 8f rank 1) ----------------------
+    def save(self, filepath, include_optimizer=True):
+        eng = self.engine
+        arrays = {'w_%03d' % i: w for i, w in enumerate(eng.get_weights())}
+        meta = dict(format='dcunet-npz-1', config=self.config, compiled=self.optimizer is not None)
+        if include_optimizer and self.optimizer is not None:
+            arrays['opt_m'] = eng.mflat.cpu().numpy()
+            arrays['opt_v'] = eng.vflat.cpu().numpy()
+            meta['optimizer'] = dict(self.optimizer.get_config(), iterations=int(eng.iterations))
+            meta['loss'] = self.loss
+        arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        with open(filepath, 'wb') as fp:         # exact file name (ModelCheckpoint passes '*.hdf5')
+            np.savez(fp, **arrays)
+
+    def load_state(self, filepath, with_optimizer):
+        z = np.load(filepath)
+        meta = json.loads(bytes(z['meta']).decode())
+        n = len([k for k in z.files if k.startswith('w_')])
+        self.set_weights([z['w_%03d' % i] for i in range(n)])
+        if with_optimizer and 'optimizer' in meta:
+            oc = dict(meta['optimizer'])
+            self.engine.iterations = int(oc.pop('iterations'))
+            self.engine.mflat.copy_(torch.from_numpy(z['opt_m']))
+            self.engine.vflat.copy_(torch.from_numpy(z['opt_v']))
+            self.compile(Adam(**oc), meta.get('loss', 'binary_crossentropy'))
+        return meta
+
+
+def unet_hip(window_shape=(128, 128), nb_filters_base=32, conv_kernel_init='he_normal',
+             prop_dropout_base=0.25, upsampling_or_transpose='transpose'):
+    """Drop-in for the reference's net_builder_func `unet()` (unet_2d_summary.py:123-124): same signature,
+    returns an uncompiled model whose ops are HIP kernels."""
+    return Model(window_shape, nb_filters_base, conv_kernel_init, prop_dropout_base, upsampling_or_transpose)
+
+
+def load_model_with_new_input_shape(model_path, input_shape, **load_model_args):
+    """The weight-I/O seam of /root/reference/deepcalcium/utils/keras_helpers.py:24-68: the same weights at a
+    new window size (the net is fully convolutional).  `compile=True` restores the optimizer state."""
+    z = np.load(model_path)
+    meta = json.loads(bytes(z['meta']).decode())
+    if meta.get('format') != 'dcunet-npz-1':
+        raise ValueError('%s is not a dcunet checkpoint' % model_path)
+    cfg = meta['config']
+    model = Model(tuple(input_shape), cfg['nb_filters_base'], prop_dropout_base=cfg['prop_dropout_base'])
+    model.load_state(model_path, with_optimizer=bool(load_model_args.get('compile', True)))
+    return model

@@ -1,0 +1,83 @@
+"""Batch-sharded data parallelism: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The reference has no multi-device code; the path shards naturally over the batch:
+every rank draws the SAME global batch from the reference's single RNG stream and trains on its contiguous
+slice; the only exchange is ONE all-reduce of the flat 31 MB gradient buffer (+ one 64-byte all-reduce of the
+loss/metric sums) per step.  BatchNorm statistics stay local to a rank ('local' mode, standard DP semantics);
+moving statistics are averaged across ranks by `sync_moving_stats` before validation / checkpoints.
+On CPU (tests) the same functions run over the gloo backend.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+def rank():
+    return dist.get_rank() if is_dist() else 0
+
+
+def init_from_env(backend=None):
+    """Initialise from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); no-op for a single process."""
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    if ws <= 1 or is_dist():
+        return rank(), world_size()
+    local = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
+    use_cuda = torch.cuda.is_available()
+    if use_cuda:
+        torch.cuda.set_device(local)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group(backend or ('nccl' if use_cuda else 'gloo'))
+    return rank(), world_size()
+
+
+def shard_slice(global_batch, r=None, ws=None):
+    """Contiguous slice [r*B/G, (r+1)*B/G) of the global batch owned by rank r."""
+    r = rank() if r is None else r
+    ws = world_size() if ws is None else ws
+    if ws == 1:
+        return slice(0, global_batch)
+    if global_batch % ws:
+        raise ValueError('global batch %d is not divisible by world size %d' % (global_batch, ws))
+    per = global_batch // ws
+    return slice(r * per, (r + 1) * per)
+
+
+def all_reduce_sum(t):
+    if is_dist() and world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def all_reduce_max(t):
+    if is_dist() and world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
+def barrier():
+    if is_dist() and world_size() > 1:
+        dist.barrier()
+
+
+def sync_moving_stats(sflat):
+    """Average the BatchNorm moving statistics over ranks (they drift apart under local-BN data parallelism)."""
+    if is_dist() and world_size() > 1:
+        dist.all_reduce(sflat, op=dist.ReduceOp.SUM)
+        sflat.div_(world_size())
+    return sflat
+
+
+def broadcast_params(*tensors, src=0):
+    if is_dist() and world_size() > 1:
+        for t in tensors:
+            dist.broadcast(t, src)

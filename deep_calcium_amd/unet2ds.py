@@ -1,0 +1,329 @@
+"""UNet2DSummary: the reference's fit()/predict() API surface over the HIP model.
+
+Same class name, constructor, `fit`, `_batch_gen` and `predict` signatures and behaviour as
+/root/reference/deepcalcium/models/neurons/unet_2d_summary.py:301-625, with `net_builder_func` defaulting to
+`unet_hip` (the drop-in for `unet()`), and checkpoints in the build's own .npz container.
+Host-side numpy only; every tensor op happens behind `model.predict` / `model.fit_generator`.
+"""
+from __future__ import division, print_function
+
+import logging
+import os
+import pickle
+from time import time
+
+import numpy as np
+
+from . import parallel
+from .model import (Adam, Callback, CSVLogger, ModelCheckpoint, ReduceLROnPlateau, unet_hip,
+                    load_model_with_new_input_shape)
+from .nf_metrics import nf_mask_metrics
+
+# ---- 8 invertible test-time augmentations on (N,H,W) batches: (name, forward, inverse) -----------------------
+# Same table as deepcalcium/utils/neurons.py:112-137, written as (k rot90s, then optional flip of an axis).
+
+
+def _tta(k, flip_axis):
+    def fwd(x):
+        y = np.rot90(x, k, axes=(1, 2)) if k else x
+        return np.flip(y, flip_axis) if flip_axis is not None else y
+
+    def inv(x):
+        y = np.flip(x, flip_axis) if flip_axis is not None else x
+        return np.rot90(y, -k, axes=(1, 2)) if k else y
+    return fwd, inv
+
+
+INVERTIBLE_2D_AUGMENTATIONS = [
+    ('identity',) + _tta(0, None),
+    ('vflip',) + _tta(0, 1),
+    ('hflip',) + _tta(0, 2),
+    ('rot90',) + _tta(1, None),
+    ('rot180',) + _tta(2, None),
+    ('rot270',) + _tta(3, None),
+    ('rot90vflip',) + _tta(1, 1),
+    ('rot90hflip',) + _tta(1, 2),
+]
+# NB the reference's inverse for the last two entries is the forward map applied again (rot90 then flip),
+# which is its own inverse for these two compositions only on SQUARE windows; _tta's flip-then-rot(-1) is the
+# exact inverse in general and coincides with it on square windows (asserted by tests/test_host.py).
+
+# ---- the 6 training / validation augmentations (unet_2d_summary.py:54-59, :459-466) --------------------------
+_SIX = [
+    lambda a: a,
+    lambda a: a[:, ::-1],
+    lambda a: a[::-1, :],
+    lambda a: np.rot90(a, 1),
+    lambda a: np.rot90(a, 2),
+    lambda a: np.rot90(a, 3),
+]
+
+
+def _open_dataset(dspath):
+    """A dataset is the reference's HDF5 file (needs h5py) or an .npz with the same members, '/' -> '_'."""
+    if str(dspath).endswith('.npz'):
+        z = np.load(dspath, allow_pickle=False)
+        return {k.replace('_', '/', 1): z[k] for k in z.files}, None
+    try:
+        import h5py
+    except ImportError:
+        raise ImportError('h5py is required to read %s (or pass .npz datasets / custom summary functions)' % dspath)
+    return None, h5py.File(dspath, 'r')
+
+
+def _get(dspath, key):
+    d, fp = _open_dataset(dspath)
+    if d is not None:
+        return d[key]
+    try:
+        return fp.attrs[key] if key == 'name' else fp.get(key)[...]
+    finally:
+        fp.close()
+
+
+def _summarize_series(dspath):
+    """Normalised mean image, unet_2d_summary.py:227-241."""
+    summ = np.asarray(_get(dspath, 'series/mean')).astype(np.float32)
+    return (summ - np.mean(summ)) / np.std(summ)
+
+
+def _summarize_mask(dspath):
+    """Flatten the neuron mask stack to one (H,W) mask, dropping pixels owned by >1 neuron and pixels whose
+    8-neighbourhood (among the surviving single-owner pixels) touches another neuron, unet_2d_summary.py:244-291.
+    The reference removes neighbourhoods sequentially in dict order while iterating a snapshot of the keys; this
+    vectorised form reproduces that order-dependent deletion by a raster-order sweep."""
+    msks = np.asarray(_get(dspath, 'masks/raw'))
+    zz, yy, xx = np.where(msks == 1)
+    H, W = msks.shape[1:]
+    count = np.zeros((H, W), np.int32)
+    np.add.at(count, (yy, xx), 1)
+    owner = np.full((H, W), -1, np.int64)
+    owner[yy, xx] = zz
+    owner[count != 1] = -1
+    # keys in first-insertion order of the reference's dict = np.where order (z, then y, then x)
+    seen = np.zeros((H, W), bool)
+    keys = []
+    for y, x in zip(yy, xx):
+        if not seen[y, x]:
+            seen[y, x] = True
+            if count[y, x] == 1:
+                keys.append((y, x))
+    alive = owner >= 0
+    for y, x in keys:
+        nb = [(y - 1, x), (y + 1, x), (y, x - 1), (y, x + 1), (y + 1, x + 1), (y - 1, x - 1), (y + 1, x - 1),
+              (y - 1, x + 1), (y, x)]
+        nb = [(a, b) for a, b in nb if 0 <= a < H and 0 <= b < W and alive[a, b]]
+        if len(set(owner[a, b] for a, b in nb)) > 1:
+            for a, b in nb:
+                alive[a, b] = False
+    return alive.astype(np.float64)
+
+
+def _name_dataset(dspath):
+    name = _get(dspath, 'name')
+    if isinstance(name, np.ndarray):
+        name = name.item() if name.shape == () else str(name)
+    return name.decode() if isinstance(name, bytes) else str(name)
+
+
+class _ValidationMetricsCB(Callback):
+    """Full-size validation at epoch end, unet_2d_summary.py:31-120: copies the training weights into the
+    512^2 model, predicts 6 augmented copies of every dataset, scores the validation stripe with the
+    Neurofinder metrics and writes val_nf_* into the shared logs dict."""
+
+    def __init__(self, model_val, S_summ, M_summ, names, y_coords, scores_path=None):
+        super(_ValidationMetricsCB, self).__init__()
+        self.model_val = model_val
+        self.S_summ, self.M_summ, self.val_coords, self.names = [], [], [], []
+        self.scores_path = scores_path
+        for s, m, name, (y0, y1) in zip(S_summ, M_summ, names, y_coords):
+            stripe = np.zeros(s.shape, dtype=np.uint8)
+            stripe[y0:y1, :] = 1
+            for f in _SIX:
+                self.S_summ.append(f(s))
+                self.M_summ.append(f(m))
+                self.names.append(name)
+                yy, xx = np.where(f(stripe) == 1)
+                # inclusive max indices, later used as exclusive slice ends (drops one row/col) -- kept as is
+                self.val_coords.append([min(yy), max(yy), min(xx), max(xx)])
+
+    def on_epoch_end(self, epoch, logs={}):
+        logger = logging.getLogger('_ValidationMetricsCB')
+        tic = time()
+        eng_val, eng = self.model_val.engine, self.model.engine
+        if parallel.world_size() > 1:
+            parallel.sync_moving_stats(eng.sflat)
+        self.model_val.set_weights(self.model.get_weights())
+        _, hw, ww = self.model_val.input_shape
+        batch = np.stack([np.pad(s, ((0, hw - s.shape[0]), (0, ww - s.shape[1])), 'reflect')
+                          for s in self.S_summ]).astype(np.float32)
+        # one batched forward instead of 6n batch-1 forwards: identical per image in inference mode
+        MP = self.model_val.predict(batch, batch_size=8)
+        pp, rr, ff = [], [], []
+        name_to_f1 = {n: [] for n in self.names}
+        for mp, m, (y0, y1, x0, x1), name in zip(MP, self.M_summ, self.val_coords, self.names):
+            p, r, i, e, f = nf_mask_metrics(m[y0:y1, x0:x1], mp[y0:y1, x0:x1].round())
+            pp.append(p)
+            rr.append(r)
+            ff.append(f)
+            name_to_f1[name].append(f)
+            logger.info('%s p=%.3lf r=%.3lf f=%.3lf' % (name, p, r, f))
+        if self.scores_path:
+            with open(self.scores_path, 'wb') as fp:
+                pickle.dump(name_to_f1, fp)
+        eps = 1e-4 * epoch if epoch else 0
+        logs['val_nf_f1_mean'] = np.mean(ff) + eps
+        logs['val_nf_f1_median'] = np.median(ff) + eps
+        logs['val_nf_f1_min'] = np.min(ff) + eps
+        logs['val_nf_f1_adj'] = np.mean(ff) * np.min(ff) + eps
+        logs['val_nf_prec'] = np.mean(pp)
+        logs['val_nf_reca'] = np.mean(rr)
+        logger.info('mean f1 = %.3lf  (validation %.3lf s)' % (logs['val_nf_f1_mean'], time() - tic))
+
+
+class UNet2DSummary(object):
+    """Same constructor as the reference (unet_2d_summary.py:316-331); `net_builder_func` is the plug-point."""
+
+    def __init__(self, cpdir=None, dataset_name_func=_name_dataset, series_summary_func=_summarize_series,
+                 mask_summary_func=_summarize_mask, net_builder_func=unet_hip):
+        if cpdir is None:
+            cpdir = os.path.join(os.path.expanduser('~'), '.deep-calcium', 'checkpoints', 'neurons_unet2ds')
+        self.cpdir = cpdir
+        self.dataset_name_func = dataset_name_func
+        self.series_summary_func = series_summary_func
+        self.mask_summary_func = mask_summary_func
+        self.net_builder_func = net_builder_func
+        if not os.path.exists(self.cpdir):
+            os.makedirs(self.cpdir)
+        self.custom_objects = {}
+
+    def fit(self, dataset_paths, model_path=None, proceed=False, shape_trn=(96, 96), shape_val=(512, 512),
+            batch_size_trn=32, batch_size_val=1, nb_steps_trn=200, nb_epochs=20, prop_trn=0.75, prop_val=0.25,
+            keras_callbacks=[], optimizer=None, loss='binary_crossentropy'):
+        """unet_2d_summary.py:333-432.  Returns (history dict, model path)."""
+        assert len(shape_trn) == 2 and len(shape_val) == 2
+        assert shape_trn[0] == shape_trn[1] and shape_val[0] == shape_val[1]
+        assert 0 < prop_trn < 1 and 0 < prop_val < 1
+        assert not (proceed and not model_path)
+        known = ('binary_crossentropy', 'weighted_binary_crossentropy', 'dice_loss', 'dicesq_loss')
+        assert loss in known or getattr(loss, '__name__', None) in known
+        if optimizer is None:
+            optimizer = Adam(0.002)                       # the reference's default argument (:335)
+
+        if model_path:
+            model = load_model_with_new_input_shape(model_path, shape_trn, compile=proceed,
+                                                    custom_objects=self.custom_objects)
+            model_val = load_model_with_new_input_shape(model_path, shape_val, compile=False,
+                                                        custom_objects=self.custom_objects)
+        else:
+            model = self.net_builder_func(shape_trn)
+            model_val = self.net_builder_func(shape_val)
+            if parallel.rank() == 0:
+                model.summary()
+        if not proceed:
+            model.compile(optimizer=optimizer, loss=loss, metrics=['F1', 'prec', 'reca', 'dice', 'dicesq', 'posyt', 'posyp'])
+
+        names = [self.dataset_name_func(d) for d in dataset_paths]
+        S_summ = [self.series_summary_func(d) for d in dataset_paths]
+        M_summ = [self.mask_summary_func(d) for d in dataset_paths]
+        ycval = [(s.shape[0] - int(s.shape[0] * prop_val), s.shape[0]) for s in S_summ]
+        yctrn = [(0, int(s.shape[0] * prop_trn)) for s in S_summ]
+        gen_trn = self._batch_gen(S_summ, M_summ, names, yctrn, batch_size_trn, nb_steps_trn, shape_trn, 15)
+
+        tic = int(time())
+        callbacks = [_ValidationMetricsCB(model_val, S_summ, M_summ, names, ycval)]
+        if parallel.rank() == 0:
+            callbacks += [
+                CSVLogger('%s/%d_metrics.csv' % (self.cpdir, tic)),
+                ModelCheckpoint('%s/%d_model_{epoch:02d}_{val_nf_f1_mean:.3f}.hdf5' % (self.cpdir, tic), mode='max',
+                                monitor='val_nf_f1_mean', save_best_only=False, verbose=1),
+            ]
+        callbacks += [ReduceLROnPlateau(monitor='F1', factor=0.5, patience=5, min_lr=1e-4, mode='max')]
+        callbacks += list(keras_callbacks)
+        trained = model.fit_generator(gen_trn, steps_per_epoch=nb_steps_trn, epochs=nb_epochs, callbacks=callbacks,
+                                      verbose=1, max_queue_size=1)
+        self.model, self.model_val = model, model_val
+        return trained.history, '%s/model_val_nf_f1_mean.hdf5' % self.cpdir
+
+    def _batch_gen(self, S_summ, M_summ, names, y_coords, batch_size, nb_steps, window_shape, nb_max_augment=0,
+                   scores_path=None):
+        """Infinite generator of (s_batch (B,h,w) f32, m_batch (B,h,w) u8): neuron-centred random crops with
+        random flips / rot90s, drawing from numpy's GLOBAL RNG in the reference's order
+        (unet_2d_summary.py:434-530) so that a seeded run yields the reference's batches."""
+        rng = np.random
+        hw, ww = window_shape
+        nb_yields = 0
+        n_ds = len(S_summ)
+        locs = []
+        for m, (ymin, ymax) in zip(M_summ, y_coords):
+            ys, xs = np.where(m[ymin:ymax, :] == 1)          # NB relative to ymin, used as absolute (:474, :510)
+            locs.append(np.stack([ys, xs], axis=1))
+        probs = np.ones(n_ds) / n_ds
+        while True:
+            if scores_path and os.path.exists(scores_path) and (nb_yields - 1) % nb_steps == 0:
+                with open(scores_path, 'rb') as fp:
+                    scores = pickle.load(fp)
+                probs = np.array([1 - np.mean(scores[n]) for n in names])
+                probs /= probs.sum()
+            s_batch = np.zeros((batch_size, hw, ww), dtype=np.float32)
+            m_batch = np.zeros((batch_size, hw, ww), dtype=np.uint8)
+            for b in range(batch_size):
+                k = rng.choice(np.arange(n_ds), p=probs)
+                s, m = S_summ[k], M_summ[k]
+                hs, ws = s.shape
+                ymin, ymax = y_coords[k]
+                cy, cx = locs[k][rng.randint(0, len(locs[k]))]
+                cy = min(max(ymin, cy + rng.randint(-5, 5)), ymax)
+                cx = min(max(0, cx + rng.randint(-5, 5)), ws)
+                y0 = max(ymin, int(cy - (hw / 2)))
+                y1 = min(y0 + hw, ymax)
+                x0 = max(0, int(cx - (ww / 2)))
+                x1 = min(x0 + ww, ws)
+                m_batch[b, :y1 - y0, :x1 - x0] = m[y0:y1, x0:x1]      # short crops stay zero-filled
+                s_batch[b, :y1 - y0, :x1 - x0] = s[y0:y1, x0:x1]
+                for j in rng.choice(len(_SIX), rng.randint(0, nb_max_augment + 1)):
+                    s_batch[b], m_batch[b] = _SIX[j](s_batch[b]), _SIX[j](m_batch[b])
+            nb_yields += 1
+            yield s_batch, m_batch
+
+    def predict(self, dataset_paths, model_path, window_shape=(512, 512), print_scores=False, save=False,
+                augmentation=False, threshold=0.5):
+        """unet_2d_summary.py:532-625.  Returns (Mp: list of uint8 masks, names)."""
+        logger = logging.getLogger('UNet2DSummary.predict')
+        model = load_model_with_new_input_shape(model_path, window_shape, compile=False,
+                                                custom_objects=self.custom_objects)
+        assert tuple(window_shape) == (512, 512), 'TODO: implement variable window sizes.'   # as the reference (:565)
+        _, hw, ww = model.input_shape
+        Mp, names = [], []
+        mean_prec = mean_reca = mean_comb = 0.
+        for dsp in dataset_paths:
+            name = self.dataset_name_func(dsp)
+            s = self.series_summary_func(dsp)
+            hs, ws = s.shape
+            s_batch = np.pad(s, ((0, hw - hs), (0, ww - ws)), mode='reflect')[np.newaxis, :, :]
+            if augmentation:
+                # the 8 augmented copies go through ONE batch-8 forward (inference BN is per-image)
+                stack = np.concatenate([aug(s_batch) for _, aug, _ in INVERTIBLE_2D_AUGMENTATIONS])
+                out = model.predict(stack, batch_size=len(INVERTIBLE_2D_AUGMENTATIONS))
+                mp = np.zeros(s.shape)
+                for k, (_, _, inv) in enumerate(INVERTIBLE_2D_AUGMENTATIONS):
+                    mp += inv(out[k:k + 1])[0, :hs, :ws] / len(INVERTIBLE_2D_AUGMENTATIONS)
+            else:
+                mp = model.predict(s_batch)[0, :hs, :ws]
+            mp = (mp > threshold).astype(np.uint8)
+            Mp.append(mp)
+            names.append(name)
+            if print_scores:
+                m = self.mask_summary_func(dsp)
+                prec, reca, incl, excl, comb = nf_mask_metrics(m, mp.round())
+                logger.info('%s: prec=%.3lf, reca=%.3lf, incl=%.3lf, excl=%.3lf, comb=%.3lf'
+                            % (name, prec, reca, incl, excl, comb))
+                mean_prec += prec / len(dataset_paths)
+                mean_reca += reca / len(dataset_paths)
+                mean_comb += comb / len(dataset_paths)
+            if save:
+                # the reference renders red/blue outline PNGs (skimage/regional, out of scope); keep the mask itself
+                np.save('%s/%s_mp.npy' % (self.cpdir, name), mp)
+        if print_scores:
+            logger.info('Mean prec=%.3lf, reca=%.3lf, comb=%.3lf' % (mean_prec, mean_reca, mean_comb))
+        return Mp, names

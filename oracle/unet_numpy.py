@@ -15,6 +15,11 @@ import numpy as np
 
 BN_EPS = 1e-3          # Keras BatchNormalization default epsilon [3P]
 K_EPS = 1e-7           # keras.backend.epsilon() [3P]
+# The reference graph is float32: K.binary_crossentropy casts epsilon to the tensor dtype and forms
+# `1 - eps` IN float32 (= 0.99999988..., not 1 - 1e-7).  The float64 oracle uses those float32 clip bounds,
+# otherwise saturated pixels (p -> 1) are clipped by the reference but not by the oracle.
+CLIP_LO = float(np.float32(1e-7))
+CLIP_HI = float(np.float32(1.0) - np.float32(1e-7))
 
 
 # ----------------------------------------------------------------------------
@@ -200,7 +205,7 @@ def head_fwd(a, K, b):
 
 def bce_keras(p, y):
     """keras.losses.binary_crossentropy with the TF backend (A.10): clip, logit, stable BCE, global mean."""
-    pc = np.clip(p, K_EPS, 1 - K_EPS)
+    pc = np.clip(p, CLIP_LO, CLIP_HI)
     x = np.log(pc / (1 - pc))
     l = np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x)))
     return l.mean()
@@ -208,8 +213,8 @@ def bce_keras(p, y):
 
 def bce_keras_grad(p, y):
     """d(mean BCE)/dp; zero where the clip is active (A.10)."""
-    inside = (p > K_EPS) & (p < 1 - K_EPS)
-    pc = np.clip(p, K_EPS, 1 - K_EPS)
+    inside = (p > CLIP_LO) & (p < CLIP_HI)
+    pc = np.clip(p, CLIP_LO, CLIP_HI)
     # l(x) with x = logit(pc): dl/dx = sigmoid(x) - y = pc - y ; dx/dp = 1/(pc(1-pc))
     return inside * (pc - y) / (pc * (1 - pc)) / p.size
 
@@ -311,7 +316,7 @@ class UNetOracle(object):
             cache['out'] = (x, sm)
         return p
 
-    def loss_and_grads(self, x, y, masks=None):
+    def loss_and_grads(self, x, y, masks=None, taps=None):
         """One training-mode forward + backward.  Returns (loss, p, grads{name:[dK,db,dgamma,dbeta]}, batch_stats)."""
         cache = {}
         p = self.forward(x, True, masks, cache)
@@ -334,6 +339,8 @@ class UNetOracle(object):
             dy = da * relu_mask
             pl = self.P[name]
             dz, dg, db_ = bn_train_bwd(dy, pl[2], bnc)
+            if taps is not None:
+                taps['da_' + name], taps['dz_' + name], taps['x_' + name] = da, dz, xin
             if kind == 'conv':
                 dx, dK, dbias = conv3x3_bwd(xin, pl[0], dz)
             else:

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .unet_numpy import layer_table, dropout_rates, BN_EPS, K_EPS
+from .unet_numpy import layer_table, dropout_rates, BN_EPS, CLIP_LO, CLIP_HI
 
 
 def _to_t(w, dtype, requires_grad=False):
@@ -84,7 +84,7 @@ class UNetTorch(object):
 
     @staticmethod
     def bce(p, y):
-        pc = torch.clamp(p, K_EPS, 1 - K_EPS)
+        pc = torch.clamp(p, CLIP_LO, CLIP_HI)
         x = torch.log(pc / (1 - pc))
         # TF's sigmoid_cross_entropy_with_logits selects with where(x >= 0, ...) rather than relu/abs, so
         # its autograd is exact at x == 0 (p == 0.5 exactly, e.g. all-zero activations with a zero head

@@ -13,11 +13,24 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
 
 
+_KEEP = []
+
+
+@pytest.fixture(autouse=True)
+def _keep_alive():
+    """dev() temporaries must outlive the asynchronous launches that read them (raw pointers cross the C ABI)."""
+    yield
+    torch.cuda.synchronize()
+    del _KEEP[:]
+
+
 def dev(a, dtype=None):
     t = torch.from_numpy(np.ascontiguousarray(a))
     if dtype is not None:
         t = t.to(dtype)
-    return t.cuda()
+    t = t.cuda()
+    _KEEP.append(t)
+    return t
 
 
 def rel_err(got, ref):
@@ -331,7 +344,8 @@ def test_head_fwd_bwd_metrics(dclib, C, pixels):
     s = sums.cpu().numpy()
     yf = y.astype(np.float64)
     assert abs(s[0] / pixels - on.bce_keras(pg.astype(np.float64), yf)) < 1e-6     # loss on the GPU's own p
-    assert abs(s[0] / pixels - on.bce_keras(p_ref, yf)) < 1e-5
+    # vs the float64 p: fp32 rounding of p near 1 moves -log(1-p) by a few % on near-saturated pixels
+    assert abs(s[0] / pixels - on.bce_keras(p_ref, yf)) < 1e-4
     pr = np.round(pg.astype(np.float64))
     exp = [None, (pr * yf).sum(), pr.sum(), np.clip(yf - pr, 0, 1).sum(), yf.sum(), (yf * pg).sum(), (pg.astype(np.float64) ** 2).sum(), (yf ** 2).sum()]
     for k in range(1, 8):
