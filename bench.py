@@ -84,30 +84,47 @@ class KernelTimer(object):
         return n, tot_ms, tot_flops
 
 
-def cpu_baseline():
-    """The oracle port (oracle/unet_torch.py: torch-CPU fp32, all host threads, same graph/optimizer) on a bounded
-    sample of the same workload: 2 train steps at batch 4 of 512x512 after a batch-1 warm-up."""
+def host_cores():
+    """CPUs this process may actually use: min(affinity mask, cgroup cpu.max quota) -- os.cpu_count() reports the
+    whole 256-thread host while the GPU box's container is capped (oversubscribing oneDNN 16x runs 20x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(budget_s=25.0):
+    """The oracle port (oracle/unet_torch.py: torch-CPU fp32 / oneDNN, same graph, loss and Keras-form Adam) timed
+    on the host cores on a BOUNDED sample of the same workload: batch-2 train steps of 512x512 for ~budget_s."""
     import torch
     from oracle import unet_numpy as on
     from oracle.unet_torch import UNetTorch
-    threads = os.cpu_count() or 1
+    threads = host_cores()
     torch.set_num_threads(threads)
     Wt = on.init_weights(NFB)
     net = UNetTorch(Wt, NFB, dtype=torch.float32)
     state = dict(it=0, m={}, v={})
-    bs = 4
+    bs = 2
     x, y = on.synthetic_batch(bs, H, W)
     masks = on.make_drop_masks(NFB, bs, H, W)
-    net.train_step(x[:1], y[:1], state, {k: v[:1] for k, v in masks.items()})
-    steps = 2
     t0 = time.time()
-    for _ in range(steps):
+    net.train_step(x[:1], y[:1], state, {k: v[:1] for k, v in masks.items()})     # warm-up (oneDNN primitives)
+    warm = time.time() - t0
+    steps, t0 = 0, time.time()
+    while True:
         net.train_step(x, y, state, masks)
-    dt = time.time() - t0
-    return {'value': round(steps * bs / dt, 4), 'unit': 'images/s', 'cores': int(torch.get_num_threads()),
-            'kind': 'port',
-            'sample': '%d train steps (fwd+bwd+Keras-Adam), batch %d of 512x512 fp32, oracle/unet_torch.py on torch-CPU/oneDNN '
-                      '(Keras 2.0.6/TF 1.2.1 not installable offline); %.1f s' % (steps, bs, dt)}
+        steps += 1
+        dt = time.time() - t0
+        if dt > budget_s or steps >= 20:
+            break
+    return {'value': round(steps * bs / dt, 4), 'unit': 'images/s', 'cores': int(threads), 'kind': 'port',
+            'sample': '%d train steps (fwd+BCE+bwd+Keras-Adam) at batch %d of 512x512 fp32 in %.1f s (+%.1f s warm-up), '
+                      'oracle/unet_torch.py on torch-CPU/oneDNN with %d threads (Keras 2.0.6/TF 1.2.1, the '
+                      "reference's CPU path, is not installable offline)" % (steps, bs, dt, warm, threads)}
 
 
 def main():
