@@ -105,6 +105,12 @@ def cpu_baseline(budget_s=25.0):
     from oracle.unet_torch import UNetTorch
     threads = host_cores()
     torch.set_num_threads(threads)
+    try:    # keep freed activation buffers in the heap: without this glibc returns them to the OS every step and the
+        libc = ctypes.CDLL('libc.so.6')     # baseline spends >half its time in page faults (2.4x slower)
+        libc.mallopt(-1, 2 ** 31 - 1)       # M_TRIM_THRESHOLD
+        libc.mallopt(-3, 2 ** 31 - 1)       # M_MMAP_THRESHOLD
+    except Exception:
+        pass
     Wt = on.init_weights(NFB)
     net = UNetTorch(Wt, NFB, dtype=torch.float32)
     state = dict(it=0, m={}, v={})

@@ -48,7 +48,22 @@ def install_stubs():
     sm = _stub('scipy.misc', imsave=None, imread=None)
     import scipy
     scipy.misc = sm
-    _stub('h5py')
+    class _FakeH5(object):
+        store = {}
+
+        def __init__(self, path, *a, **k):
+            self.d = _FakeH5.store[path]
+            self.attrs = {'name': self.d.get('name')}
+
+        def get(self, key):
+            return self.d[key]
+
+        def __contains__(self, key):
+            return key in self.d
+
+        def close(self):
+            pass
+    _stub('h5py', File=_FakeH5)
     _stub('skimage')
     _stub('skimage.color', gray2rgb=None, rgb2gray=None)
     _stub('skimage.measure')
@@ -128,6 +143,22 @@ def main():
         met[fn] = np.float64(getattr(RN, fn)(yt, yp))
     met['weighted_binary_crossentropy'] = RN.weighted_binary_crossentropy(yt, yp)
     np.savez_compressed(os.path.join(OUT, 'metrics.npz'), **met)
+    # (v) _summarize_series / _summarize_mask, unet_2d_summary.py:227-291, through a dict-backed h5py.File stand-in
+    import h5py
+    rs = np.random.RandomState(5)
+    mean_img = (rs.random_sample((40, 48)) * 900 + 100).astype(np.float16)
+    msk = np.zeros((6, 40, 48), np.int8)
+    msk[0, 5:12, 5:12] = 1           # isolated neuron
+    msk[1, 10:18, 10:18] = 1         # overlaps neuron 0
+    msk[2, 20:26, 5:11] = 1
+    msk[3, 20:26, 11:17] = 1         # touches neuron 2 (adjacent columns)
+    msk[4, 30:36, 30:38] = 1
+    msk[5, 35:39, 37:44] = 1         # overlaps + touches neuron 4 diagonally
+    h5py.File.store['fake.hdf5'] = {'series/mean': mean_img, 'masks/raw': msk, 'name': 'neurofinder.99.99'}
+    from deepcalcium.models.neurons import unet_2d_summary as U
+    np.savez_compressed(os.path.join(OUT, 'summaries.npz'), series_mean=mean_img, masks_raw=msk,
+                        name=np.array('neurofinder.99.99'),
+                        summ_series=U._summarize_series('fake.hdf5'), summ_mask=U._summarize_mask('fake.hdf5'))
     print('wrote', sorted(f for f in os.listdir(OUT) if f.endswith('.npz')))
 
 

@@ -1,0 +1,66 @@
+"""The C ABI without a GPU: the library builds, loads, exports every symbol include/dcunet.h declares, sizes
+its workspaces, and the product path refuses to run (loudly) when there is no GPU -- no CPU fallback exists."""
+import ctypes
+import os
+import re
+
+import pytest
+
+
+def test_library_exports_every_declared_symbol(dclib):
+    from deep_calcium_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 36
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(raw, name), 'libdcunet.so does not export %s' % name
+    # and nothing dc_* is exported that the header does not declare
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r' T (dc_\w+)', out))
+    assert exported == set(protos), exported ^ set(protos)
+
+
+def test_header_cites_reference_call_sites():
+    src = open(os.path.join(os.path.dirname(__file__), '..', 'include', 'dcunet.h')).read()
+    assert 'unet_2d_summary.py:123-224' in src and 'unet_2d_summary.py:164-165' in src and ':156-157' in src
+
+
+def test_host_side_helpers_run_without_gpu(dclib):
+    L = dclib
+    assert L.dc_version() >= 100
+    assert L.dc_conv3x3_tiles(16, 512, 512, 32) == 16 * 32 * 16          # 512px x 32col tiles
+    assert L.dc_conv3x3_tiles(16, 256, 256, 64) == 16 * 32 * 8           # 256px x 64col tiles
+    assert L.dc_convT2x2_tiles(2, 32, 32, 256) == 2 * 4
+    assert L.dc_conv3x3_wgrad_ws_floats(16, 512, 512, 32, 32) > 9 * 32 * 32
+    assert L.dc_conv3x3_wgrad_ws_floats(2, 32, 32, 1, 32) > 0
+    assert L.dc_bn_bwd_blocks(16 * 512 * 512, 32) == 2048 and L.dc_head_blocks(100) == 1
+
+
+def test_argument_validation_returns_codes(dclib):
+    from deep_calcium_amd._lib import DcunetError
+    with pytest.raises(DcunetError, match='null pointer'):
+        dclib.dc_conv3x3_fwd(None, None, None, None, 32, None, None, None, 0, 1, 8, 8, 8, 8, None)
+    with pytest.raises(DcunetError, match='power of two'):
+        dclib.dc_bn_relu_drop_fwd(1, 1, 1, 1, 1, None, 1.0, 0, 16, 24, 10, 24, None)
+    with pytest.raises(DcunetError, match='even'):
+        dclib.dc_maxpool2x2_fwd(16, 8, 16, None, 1, 7, 8, 8, None)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from deep_calcium_amd import unet_hip
+    from deep_calcium_amd._lib import DcunetError
+    with pytest.raises(DcunetError, match='no CPU fallback'):
+        unet_hip((32, 32))
+
+
+def test_product_never_imports_oracle():
+    root = os.path.join(os.path.dirname(__file__), '..', 'deep_calcium_amd')
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f

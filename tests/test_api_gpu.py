@@ -1,0 +1,87 @@
+"""The reference's API surface on the GPU: unet_hip as net_builder_func, Model duck-type, UNet2DSummary.fit /
+predict (incl. batched 8x TTA), checkpoint round trip at a new window size."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import unet_numpy as on
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+def _make_datasets(tmp_path, n=2, hw=(72, 80)):
+    rs = np.random.RandomState(3)
+    paths = []
+    for k in range(n):
+        mean = (rs.random_sample(hw) * 500 + 50).astype(np.float16)
+        masks = np.zeros((10,) + hw, np.int8)
+        for z in range(10):
+            cy, cx = rs.randint(6, hw[0] - 6), rs.randint(6, hw[1] - 6)
+            masks[z, cy - 3:cy + 4, cx - 3:cx + 4] = 1
+            mean[cy - 3:cy + 4, cx - 3:cx + 4] += 400
+        p = str(tmp_path / ('ds%d.npz' % k))
+        np.savez(p, series_mean=mean, masks_raw=masks, name=np.array('neurofinder.0%d.00' % k))
+        paths.append(p)
+    return paths
+
+
+def test_model_duck_type_and_checkpoint_roundtrip(tmp_path):
+    from deep_calcium_amd import unet_hip, Adam, load_model_with_new_input_shape
+    m = unet_hip((32, 32), nb_filters_base=8)
+    assert m.input_shape == (None, 32, 32)
+    Wt = on.init_weights(8, randomize_bn=True)
+    m.set_weights(Wt)
+    x, y = on.synthetic_batch(3, 32, 32)
+    p_ref = on.UNetOracle(Wt, 8).forward(x)
+    p = m.predict(x)
+    assert p.dtype == np.float32 and p.shape == (3, 32, 32) and np.abs(p - p_ref).max() < 1e-4
+    m.compile(optimizer=Adam(0.002), loss='binary_crossentropy', metrics=[])
+    vals = m.train_on_batch(x, y)
+    assert len(vals) == 8 and m.metrics_names == ['loss', 'F1', 'prec', 'reca', 'dice', 'dicesq', 'posyt', 'posyp']
+    assert np.isfinite(vals).all() and abs(vals[6] - y.mean()) < 1e-6          # posyt
+    path = str(tmp_path / 'ck_01_0.500.hdf5')
+    m.save(path)
+    # same weights at a NEW window size (keras_helpers.load_model_with_new_input_shape seam)
+    m2 = load_model_with_new_input_shape(path, (64, 64), compile=True)
+    assert m2.input_shape == (None, 64, 64) and m2.engine.iterations == 1 and m2.optimizer.lr == 0.002
+    for a, b in zip(m.get_weights(), m2.get_weights()):
+        assert np.array_equal(a, b)
+    x64, _ = on.synthetic_batch(1, 64, 64)
+    assert np.abs(m2.predict(x64) - on.UNetOracle(m.get_weights(), 8).forward(x64)).max() < 1e-4
+    with pytest.raises(NotImplementedError):
+        m.compile(Adam(), loss='dice_loss')
+
+
+def test_fit_and_predict_end_to_end(tmp_path):
+    from deep_calcium_amd import UNet2DSummary, unet_hip, INVERTIBLE_2D_AUGMENTATIONS
+    from deep_calcium_amd import load_model_with_new_input_shape
+    paths = _make_datasets(tmp_path)
+    cp = str(tmp_path / 'cp')
+    np.random.seed(865)
+    model = UNet2DSummary(cpdir=cp, net_builder_func=lambda shape: unet_hip(shape, nb_filters_base=8))
+    hist, _ = model.fit(paths, shape_trn=(32, 32), shape_val=(96, 96), batch_size_trn=4, nb_steps_trn=6, nb_epochs=2)
+    for k in ('loss', 'F1', 'prec', 'reca', 'dice', 'dicesq', 'posyt', 'posyp', 'val_nf_f1_mean', 'val_nf_f1_median',
+              'val_nf_f1_min', 'val_nf_f1_adj', 'val_nf_prec', 'val_nf_reca', 'lr'):
+        assert k in hist and len(hist[k]) == 2, k
+    assert hist['loss'][1] < hist['loss'][0] + 0.2 and hist['lr'] == [0.002, 0.002]
+    cks = sorted(f for f in os.listdir(cp) if f.endswith('.hdf5'))
+    assert len(cks) == 2 and '_model_00_' in cks[0] and '_model_01_' in cks[1]
+    assert any(f.endswith('_metrics.csv') for f in os.listdir(cp))
+
+    ck = os.path.join(cp, cks[-1])
+    Mp, names = model.predict(paths, ck, window_shape=(512, 512), augmentation=False)
+    assert names == ['neurofinder.00.00', 'neurofinder.01.00']
+    assert all(m.dtype == np.uint8 and m.shape == (72, 80) and set(np.unique(m)) <= {0, 1} for m in Mp)
+    MpT, _ = model.predict(paths, ck, window_shape=(512, 512), augmentation=True, print_scores=True)
+    # batched 8x TTA == the reference's 8 sequential batch-1 forwards, inverse-mapped and averaged
+    net = load_model_with_new_input_shape(ck, (512, 512), compile=False)
+    s = model.series_summary_func(paths[0])
+    sb = np.pad(s, ((0, 512 - s.shape[0]), (0, 512 - s.shape[1])), mode='reflect')[np.newaxis]
+    mp = np.zeros(s.shape)
+    for _, aug, inv in INVERTIBLE_2D_AUGMENTATIONS:
+        mp += inv(net.predict(np.ascontiguousarray(aug(sb))))[0, :s.shape[0], :s.shape[1]] / 8
+    assert np.array_equal((mp > 0.5).astype(np.uint8), MpT[0])
+    with pytest.raises(AssertionError):
+        model.predict(paths, ck, window_shape=(256, 256))

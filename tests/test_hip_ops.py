@@ -357,8 +357,11 @@ def test_head_fwd_bwd_metrics(dclib, C, pixels):
     L.dc_head_bwd(ad.data_ptr(), p.data_ptr(), yd.data_ptr(), kd.data_ptr(), da.data_ptr(), part2.data_ptr(), pixels, C, None)
     L.dc_head_grad_finalize(part2.data_ptr(), blocks, C, dk.data_ptr(), db.data_ptr(), None)
     torch.cuda.synchronize()
-    dp = on.bce_keras_grad(p_ref, yf)
-    sref = dp * sm[..., 1] * sm[..., 0]
+    # the backward consumes the stored fp32 p: evaluate the oracle's formula at that p (a saturated pixel whose
+    # fp32 p lands exactly on the clip bound is 'clipped' in fp32 and 'inside' in float64)
+    p64 = pg.astype(np.float64)
+    dp = on.bce_keras_grad(p64, yf)
+    sref = dp * p64 * (1 - p64)
     dlog = np.stack([-sref, sref], -1)
     assert np.abs(da.cpu().numpy() - dlog @ Kh[0, 0].astype(np.float64).T).max() < 1e-6
     assert np.abs(dk.cpu().numpy()[0, 0] - a.astype(np.float64).T @ dlog).max() < 2e-5
