@@ -94,6 +94,7 @@ struct BnParams {
   const float* dgamma; const float* dbeta;
   float* out; long out_ld;
   float* partial;
+  float* absmax;   // bn_bwd_apply: per-block max |dz| (nullable)
   long pixels; int C;
 };
 
@@ -192,11 +193,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnParams p) {
   const bool drop = p.keep < 1.f;
   const float inv_keep = drop ? 1.f / p.keep : 1.f;
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+  float amax = 0.f;
   for (long pix = (long)blockIdx.x * PPB + pl; pix < p.pixels; pix += (long)gridDim.x * PPB) {
     f32x4 dy, xh;
     bn_bwd_elem(p, pix, q, mu, is, ga, be, drop, inv_keep, dy, xh);
     const f32x4 dz = gs * (dy - mdy - xh * mdyx);
     s1 += dz;
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(dz[0]), fabsf(dz[1])), fmaxf(fabsf(dz[2]), fabsf(dz[3]))));
     st4(p.out + pix * p.out_ld + 4 * q, dz);
   }
   if (p.partial) {
@@ -207,6 +210,39 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnParams p) {
       st4(p.partial + (long)blockIdx.x * p.C + 4 * q, s1);
     }
   }
+  if (p.absmax) {
+    __shared__ float smax[4];
+    for (int s = 32; s > 0; s >>= 1) amax = fmaxf(amax, __shfl_xor(amax, s));
+    if ((tid & 63) == 0) smax[tid >> 6] = amax;
+    __syncthreads();
+    if (tid == 0) p.absmax[blockIdx.x] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+  }
+}
+
+// scale = 2^floor(log2(target / max_i partial[i]))  (1 if the tensor is all zero): a power of two, so applying and
+// undoing it is exact in fp32.
+__global__ void pow2_scale_kernel(const float* __restrict__ partial, int n, float target, float* __restrict__ scale) {
+  __shared__ float sm[256];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, partial[i]);
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    m = sm[0];
+    float e = (m > 0.f && isfinite(m)) ? floorf(log2f(target / m)) : 0.f;
+    e = fminf(fmaxf(e, -100.f), 100.f);
+    scale[0] = exp2f(e);
+  }
+}
+extern "C" int dc_pow2_scale_from_absmax(const float* partial, int n, float target, float* scale, dc_stream_t stream) {
+  DC_REQUIRE(partial && scale && n > 0 && target > 0.f, DC_EINVAL, "dc_pow2_scale_from_absmax: bad arguments");
+  hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, target, scale);
+  DC_CHECK_LAUNCH("dc_pow2_scale_from_absmax");
+  return DC_OK;
 }
 
 extern "C" int dc_bn_bwd_blocks(long pixels, int C) { return ew_blocks(pixels, C); }
@@ -228,8 +264,8 @@ extern "C" int dc_bn_bwd_reduce(const float* da, long da_ld, const float* z, con
 
 extern "C" int dc_bn_bwd_apply(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
                                const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
-                               const float* dgamma, const float* dbeta, float* dz, float* dbias_partial, long pixels,
-                               int C, dc_stream_t stream) {
+                               const float* dgamma, const float* dbeta, float* dz, float* dbias_partial,
+                               float* absmax_partial, long pixels, int C, dc_stream_t stream) {
   DC_REQUIRE(da && z && mean && invstd && gamma && beta && dgamma && dbeta && dz, DC_EINVAL,
              "dc_bn_bwd_apply: null pointer");
   DC_REQUIRE(pixels > 0 && da_ld >= C && da_ld % 4 == 0 && keep > 0.f, DC_EINVAL, "dc_bn_bwd_apply: bad sizes");
@@ -238,7 +274,7 @@ extern "C" int dc_bn_bwd_apply(const float* da, long da_ld, const float* z, cons
   BnParams p{};
   p.da = da; p.da_ld = da_ld; p.z = z; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
   p.mask = mask; p.keep = keep; p.seed = seed; p.dgamma = dgamma; p.dbeta = dbeta; p.out = dz; p.out_ld = C;
-  p.partial = dbias_partial; p.pixels = pixels; p.C = C;
+  p.partial = dbias_partial; p.absmax = absmax_partial; p.pixels = pixels; p.C = C;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(pixels, C)), dim3(256), 0, (hipStream_t)stream, p);
   DC_CHECK_LAUNCH("dc_bn_bwd_apply");
   return DC_OK;

@@ -22,24 +22,7 @@
 //     behind ~37k MFMA cycles), written to LDS after the barrier; 2 CTAs/CU give a second layer of overlap;
 //   * epilogue: channel sits on the lane (C/D col = lane&31), so bias / folded-BN affine are per-lane
 //     scalars and the BatchNorm (sum, sumsq) partials are an in-register reduction + one xor-32 shuffle.
-#include "common.h"
-
-struct IgemmParams {
-  const float* in;
-  const float* wp;
-  const float* bias;
-  float* out;
-  float* stats;
-  const float* scale;
-  const float* shift;
-  int N, Hin, Win, Cin;
-  int Hout, Wout, Ncols;
-  int tilesX, tilesY;
-  int relu;
-  int scatterCo;  // 0 = dense NHWC output; >0 = Conv2DTranspose scatter with Co = scatterCo
-  int biasMod;    // bias index = n % biasMod
-  long outLd;     // pixel stride of the output tensor in floats
-};
+#include "igemm_common.h"
 
 template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB, int CK>
 struct IgemmCfg {

@@ -1,0 +1,363 @@
+// Implicit-GEMM convolution with fp32-grade accuracy on the fp16 matrix cores (v_mfma_f32_32x32x16_f16), gfx950.
+//
+// The fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the vector rate, 157 TF/s -- the roof that bounds the fp32
+// path.  The fp16 MFMA is 16x faster per instruction-cycle.  This kernel feeds it an exact
+// two-term split of every fp32 operand,
+//        x = hi + lo,   hi = fp16(x),  lo = fp16(x - hi)        (22-bit significand, |err| <= 2^-22 |x|)
+// and accumulates   a_hi*b_hi + a_hi*b_lo + a_lo*b_hi   in the fp32 accumulator (the dropped lo*lo term is
+// 2^-22 relative): 3 MFMAs replace 8, i.e. 16/3 = 5.3x the fp32 matrix rate at ~4x fp32's rounding noise,
+// well inside the 1e-4 parity budget (tests/test_hip_ops.py, tests/test_engine_gpu.py run both paths).
+// fp16's narrow exponent range is handled with a per-tensor POWER-OF-TWO input scale (exact in fp32) read from
+// device memory: 1 for forward activations (O(1) after BatchNorm), 2^k for gradients (their 1/(N*H*W) factor
+// would otherwise underflow), undone exactly in the epilogue.
+//
+// Structure = the fp32 kernel's (igemm_conv.hip): halo'd input patch staged once per 16-channel chunk, taps are
+// shifted ds_read_b128 windows of the same LDS patch, channel on the lane in the epilogue.  Differences:
+//   * LDS slots hold 8 fp16 channels (16 B): [hi|lo][8-channel group][pixel]; one b128 read = one MFMA operand
+//     (lane half h supplies k = 8h..8h+7, the 32x32x16 operand map);
+//   * activations are split while being written to LDS (v_cvt_pk_f16_f32 x2 + 2 sub per pair);
+//   * weights arrive PRE-split from dc_pack_weights_f16x3 ([tap][K/8][hi|lo][col][8]) and are copied verbatim.
+#include "igemm_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB>
+struct IgemmH {
+  static constexpr int CK = 16;
+  static constexpr int TAPS = KH * KW;
+  static constexpr int WAVES_N = 4 / WAVES_M;
+  static constexpr int RPM = 32 / TW;
+  static constexpr int TH = WAVES_M * MB * RPM;
+  static constexpr int BN = WAVES_N * NB * 32;
+  static constexpr int THI = (TH - 1) * S + KH;
+  static constexpr int TWI = (TW - 1) * S + KW;
+  static constexpr int NPIXH = THI * TWI;
+  static constexpr int PS = ((NPIXH + 5) / 8) * 8 + 2;
+  static constexpr int G4 = CK / 4;   // float4 groups per pixel in HBM
+  static constexpr int G8 = CK / 8;   // 8-channel fp16 slots per pixel in LDS
+  static constexpr int NA = (NPIXH * G4 + 255) / 256;
+  static constexpr int BROWS = TAPS * G8 * 2;  // (tap, g8, hi|lo) rows of BN slots
+  static constexpr int NBV = (BROWS * BN + 255) / 256;
+  static constexpr int A_SLOTS = 2 * G8 * PS;
+  static constexpr int LDS_BYTES = (A_SLOTS + BROWS * BN) * 16;
+  static_assert(256 % BN == 0, "staging assumes BN divides the block size");
+};
+
+__device__ __forceinline__ void split_f16(const f32x4 v, float s, u32x2& hi, u32x2& lo) {
+  f16x4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x = v[e] * s;
+    const _Float16 hh = (_Float16)x;
+    h[e] = hh;
+    l[e] = (_Float16)(x - (float)hh);
+  }
+  hi = __builtin_bit_cast(u32x2, h);
+  lo = __builtin_bit_cast(u32x2, l);
+}
+
+template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB>
+__global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
+  using Cfg = IgemmH<KH, KW, S, PAD, TW, WAVES_M, MB, NB>;
+  constexpr int TAPS = Cfg::TAPS, TH = Cfg::TH, BN = Cfg::BN, TWI = Cfg::TWI, NPIXH = Cfg::NPIXH, CK = Cfg::CK;
+  constexpr int PS = Cfg::PS, G4 = Cfg::G4, G8 = Cfg::G8, NA = Cfg::NA, NBV = Cfg::NBV, RPM = Cfg::RPM;
+  constexpr int BROWS = Cfg::BROWS;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* ldsA = reinterpret_cast<u32x4*>(smem);  // [hl][g8][PS] slots of 8 halfs
+  u32x4* ldsB = ldsA + Cfg::A_SLOTS;             // [tap][g8][hl][BN]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wave_m = wave % WAVES_M, wave_n = wave / WAVES_M;
+
+  int t = blockIdx.x;
+  const int tx = t % p.tilesX; t /= p.tilesX;
+  const int ty = t % p.tilesY;
+  const int img = t / p.tilesY;
+  const int n0 = blockIdx.y * BN;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+  const int Cin4 = p.Cin >> 2, Cin8 = (p.Cin + 7) >> 3;
+  const float in_scale = p.inScale ? *p.inScale : 1.f;
+
+  const f32x4* in4 = reinterpret_cast<const f32x4*>(p.in) + (long)img * p.Hin * p.Win * Cin4;
+  const u32x4* wp4 = reinterpret_cast<const u32x4*>(p.wp);
+
+  constexpr int A_STEP = 256 / G4, B_STEP = 256 / BN;
+  const int a_g = tid % G4, a_pix0 = tid / G4;
+  const int b_j = tid % BN, b_row0 = tid / BN;
+  const bool b_col_ok = n0 + b_j < p.Ncols;
+  int a_goff[NA];
+#pragma unroll
+  for (int it = 0; it < NA; ++it) {
+    const int pix = a_pix0 + it * A_STEP;
+    const int r = pix / TWI, c = pix - r * TWI;
+    const int y = iy0 + r, x = ix0 + c;
+    const bool in_img = pix < NPIXH && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+    a_goff[it] = in_img ? ((y * p.Win + x) * Cin4 + a_g) : -1;
+  }
+
+  f32x4 ra[NA];
+  u32x4 rb[NBV];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const u32x4 zeroi = {0u, 0u, 0u, 0u};
+  auto load_chunk = [&](int c0) {
+    const int cg0 = c0 >> 2;
+    const bool a_ch_ok = (cg0 + a_g) < Cin4;
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const bool ok = a_goff[it] >= 0 && a_ch_ok;
+      ra[it] = ok ? in4[a_goff[it] + cg0] : zero4;
+    }
+    const int c8 = c0 >> 3;
+#pragma unroll
+    for (int it = 0; it < NBV; ++it) {
+      const int row = b_row0 + it * B_STEP;       // (tap, g8, hl)
+      const int tap = row / (2 * G8), g8 = (row >> 1) % G8, hl = row & 1;
+      const bool ok = b_col_ok && row < BROWS && (c8 + g8) < Cin8;
+      rb[it] = ok ? wp4[((long)(tap * Cin8 + c8 + g8) * 2 + hl) * p.Ncols + n0 + b_j] : zeroi;
+    }
+  };
+
+  int a_base[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int mblk = wave_m * MB + mb;
+    const int row = mblk * RPM + li / TW, col = li % TW;
+    a_base[mb] = h * PS + (row * S) * TWI + col * S;      // g8 = h (CK = 16: one k-step of 16 channels per tap)
+  }
+  const int b_base = (h * 2) * BN + wave_n * NB * 32 + li;  // row (tap, g8 = h, hl = 0)
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  load_chunk(0);
+  for (int c0 = 0; c0 < p.Cin; c0 += CK) {
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int pix = a_pix0 + it * A_STEP;
+      if (pix < NPIXH) {
+        u32x2 hi, lo;
+        split_f16(ra[it], in_scale, hi, lo);
+        char* base = smem + ((a_g >> 1) * PS + pix) * 16 + (a_g & 1) * 8;
+        *reinterpret_cast<u32x2*>(base) = hi;
+        *reinterpret_cast<u32x2*>(base + G8 * PS * 16) = lo;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NBV; ++it) {
+      const int row = b_row0 + it * B_STEP;
+      if (row < BROWS) ldsB[row * BN + b_j] = rb[it];
+    }
+    __syncthreads();
+    if (c0 + CK < p.Cin) load_chunk(c0 + CK);
+
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int toff = (tap / KW) * TWI + (tap % KW);
+      f16x8 ah[MB], al[MB], bh[NB], bl[NB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        ah[mb] = __builtin_bit_cast(f16x8, ldsA[a_base[mb] + toff]);
+        al[mb] = __builtin_bit_cast(f16x8, ldsA[a_base[mb] + toff + G8 * PS]);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        bh[nb] = __builtin_bit_cast(f16x8, ldsB[b_base + tap * (2 * G8) * BN + nb * 32]);
+        bl[nb] = __builtin_bit_cast(f16x8, ldsB[b_base + tap * (2 * G8) * BN + BN + nb * 32]);
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl[nb], acc[mb][nb], 0, 0, 0);
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (identical to the fp32 kernel, plus the exact un-scaling) ---------------------------------
+  const float out_scale = 1.f / in_scale;
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = n0 + (wave_n * NB + nb) * 32 + li;
+    const bool n_ok = n < p.Ncols;
+    const float bv = (p.bias && n_ok) ? p.bias[n % p.biasMod] : 0.f;
+    const float sc = (p.scale && n_ok) ? p.scale[n % p.biasMod] : 1.f;
+    const float sh = (p.shift && n_ok) ? p.shift[n % p.biasMod] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    long obase, ostride_y, ostride_x;
+    if (p.scatterCo > 0) {
+      const int ab = n / p.scatterCo, o = n - ab * p.scatterCo;
+      const int W2 = 2 * p.Wout;
+      obase = (((long)img * 2 * p.Hout + (ab >> 1)) * W2 + (ab & 1)) * p.outLd + o;
+      ostride_y = 2 * W2 * p.outLd;
+      ostride_x = 2 * p.outLd;
+    } else {
+      obase = (long)img * p.Hout * p.Wout * p.outLd + n;
+      ostride_y = p.Wout * p.outLd;
+      ostride_x = p.outLd;
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int mblk = wave_m * MB + mb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int oy = oy0 + mblk * RPM + m / TW, ox = ox0 + m % TW;
+        const bool ok = n_ok && oy < p.Hout && ox < p.Wout;
+        float v = acc[mb][nb][r] * out_scale + bv;
+        if (ok) {
+          s1 += v;
+          s2 += v * v;
+          if (p.scale) v = v * sc + sh;
+          if (p.relu) v = fmaxf(v, 0.f);
+          p.out[obase + oy * ostride_y + ox * ostride_x] = v;
+        }
+      }
+    }
+    if (p.stats) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (h == 0) {
+        red[((wave * NB + nb) * 32 + li) * 2 + 0] = s1;
+        red[((wave * NB + nb) * 32 + li) * 2 + 1] = s2;
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    if (tid < Cfg::WAVES_N * NB * 32) {
+      const int wn = tid / (NB * 32), rem = tid % (NB * 32);
+      const int nb = rem / 32, l = rem % 32;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int wm = 0; wm < WAVES_M; ++wm) {
+        const int w = wn * WAVES_M + wm;
+        s1 += red[((w * NB + nb) * 32 + l) * 2 + 0];
+        s2 += red[((w * NB + nb) * 32 + l) * 2 + 1];
+      }
+      const int n = n0 + (wn * NB + nb) * 32 + l;
+      if (n < p.Ncols) {
+        float* dst = p.stats + ((long)blockIdx.x * p.Ncols + n) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB>
+static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name) {
+  using Cfg = IgemmH<KH, KW, S, PAD, TW, WAVES_M, MB, NB>;
+  auto kern = igemm_f16x3_kernel<KH, KW, S, PAD, TW, WAVES_M, MB, NB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    DC_REQUIRE(e == hipSuccess, DC_EHIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+    attr_set = true;
+  }
+  p.tilesX = dc_cdiv(p.Wout, TW);
+  p.tilesY = dc_cdiv(p.Hout, Cfg::TH);
+  dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)dc_cdiv(p.Ncols, Cfg::BN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, p);
+  DC_CHECK_LAUNCH(name);
+  return DC_OK;
+}
+
+// Same tile-shape choice (and therefore the same `tiles` count for the BN partials) as the fp32 kernel.
+static int conv3x3_h_launch(IgemmParams p, hipStream_t st) {
+  if (p.Wout > 16) {
+    if (p.Ncols <= 32) return igemm_h_launch<3, 3, 1, 1, 32, 4, 4, 1>(p, st, "conv3x3_f16x3");
+    return igemm_h_launch<3, 3, 1, 1, 32, 4, 2, 2>(p, st, "conv3x3_f16x3");
+  }
+  if (p.Wout > 8) return igemm_h_launch<3, 3, 1, 1, 16, 4, 2, 2>(p, st, "conv3x3_f16x3");
+  return igemm_h_launch<3, 3, 1, 1, 8, 2, 1, 2>(p, st, "conv3x3_f16x3");
+}
+
+// dst (fp16 pairs, same byte size as the fp32 source):
+//   [tap][K/8][hi|lo][n][8 halfs]  with  value(tap,k,n) = src[(flip ? taps-1-tap : tap)*s_tap + k*s_k + n*s_n]
+__global__ void pack_weights_f16x3_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int taps, int K,
+                                          int Ncols, long s_tap, long s_k, long s_n, int flip, long total) {
+  const int K8 = (K + 7) >> 3;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7);
+    long r = i >> 3;
+    const int n = (int)(r % Ncols); r /= Ncols;
+    const int k8 = (int)(r % K8);
+    const int tap = (int)(r / K8);
+    const int k = k8 * 8 + e;
+    const int ts = flip ? (taps - 1 - tap) : tap;
+    const float x = (k < K) ? src[ts * s_tap + k * s_k + n * s_n] : 0.f;
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    const long slot = ((long)(tap * K8 + k8) * 2) * Ncols + n;
+    dst[slot * 8 + e] = hi;
+    dst[(slot + Ncols) * 8 + e] = lo;
+  }
+}
+
+extern "C" int dc_pack_weights_f16x3(const float* src, void* dst, int taps, int K, int Ncols, long s_tap, long s_k,
+                                     long s_n, int flip, dc_stream_t stream) {
+  DC_REQUIRE(src && dst, DC_EINVAL, "dc_pack_weights_f16x3: null pointer");
+  DC_REQUIRE(taps > 0 && K > 0 && Ncols > 0 && K % 4 == 0, DC_EINVAL, "dc_pack_weights_f16x3: K=%d must be a positive multiple of 4", K);
+  const long total = (long)taps * ((K + 7) / 8) * 8 * Ncols;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_weights_f16x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
+                     reinterpret_cast<_Float16*>(dst), taps, K, Ncols, s_tap, s_k, s_n, flip, total);
+  DC_CHECK_LAUNCH("dc_pack_weights_f16x3");
+  return DC_OK;
+}
+
+extern "C" long dc_pack_weights_f16x3_floats(int taps, int K, int Ncols) {
+  return (long)taps * ((K + 7) / 8) * 8 * Ncols;   // 2 halfs per element = one float's worth of bytes
+}
+
+static int check_h(const char* fn, const void* a, const void* b, const void* c, int N, int H, int W, int Cin, int Cout) {
+  DC_REQUIRE(a && b && c, DC_EINVAL, "%s: null pointer", fn);
+  DC_REQUIRE(dc_aligned16(a) && dc_aligned16(b) && dc_aligned16(c), DC_EINVAL, "%s: pointers must be 16-byte aligned", fn);
+  DC_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, DC_EINVAL, "%s: non-positive dimension", fn);
+  DC_REQUIRE(Cin % 4 == 0, DC_EUNSUP, "%s: Cin=%d must be a multiple of 4", fn, Cin);
+  return DC_OK;
+}
+
+extern "C" int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld,
+                                    float* stats, const float* scale, const float* shift, int relu,
+                                    const float* in_scale, int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
+  int rc = check_h("dc_conv3x3_fwd_f16x3", x, wp16, z, N, H, W, Cin, Cout);
+  if (rc) return rc;
+  DC_REQUIRE((scale == nullptr) == (shift == nullptr), DC_EINVAL, "dc_conv3x3_fwd_f16x3: scale and shift go together");
+  DC_REQUIRE(z_ld >= Cout, DC_EINVAL, "dc_conv3x3_fwd_f16x3: z_ld < Cout");
+  IgemmParams p{};
+  p.in = x; p.wp = reinterpret_cast<const float*>(wp16); p.bias = bias; p.out = z; p.stats = stats;
+  p.scale = scale; p.shift = shift; p.inScale = in_scale;
+  p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = Cout;
+  p.relu = relu; p.scatterCo = 0; p.biasMod = Cout; p.outLd = z_ld;
+  return conv3x3_h_launch(p, (hipStream_t)stream);
+}
+
+extern "C" int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale, int N, int H,
+                                      int W, int Cin, int Cout, dc_stream_t stream) {
+  int rc = check_h("dc_conv3x3_dgrad_f16x3", dz, wp16, dx, N, H, W, Cout, Cin);
+  if (rc) return rc;
+  IgemmParams p{};
+  p.in = dz; p.wp = reinterpret_cast<const float*>(wp16); p.out = dx; p.inScale = in_scale;
+  p.N = N; p.Hin = H; p.Win = W; p.Cin = Cout; p.Hout = H; p.Wout = W; p.Ncols = Cin;
+  p.biasMod = Cin; p.outLd = Cin;
+  return conv3x3_h_launch(p, (hipStream_t)stream);
+}

@@ -13,6 +13,8 @@ Memory plan (sized for 288 GB HBM: nothing is recomputed, nothing is pooled):
     channel halves of one `cat` buffer through the kernels' pixel-stride (ld) arguments;
   * training keeps z (pre-BN) and the block outputs for backward; inference folds BN into the conv epilogue.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -64,7 +66,11 @@ def build_layer_table(nfb=32, drp=0.25):
 
 
 class UNetEngine(object):
-    def __init__(self, window_shape, nb_filters_base=32, prop_dropout_base=0.25, device=None, seed=7535):
+    def __init__(self, window_shape, nb_filters_base=32, prop_dropout_base=0.25, device=None, seed=7535, mfma=None):
+        # mfma: 'f16x3' (default; fp32-grade split-fp16 products on the fp16 matrix cores) or 'f32' (fp32 MFMA)
+        self.mfma = mfma or os.environ.get('DC_MFMA', 'f16x3')
+        if self.mfma not in ('f16x3', 'f32'):
+            raise ValueError("mfma must be 'f16x3' or 'f32', got %r" % self.mfma)
         H, W = window_shape
         if H % 16 or W % 16:
             raise ValueError('window_shape must be a multiple of 16 (4 max-pools), got %r' % (window_shape,))
@@ -112,8 +118,13 @@ class UNetEngine(object):
             if l.kind == 'head' or (l.kind == 'conv' and l.cin == 1):
                 continue
             n = int(np.prod(l.kshape))
-            self.wp_fwd[l.name] = torch.empty(n, dtype=torch.float32, device=dev)
-            self.wp_dgrad[l.name] = torch.empty(n, dtype=torch.float32, device=dev)
+            if self.mfma == 'f16x3' and l.kind == 'conv':
+                # pre-split fp16 (hi, lo) slabs: [tap][K/8][hi|lo][col][8], K padded to a multiple of 8
+                self.wp_fwd[l.name] = torch.empty(self.L.dc_pack_weights_f16x3_floats(9, l.cin, l.cout), dtype=torch.float32, device=dev)
+                self.wp_dgrad[l.name] = torch.empty(self.L.dc_pack_weights_f16x3_floats(9, l.cout, l.cin), dtype=torch.float32, device=dev)
+            else:
+                self.wp_fwd[l.name] = torch.empty(n, dtype=torch.float32, device=dev)
+                self.wp_dgrad[l.name] = torch.empty(n, dtype=torch.float32, device=dev)
         self._bufs = {}
         self._packed_dirty = True
         self._fold_dirty = True
@@ -230,8 +241,9 @@ class UNetEngine(object):
             src = self.pview(self.pflat, l, 'k')
             ci, co = l.cin, l.cout
             if l.kind == 'conv':
-                L.dc_pack_weights(src, _ptr(self.wp_fwd[l.name]), 9, ci, co, ci * co, co, 1, 0, st)
-                L.dc_pack_weights(src, _ptr(self.wp_dgrad[l.name]), 9, co, ci, ci * co, 1, co, 1, st)
+                pack = L.dc_pack_weights_f16x3 if self.mfma == 'f16x3' else L.dc_pack_weights
+                pack(src, _ptr(self.wp_fwd[l.name]), 9, ci, co, ci * co, co, 1, 0, st)
+                pack(src, _ptr(self.wp_dgrad[l.name]), 9, co, ci, ci * co, 1, co, 1, st)
             else:
                 L.dc_pack_weights(src, _ptr(self.wp_fwd[l.name]), 1, ci, 4 * co, 0, 1, ci, 0, st)
                 L.dc_pack_weights(src, _ptr(self.wp_dgrad[l.name]), 4, co, ci, co * ci, ci, 1, 0, st)
@@ -248,6 +260,14 @@ class UNetEngine(object):
                          self.sview(l, 'mmean'), self.sview(l, 'mvar'), self.pview(self.pflat, l, 'b'),
                          BN_EPS, self.stat_ptr(l, 2), self.stat_ptr(l, 3), l.cout, st)
         self._fold_dirty = False
+
+    def _conv_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st):
+        if self.mfma == 'f16x3':
+            self.L.dc_conv3x3_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu, None,
+                                        N, h, w, l.cin, l.cout, st)
+        else:
+            self.L.dc_conv3x3_fwd(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu,
+                                  N, h, w, l.cin, l.cout, st)
 
     # ---- geometry helpers --------------------------------------------------------------------------------
     def _hw(self, lvl):
@@ -331,8 +351,7 @@ class UNetEngine(object):
                 L.dc_conv3x3_c1_fwd(_ptr(x_dev), self.pview(self.pflat, l, 'k'), None, _ptr(dst, coff), ld, None,
                                     sc, sh, 1, N, h, w, l.cout, st)
             elif l.kind == 'conv':
-                L.dc_conv3x3_fwd(_ptr(src), _ptr(self.wp_fwd[l.name]), None, _ptr(dst, coff), ld, None, sc, sh, 1,
-                                 N, h, w, l.cin, l.cout, st)
+                self._conv_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h, w, st)
             else:
                 L.dc_convT2x2_fwd(_ptr(src), _ptr(self.wp_fwd[l.name]), None, _ptr(dst, coff), ld, None, sc, sh, 1,
                                   N, h // 2, w // 2, l.cin, l.cout, st)
@@ -372,6 +391,8 @@ class UNetEngine(object):
         T['stats_ws'] = torch.empty(stats_floats, dtype=torch.float32, device=dev)
         T['part_ws'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['part_ws2'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
+        T['absmax'] = torch.empty(4096, dtype=torch.float32, device=dev)
+        T['dz_scale'] = torch.ones(4, dtype=torch.float32, device=dev)
         T['red_tmp'] = torch.empty(32 * 1024, dtype=torch.float32, device=dev)
         T['wgrad_ws'] = torch.empty(ws_floats, dtype=torch.float32, device=dev)
         T['sums'] = torch.zeros(8, dtype=torch.float64, device=dev)
@@ -420,8 +441,7 @@ class UNetEngine(object):
                                     None, None, 0, N, h, w, l.cout, st)
             elif l.kind == 'conv':
                 tiles = L.dc_conv3x3_tiles(N, h, w, l.cout)
-                L.dc_conv3x3_fwd(_ptr(src), _ptr(self.wp_fwd[l.name]), bias, _ptr(z), l.cout, stats, None, None, 0,
-                                 N, h, w, l.cin, l.cout, st)
+                self._conv_fwd(_ptr(src), l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h, w, st)
             else:
                 tiles = L.dc_convT2x2_tiles(N, h // 2, w // 2, l.cout)
                 groups = 4
@@ -474,13 +494,19 @@ class UNetEngine(object):
                                _ptr(T['part_ws']), pixels, l.cout, st)
             L.dc_bn_bwd_finalize(_ptr(T['part_ws']), blocks, l.cout, dgamma, dbeta, st)
             L.dc_bn_bwd_apply(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed, dgamma, dbeta,
-                              _ptr(T['dz']), _ptr(T['part_ws2']), pixels, l.cout, st)
+                              _ptr(T['dz']), _ptr(T['part_ws2']), _ptr(T['absmax']), pixels, l.cout, st)
+            if self.mfma == 'f16x3':
+                # exact power-of-two scale that brings max|dz| to [512, 1024] before the fp16 split
+                L.dc_pow2_scale_from_absmax(_ptr(T['absmax']), blocks, 1024.0, _ptr(T['dz_scale']), st)
             L.dc_reduce_partials(_ptr(T['part_ws2']), blocks, l.cout, 1.0, self.pview(self.gflat, l, 'b'),
                                  _ptr(T['red_tmp']), st)
             dk = self.pview(self.gflat, l, 'k')
             if l.kind == 'conv':
                 L.dc_conv3x3_wgrad(x_in, _ptr(T['dz']), dk, _ptr(T['wgrad_ws']), N, h, w, l.cin, l.cout, st)
-                if dx_ptr is not None:
+                if dx_ptr is not None and self.mfma == 'f16x3':
+                    L.dc_conv3x3_dgrad_f16x3(_ptr(T['dz']), _ptr(self.wp_dgrad[l.name]), dx_ptr, _ptr(T['dz_scale']),
+                                             N, h, w, l.cin, l.cout, st)
+                elif dx_ptr is not None:
                     L.dc_conv3x3_dgrad(_ptr(T['dz']), _ptr(self.wp_dgrad[l.name]), dx_ptr, N, h, w, l.cin, l.cout, st)
             else:
                 L.dc_convT2x2_wgrad(x_in, _ptr(T['dz']), dk, _ptr(T['wgrad_ws']), N, h // 2, w // 2, l.cin, l.cout, st)

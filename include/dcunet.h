@@ -68,6 +68,21 @@ long dc_conv3x3_wgrad_ws_floats(int N, int H, int W, int Cin, int Cout);
 int dc_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* ws,
                      int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 
+/* ---- split-fp16 ("f16x3") variants: same contraction on the fp16 matrix cores with fp32-grade accuracy ----
+ * Every fp32 operand is split exactly into hi + lo fp16 (22-bit significand) and hi*hi + hi*lo + lo*hi is
+ * accumulated in fp32: 3 fp16 MFMAs replace 8 fp32 ones.  wp16 = dc_pack_weights_f16x3 (same forms/strides as
+ * dc_pack_weights; dc_pack_weights_f16x3_floats() floats of storage).  in_scale: nullable DEVICE scalar, a power of
+ * two applied to the input tensor before the split and undone in the epilogue (fp16 range; 1 for activations,
+ * dc_pow2_scale_from_absmax() for gradients). */
+long dc_pack_weights_f16x3_floats(int taps, int K, int Ncols);
+int dc_pack_weights_f16x3(const float* src, void* dst, int taps, int K, int Ncols,
+                          long s_tap, long s_k, long s_n, int flip, dc_stream_t stream);
+int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, float* stats,
+                         const float* scale, const float* shift, int relu, const float* in_scale,
+                         int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
+                           int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+
 /* ---- Conv2DTranspose(nf, 2, strides=2)  unet_2d_summary.py:156-157 -----------
  * x: [N,H,W,Cin] -> z: [N,2H,2W,Cout].  wp = dc_pack_weights(convT fwd form).
  * stats: float[dc_convT2x2_tiles()][4*Cout][2] (finalize with groups = 4). */
@@ -101,11 +116,15 @@ int dc_bn_bwd_blocks(long pixels, int C);
 int dc_bn_bwd_reduce(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
                      float* partial, long pixels, int C, dc_stream_t stream);
-/* backward, pass 2: dz = gamma*invstd*(dy - dbeta/M - xhat*dgamma/M); dbias_partial[blocks][C] = sum dz. */
+/* backward, pass 2: dz = gamma*invstd*(dy - dbeta/M - xhat*dgamma/M); dbias_partial[blocks][C] = sum dz;
+ * absmax_partial (nullable) [blocks] = max |dz| per block, for dc_pow2_scale_from_absmax. */
 int dc_bn_bwd_apply(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
                     const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
-                    const float* dgamma, const float* dbeta, float* dz, float* dbias_partial,
+                    const float* dgamma, const float* dbeta, float* dz, float* dbias_partial, float* absmax_partial,
                     long pixels, int C, dc_stream_t stream);
+/* scale[0] = 2^floor(log2(target / max_i partial[i])) (1 for an all-zero tensor): the exact power-of-two input scale
+ * of the f16x3 gradient contractions. */
+int dc_pow2_scale_from_absmax(const float* partial, int n, float target, float* scale, dc_stream_t stream);
 
 /* ---- MaxPooling2D(2, strides=2)  :176 ----------------------------------------
  * in strided [N,H,W,C] (in_ld), out dense [N,H/2,W/2,C], idx (nullable) uint8 in {0..3}: FIRST max in

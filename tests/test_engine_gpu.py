@@ -12,9 +12,12 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
 
 
-def make_engine(H, W, nfb, drp=0.25, randomize_bn=True, seed=7535):
+MODES = ['f16x3', 'f32']
+
+
+def make_engine(H, W, nfb, drp=0.25, randomize_bn=True, seed=7535, mfma='f16x3'):
     from deep_calcium_amd.net import UNetEngine
-    eng = UNetEngine((H, W), nb_filters_base=nfb, prop_dropout_base=drp)
+    eng = UNetEngine((H, W), nb_filters_base=nfb, prop_dropout_base=drp, mfma=mfma)
     Wt = on.init_weights(nfb, seed=seed, randomize_bn=randomize_bn)
     eng.set_weights(Wt)
     return eng, Wt
@@ -24,9 +27,10 @@ def dev_masks(masks):
     return {k: torch.from_numpy(v).cuda() for k, v in masks.items()}
 
 
+@pytest.mark.parametrize('mfma', MODES)
 @pytest.mark.parametrize('N,H,W,nfb', [(2, 32, 32, 32), (1, 64, 64, 8), (3, 96, 96, 4), (1, 48, 80, 16)])
-def test_forward_inference_matches_oracle(N, H, W, nfb):
-    eng, Wt = make_engine(H, W, nfb)
+def test_forward_inference_matches_oracle(N, H, W, nfb, mfma):
+    eng, Wt = make_engine(H, W, nfb, mfma=mfma)
     x, _ = on.synthetic_batch(N, H, W)
     p_ref = on.UNetOracle(Wt, nfb).forward(x, training=False)
     p = eng.forward_infer(torch.from_numpy(x).cuda()).cpu().numpy()
@@ -60,9 +64,10 @@ def count_relu_flips(eng, N, cache, masks):
     return flips
 
 
+@pytest.mark.parametrize('mfma', MODES)
 @pytest.mark.parametrize('N,H,W,nfb', [(1, 16, 16, 4), (2, 32, 32, 32), (2, 64, 64, 8)])
-def test_train_forward_backward_matches_oracle(N, H, W, nfb):
-    eng, Wt = make_engine(H, W, nfb)
+def test_train_forward_backward_matches_oracle(N, H, W, nfb, mfma):
+    eng, Wt = make_engine(H, W, nfb, mfma=mfma)
     x, y = on.synthetic_batch(N, H, W)
     masks = on.make_drop_masks(nfb, N, H, W)
     orc = on.UNetOracle(Wt, nfb)
@@ -116,11 +121,12 @@ def test_train_forward_backward_matches_oracle(N, H, W, nfb):
     print('relu gate flips: %d, gradient cosine %.7f' % (flips, cos))
 
 
-def test_train_steps_loss_matches_oracle():
+@pytest.mark.parametrize('mfma', MODES)
+def test_train_steps_loss_matches_oracle(mfma):
     """Two full train steps (fwd + bwd + Keras Adam + BN moving stats), explicit dropout masks: BCE loss and
     the next-step probabilities stay within 1e-4 of the float64 oracle."""
     N, H, W, nfb = 2, 32, 32, 16
-    eng, Wt = make_engine(H, W, nfb, randomize_bn=False)
+    eng, Wt = make_engine(H, W, nfb, randomize_bn=False, mfma=mfma)
     orc = on.UNetOracle(Wt, nfb)
     state = dict(it=0, m={}, v={})
     x, y = on.synthetic_batch(N, H, W)
@@ -151,10 +157,11 @@ def test_train_steps_loss_matches_oracle():
     assert np.abs(p - p_ref).max() < 5e-3      # after 2 Adam steps of size lr the sign-like update amplifies 1e-7 noise
 
 
-def test_determinism_same_input_twice():
+@pytest.mark.parametrize('mfma', MODES)
+def test_determinism_same_input_twice(mfma):
     """Bit-identical gradients across two runs: no atomics anywhere (wgrad slabs / BN partials are fixed-order)."""
     N, H, W, nfb = 2, 32, 32, 32
-    eng, _ = make_engine(H, W, nfb)
+    eng, _ = make_engine(H, W, nfb, mfma=mfma)
     x, y = on.synthetic_batch(N, H, W)
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
     outs = []

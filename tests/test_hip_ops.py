@@ -103,6 +103,45 @@ def test_conv3x3_fwd_dgrad_wgrad(dclib, N, H, W, Ci, Co):
     assert rel_err(dw.cpu().numpy(), dK_ref) < 2e-5
 
 
+@pytest.mark.parametrize('N,H,W,Ci,Co', CONV_SHAPES)
+def test_conv3x3_f16x3_fwd_dgrad(dclib, N, H, W, Ci, Co):
+    """Split-fp16 contraction: fp32-grade accuracy (tolerance as tight as the fp32-MFMA path), gradient-sized
+    inputs (1e-7) survive thanks to the exact power-of-two input scale."""
+    L = dclib
+    rs = np.random.RandomState(N * 1000 + H + Ci)
+    x = rs.standard_normal((N, H, W, Ci)).astype(np.float32)
+    K = (rs.standard_normal((3, 3, Ci, Co)) * np.sqrt(2.0 / (9 * Ci))).astype(np.float32)
+    b = rs.standard_normal(Co).astype(np.float32)
+    dz = (rs.standard_normal((N, H, W, Co)) * 3e-7).astype(np.float32)          # gradient magnitudes (1/(N*H*W))
+    z_ref = on.conv3x3_fwd(x.astype(np.float64), K.astype(np.float64), b.astype(np.float64))
+    dx_ref, _, _ = on.conv3x3_bwd(x.astype(np.float64), K.astype(np.float64), dz.astype(np.float64))
+    Kd = dev(K)
+    wp = torch.empty(L.dc_pack_weights_f16x3_floats(9, Ci, Co), device='cuda')
+    wpd = torch.empty(L.dc_pack_weights_f16x3_floats(9, Co, Ci), device='cuda')
+    L.dc_pack_weights_f16x3(Kd.data_ptr(), wp.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
+    L.dc_pack_weights_f16x3(Kd.data_ptr(), wpd.data_ptr(), 9, Co, Ci, Ci * Co, 1, Co, 1, None)
+    z = torch.full((N, H, W, Co), float('nan'), device='cuda')
+    tiles = L.dc_conv3x3_tiles(N, H, W, Co)
+    stats = torch.zeros(tiles * Co * 2, device='cuda')
+    L.dc_conv3x3_fwd_f16x3(dev(x).data_ptr(), wp.data_ptr(), dev(b).data_ptr(), z.data_ptr(), Co, stats.data_ptr(),
+                           None, None, 0, None, N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert rel_err(z.cpu().numpy(), z_ref) < 2e-5
+    st = stats.cpu().numpy().reshape(tiles, Co, 2).astype(np.float64).sum(0)
+    assert np.allclose(st[:, 0], z_ref.sum((0, 1, 2)), rtol=1e-4, atol=1e-3 * np.sqrt(N * H * W))
+    amax = dev(np.array([np.abs(dz).max()], np.float32))
+    scl = torch.empty(1, device='cuda')
+    L.dc_pow2_scale_from_absmax(amax.data_ptr(), 1, 1024.0, scl.data_ptr(), None)
+    dx = torch.full((N, H, W, Ci), float('nan'), device='cuda')
+    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert rel_err(dx.cpu().numpy(), dx_ref) < 2e-5
+    # without the scale the same input underflows fp16 and the result is garbage-level: the scale is load-bearing
+    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert rel_err(dx.cpu().numpy(), dx_ref) > 1e-3
+
+
 def test_conv3x3_identity_kernel_kat(dclib):
     """Analytic known-answer: centre-tap identity kernel reproduces the input exactly; a one-hot shifted
     tap reproduces the zero-padded shift (pins 'same' padding + cross-correlation orientation)."""
@@ -246,7 +285,10 @@ def test_batchnorm_relu_dropout_fwd_bwd(dclib, pixels_shape, C, keep):
     args = (dad.data_ptr(), C, zd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(), mptr, keep, 0)
     L.dc_bn_bwd_reduce(*args, part1.data_ptr(), M, C, None)
     L.dc_bn_bwd_finalize(part1.data_ptr(), blocks, C, dg.data_ptr(), db.data_ptr(), None)
-    L.dc_bn_bwd_apply(*args, dg.data_ptr(), db.data_ptr(), dz.data_ptr(), part2.data_ptr(), M, C, None)
+    amax = torch.empty(blocks, device='cuda')
+    scl = torch.empty(1, device='cuda')
+    L.dc_bn_bwd_apply(*args, dg.data_ptr(), db.data_ptr(), dz.data_ptr(), part2.data_ptr(), amax.data_ptr(), M, C, None)
+    L.dc_pow2_scale_from_absmax(amax.data_ptr(), blocks, 1024.0, scl.data_ptr(), None)
     L.dc_reduce_partials(part2.data_ptr(), blocks, C, 1.0, dbias.data_ptr(), tmp.data_ptr(), None)
     torch.cuda.synchronize()
     scale = np.abs(dg_ref).max()
@@ -254,6 +296,10 @@ def test_batchnorm_relu_dropout_fwd_bwd(dclib, pixels_shape, C, keep):
     assert np.abs(db.cpu().numpy() - db_ref).max() < 2e-5 * max(np.abs(db_ref).max(), 1)
     assert np.abs(dz.cpu().numpy() - dz_ref).max() < 3e-5 * max(np.abs(dz_ref).max(), 1)
     assert np.abs(dbias.cpu().numpy()).max() < 1e-2          # analytically zero
+    mx = np.abs(dz.cpu().numpy()).max()
+    assert amax.cpu().numpy().max() == mx
+    sv = float(scl.cpu().numpy()[0])
+    assert sv == 2.0 ** np.floor(np.log2(1024.0 / mx)) and 512 < sv * mx <= 1024
 
 
 def test_bn_constant_input_kat(dclib):
