@@ -501,18 +501,24 @@ class UNetEngine(object):
             L.dc_reduce_partials(_ptr(T['part_ws2']), blocks, l.cout, 1.0, self.pview(self.gflat, l, 'b'),
                                  _ptr(T['red_tmp']), st)
             dk = self.pview(self.gflat, l, 'k')
+            dz, ws, f16 = _ptr(T['dz']), _ptr(T['wgrad_ws']), self.mfma == 'f16x3'
+            scale = _ptr(T['dz_scale'])
             if l.kind == 'conv':
-                L.dc_conv3x3_wgrad(x_in, _ptr(T['dz']), dk, _ptr(T['wgrad_ws']), N, h, w, l.cin, l.cout, st)
-                if dx_ptr is not None and self.mfma == 'f16x3':
-                    L.dc_conv3x3_dgrad_f16x3(_ptr(T['dz']), _ptr(self.wp_dgrad[l.name]), dx_ptr, _ptr(T['dz_scale']),
-                                             N, h, w, l.cin, l.cout, st)
+                if f16:
+                    L.dc_conv3x3_wgrad_f16x3(x_in, dz, dk, ws, scale, N, h, w, l.cin, l.cout, st)
+                else:
+                    L.dc_conv3x3_wgrad(x_in, dz, dk, ws, N, h, w, l.cin, l.cout, st)
+                if dx_ptr is not None and f16:
+                    L.dc_conv3x3_dgrad_f16x3(dz, _ptr(self.wp_dgrad[l.name]), dx_ptr, scale, N, h, w, l.cin, l.cout, st)
                 elif dx_ptr is not None:
-                    L.dc_conv3x3_dgrad(_ptr(T['dz']), _ptr(self.wp_dgrad[l.name]), dx_ptr, N, h, w, l.cin, l.cout, st)
+                    L.dc_conv3x3_dgrad(dz, _ptr(self.wp_dgrad[l.name]), dx_ptr, N, h, w, l.cin, l.cout, st)
             else:
-                L.dc_convT2x2_wgrad(x_in, _ptr(T['dz']), dk, _ptr(T['wgrad_ws']), N, h // 2, w // 2, l.cin, l.cout, st)
+                if f16:
+                    L.dc_convT2x2_wgrad_f16x3(x_in, dz, dk, ws, scale, N, h // 2, w // 2, l.cin, l.cout, st)
+                else:
+                    L.dc_convT2x2_wgrad(x_in, dz, dk, ws, N, h // 2, w // 2, l.cin, l.cout, st)
                 if dx_ptr is not None:
-                    L.dc_convT2x2_dgrad(_ptr(T['dz']), _ptr(self.wp_dgrad[l.name]), dx_ptr, N, h // 2, w // 2,
-                                        l.cin, l.cout, st)
+                    L.dc_convT2x2_dgrad(dz, _ptr(self.wp_dgrad[l.name]), dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
 
         g, other = T['gA'], T['gB']      # g holds the gradient w.r.t. the current block's output
         for lvl in (0, 1, 2, 3):

@@ -82,6 +82,12 @@ int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, fl
                          int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
                            int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+/* weight gradients: same workspace (dc_*_wgrad_ws_floats) and fixed-order slab reduction as the fp32 entry points;
+ * dz_scale = device scalar from dc_pow2_scale_from_absmax (nullable). */
+int dc_conv3x3_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,
+                           int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+int dc_convT2x2_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,
+                            int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 
 /* ---- Conv2DTranspose(nf, 2, strides=2)  unet_2d_summary.py:156-157 -----------
  * x: [N,H,W,Cin] -> z: [N,2H,2W,Cout].  wp = dc_pack_weights(convT fwd form).

@@ -136,6 +136,13 @@ def test_conv3x3_f16x3_fwd_dgrad(dclib, N, H, W, Ci, Co):
     L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert rel_err(dx.cpu().numpy(), dx_ref) < 2e-5
+    ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, H, W, Ci, Co), device='cuda')
+    dw = torch.full((3, 3, Ci, Co), float('nan'), device='cuda')
+    L.dc_conv3x3_wgrad_f16x3(dev(x).data_ptr(), dev(dz).data_ptr(), dw.data_ptr(), ws.data_ptr(), scl.data_ptr(),
+                             N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    _, dK_ref, _ = on.conv3x3_bwd(x.astype(np.float64), K.astype(np.float64), dz.astype(np.float64))
+    assert rel_err(dw.cpu().numpy(), dK_ref) < 2e-5
     # without the scale the same input underflows fp16 and the result is garbage-level: the scale is load-bearing
     L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
@@ -219,6 +226,15 @@ def test_convT2x2(dclib, N, H, W, Ci, Co):
     assert np.allclose(st[:, 1], (z_ref ** 2).sum((0, 1, 2)), rtol=1e-4)
     assert rel_err(dx.cpu().numpy(), dx_ref) < 2e-5
     assert rel_err(dw.cpu().numpy(), dK_ref) < 2e-5
+    # split-fp16 weight gradient on gradient-sized dz (scaled exactly by a power of two)
+    dzs = (dz * 1e-7).astype(np.float32)
+    scl = torch.empty(1, device='cuda')
+    L.dc_pow2_scale_from_absmax(dev(np.array([np.abs(dzs).max()], np.float32)).data_ptr(), 1, 1024.0, scl.data_ptr(), None)
+    dw2 = torch.full((2, 2, Co, Ci), float('nan'), device='cuda')
+    L.dc_convT2x2_wgrad_f16x3(dev(x).data_ptr(), dev(dzs).data_ptr(), dw2.data_ptr(), ws.data_ptr(), scl.data_ptr(),
+                              N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert rel_err(dw2.cpu().numpy(), dK_ref * 1e-7) < 2e-5
 
 
 def test_convT_onehot_is_pixel_replication(dclib):
