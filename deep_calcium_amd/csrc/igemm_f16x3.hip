@@ -24,9 +24,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB>
+template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB, int CK_ = 16>
 struct IgemmH {
-  static constexpr int CK = 16;
+  static constexpr int CK = CK_;
   static constexpr int TAPS = KH * KW;
   static constexpr int WAVES_N = 4 / WAVES_M;
   static constexpr int RPM = 32 / TW;
@@ -44,6 +44,7 @@ struct IgemmH {
   static constexpr int A_SLOTS = 2 * G8 * PS;
   static constexpr int LDS_BYTES = (A_SLOTS + BROWS * BN) * 16;
   static_assert(256 % BN == 0, "staging assumes BN divides the block size");
+  static_assert(CK % 16 == 0 && 256 % G4 == 0, "CK must be a multiple of the MFMA k (16)");
 };
 
 __device__ __forceinline__ void split_f16(const f32x4 v, float s, u32x2& hi, u32x2& lo) {
@@ -59,9 +60,9 @@ __device__ __forceinline__ void split_f16(const f32x4 v, float s, u32x2& hi, u32
   lo = __builtin_bit_cast(u32x2, l);
 }
 
-template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB>
+template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB, int CK_>
 __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
-  using Cfg = IgemmH<KH, KW, S, PAD, TW, WAVES_M, MB, NB>;
+  using Cfg = IgemmH<KH, KW, S, PAD, TW, WAVES_M, MB, NB, CK_>;
   constexpr int TAPS = Cfg::TAPS, TH = Cfg::TH, BN = Cfg::BN, TWI = Cfg::TWI, NPIXH = Cfg::NPIXH, CK = Cfg::CK;
   constexpr int PS = Cfg::PS, G4 = Cfg::G4, G8 = Cfg::G8, NA = Cfg::NA, NBV = Cfg::NBV, RPM = Cfg::RPM;
   constexpr int BROWS = Cfg::BROWS;
@@ -129,9 +130,9 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   for (int mb = 0; mb < MB; ++mb) {
     const int mblk = wave_m * MB + mb;
     const int row = mblk * RPM + li / TW, col = li % TW;
-    a_base[mb] = h * PS + (row * S) * TWI + col * S;      // g8 = h (CK = 16: one k-step of 16 channels per tap)
+    a_base[mb] = h * PS + (row * S) * TWI + col * S;      // g8 = 2*ks + h for k-step ks (16 channels each)
   }
-  const int b_base = (h * 2) * BN + wave_n * NB * 32 + li;  // row (tap, g8 = h, hl = 0)
+  const int b_base = (h * 2) * BN + wave_n * NB * 32 + li;  // row (tap 0, g8 = h, hl = 0)
 
   f32x16 acc[MB][NB];
 #pragma unroll
@@ -163,8 +164,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
     if (c0 + CK < p.Cin) load_chunk(c0 + CK);
 
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int toff = (tap / KW) * TWI + (tap % KW);
+    for (int tk = 0; tk < TAPS * (CK / 16); ++tk) {
+      const int tap = tk / (CK / 16), ks = tk % (CK / 16);
+      const int toff = (tap / KW) * TWI + (tap % KW) + 2 * ks * PS;
+      const int boff = (tap * G8 + 2 * ks) * 2 * BN;
       f16x8 ah[MB], al[MB], bh[NB], bl[NB];
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
@@ -173,8 +176,8 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
       }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        bh[nb] = __builtin_bit_cast(f16x8, ldsB[b_base + tap * (2 * G8) * BN + nb * 32]);
-        bl[nb] = __builtin_bit_cast(f16x8, ldsB[b_base + tap * (2 * G8) * BN + BN + nb * 32]);
+        bh[nb] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + nb * 32]);
+        bl[nb] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + BN + nb * 32]);
       }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
@@ -261,10 +264,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB>
+template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB, int CK_ = 16>
 static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name) {
-  using Cfg = IgemmH<KH, KW, S, PAD, TW, WAVES_M, MB, NB>;
-  auto kern = igemm_f16x3_kernel<KH, KW, S, PAD, TW, WAVES_M, MB, NB>;
+  using Cfg = IgemmH<KH, KW, S, PAD, TW, WAVES_M, MB, NB, CK_>;
+  auto kern = igemm_f16x3_kernel<KH, KW, S, PAD, TW, WAVES_M, MB, NB, CK_>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -288,6 +291,23 @@ static int conv3x3_h_launch(IgemmParams p, hipStream_t st) {
   }
   if (p.Wout > 8) return igemm_h_launch<3, 3, 1, 1, 16, 4, 2, 2>(p, st, "conv3x3_f16x3");
   return igemm_h_launch<3, 3, 1, 1, 8, 2, 1, 2>(p, st, "conv3x3_f16x3");
+}
+
+// Conv2DTranspose forward = a 1x1 contraction into 4*Cout columns with the scatter epilogue.  The tile shapes
+// (and so the BN-partial `tiles` count) are those of the fp32 kernel (dc_convT2x2_tiles).
+static int convT_fwd_h_launch(IgemmParams p, hipStream_t st) {
+  if (p.Wout > 16) {
+    if (p.Ncols <= 32) return igemm_h_launch<1, 1, 1, 0, 32, 4, 4, 1, 32>(p, st, "convT2x2_fwd_f16x3");
+    return igemm_h_launch<1, 1, 1, 0, 32, 4, 2, 2, 32>(p, st, "convT2x2_fwd_f16x3");
+  }
+  if (p.Wout > 8) return igemm_h_launch<1, 1, 1, 0, 16, 4, 2, 2, 32>(p, st, "convT2x2_fwd_f16x3");
+  return igemm_h_launch<1, 1, 1, 0, 8, 2, 1, 2, 32>(p, st, "convT2x2_fwd_f16x3");
+}
+// Conv2DTranspose dgrad: 2x2 taps over the stride-2 gradient image (no BN partials => free choice of tile).
+static int convT_dgrad_h_launch(IgemmParams p, hipStream_t st) {
+  if (p.Wout > 16) return igemm_h_launch<2, 2, 2, 0, 32, 4, 1, 2>(p, st, "convT2x2_dgrad_f16x3");
+  if (p.Wout > 8) return igemm_h_launch<2, 2, 2, 0, 16, 4, 1, 2>(p, st, "convT2x2_dgrad_f16x3");
+  return igemm_h_launch<2, 2, 2, 0, 8, 2, 1, 2>(p, st, "convT2x2_dgrad_f16x3");
 }
 
 // dst (fp16 pairs, same byte size as the fp32 source):
@@ -360,4 +380,30 @@ extern "C" int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* 
   p.N = N; p.Hin = H; p.Win = W; p.Cin = Cout; p.Hout = H; p.Wout = W; p.Ncols = Cin;
   p.biasMod = Cin; p.outLd = Cin;
   return conv3x3_h_launch(p, (hipStream_t)stream);
+}
+
+extern "C" int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld,
+                                     float* stats, const float* scale, const float* shift, int relu,
+                                     const float* in_scale, int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
+  int rc = check_h("dc_convT2x2_fwd_f16x3", x, wp16, z, N, H, W, Cin, Cout);
+  if (rc) return rc;
+  DC_REQUIRE((scale == nullptr) == (shift == nullptr), DC_EINVAL, "dc_convT2x2_fwd_f16x3: scale and shift go together");
+  DC_REQUIRE(z_ld >= Cout, DC_EINVAL, "dc_convT2x2_fwd_f16x3: z_ld < Cout");
+  IgemmParams p{};
+  p.in = x; p.wp = reinterpret_cast<const float*>(wp16); p.bias = bias; p.out = z; p.stats = stats;
+  p.scale = scale; p.shift = shift; p.inScale = in_scale;
+  p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = 4 * Cout;
+  p.relu = relu; p.scatterCo = Cout; p.biasMod = Cout; p.outLd = z_ld;
+  return convT_fwd_h_launch(p, (hipStream_t)stream);
+}
+
+extern "C" int dc_convT2x2_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale, int N, int H,
+                                       int W, int Cin, int Cout, dc_stream_t stream) {
+  int rc = check_h("dc_convT2x2_dgrad_f16x3", dz, wp16, dx, N, H, W, Cout, Cin);
+  if (rc) return rc;
+  IgemmParams p{};
+  p.in = dz; p.wp = reinterpret_cast<const float*>(wp16); p.out = dx; p.inScale = in_scale;
+  p.N = N; p.Hin = 2 * H; p.Win = 2 * W; p.Cin = Cout; p.Hout = H; p.Wout = W; p.Ncols = Cin;
+  p.biasMod = Cin; p.outLd = Cin;
+  return convT_dgrad_h_launch(p, (hipStream_t)stream);
 }

@@ -118,10 +118,12 @@ class UNetEngine(object):
             if l.kind == 'head' or (l.kind == 'conv' and l.cin == 1):
                 continue
             n = int(np.prod(l.kshape))
-            if self.mfma == 'f16x3' and l.kind == 'conv':
+            if self.mfma == 'f16x3':
                 # pre-split fp16 (hi, lo) slabs: [tap][K/8][hi|lo][col][8], K padded to a multiple of 8
-                self.wp_fwd[l.name] = torch.empty(self.L.dc_pack_weights_f16x3_floats(9, l.cin, l.cout), dtype=torch.float32, device=dev)
-                self.wp_dgrad[l.name] = torch.empty(self.L.dc_pack_weights_f16x3_floats(9, l.cout, l.cin), dtype=torch.float32, device=dev)
+                sz = self.L.dc_pack_weights_f16x3_floats
+                fw, bw = ((9, l.cin, l.cout), (9, l.cout, l.cin)) if l.kind == 'conv' else ((1, l.cin, 4 * l.cout), (4, l.cout, l.cin))
+                self.wp_fwd[l.name] = torch.empty(sz(*fw), dtype=torch.float32, device=dev)
+                self.wp_dgrad[l.name] = torch.empty(sz(*bw), dtype=torch.float32, device=dev)
             else:
                 self.wp_fwd[l.name] = torch.empty(n, dtype=torch.float32, device=dev)
                 self.wp_dgrad[l.name] = torch.empty(n, dtype=torch.float32, device=dev)
@@ -240,13 +242,13 @@ class UNetEngine(object):
                 continue
             src = self.pview(self.pflat, l, 'k')
             ci, co = l.cin, l.cout
+            pack = L.dc_pack_weights_f16x3 if self.mfma == 'f16x3' else L.dc_pack_weights
             if l.kind == 'conv':
-                pack = L.dc_pack_weights_f16x3 if self.mfma == 'f16x3' else L.dc_pack_weights
                 pack(src, _ptr(self.wp_fwd[l.name]), 9, ci, co, ci * co, co, 1, 0, st)
                 pack(src, _ptr(self.wp_dgrad[l.name]), 9, co, ci, ci * co, 1, co, 1, st)
             else:
-                L.dc_pack_weights(src, _ptr(self.wp_fwd[l.name]), 1, ci, 4 * co, 0, 1, ci, 0, st)
-                L.dc_pack_weights(src, _ptr(self.wp_dgrad[l.name]), 4, co, ci, co * ci, ci, 1, 0, st)
+                pack(src, _ptr(self.wp_fwd[l.name]), 1, ci, 4 * co, 0, 1, ci, 0, st)
+                pack(src, _ptr(self.wp_dgrad[l.name]), 4, co, ci, co * ci, ci, 1, 0, st)
         self._packed_dirty = False
 
     def refold(self):
@@ -268,6 +270,14 @@ class UNetEngine(object):
         else:
             self.L.dc_conv3x3_fwd(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu,
                                   N, h, w, l.cin, l.cout, st)
+
+    def _convT_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st):
+        if self.mfma == 'f16x3':
+            self.L.dc_convT2x2_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu, None,
+                                         N, h, w, l.cin, l.cout, st)
+        else:
+            self.L.dc_convT2x2_fwd(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu,
+                                   N, h, w, l.cin, l.cout, st)
 
     # ---- geometry helpers --------------------------------------------------------------------------------
     def _hw(self, lvl):
@@ -353,8 +363,7 @@ class UNetEngine(object):
             elif l.kind == 'conv':
                 self._conv_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h, w, st)
             else:
-                L.dc_convT2x2_fwd(_ptr(src), _ptr(self.wp_fwd[l.name]), None, _ptr(dst, coff), ld, None, sc, sh, 1,
-                                  N, h // 2, w // 2, l.cin, l.cout, st)
+                self._convT_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h // 2, w // 2, st)
         lo = self.by_name['out']
         L.dc_head_fwd(_ptr(A['d0b']), self.pview(self.pflat, lo, 'k'), self.pview(self.pflat, lo, 'b'), None,
                       _ptr(A['p']), None, N * self.H * self.W, self.nfb, st)
@@ -445,8 +454,7 @@ class UNetEngine(object):
             else:
                 tiles = L.dc_convT2x2_tiles(N, h // 2, w // 2, l.cout)
                 groups = 4
-                L.dc_convT2x2_fwd(_ptr(src), _ptr(self.wp_fwd[l.name]), bias, _ptr(z), l.cout, stats, None, None, 0,
-                                  N, h // 2, w // 2, l.cin, l.cout, st)
+                self._convT_fwd(_ptr(src), l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h // 2, w // 2, st)
             pixels = N * h * w
             mom = l.mom if update_moving else -1.0
             L.dc_bn_stats_finalize(stats, tiles, groups, l.cout, float(pixels), BN_EPS, mom,
@@ -517,7 +525,9 @@ class UNetEngine(object):
                     L.dc_convT2x2_wgrad_f16x3(x_in, dz, dk, ws, scale, N, h // 2, w // 2, l.cin, l.cout, st)
                 else:
                     L.dc_convT2x2_wgrad(x_in, dz, dk, ws, N, h // 2, w // 2, l.cin, l.cout, st)
-                if dx_ptr is not None:
+                if dx_ptr is not None and f16:
+                    L.dc_convT2x2_dgrad_f16x3(dz, _ptr(self.wp_dgrad[l.name]), dx_ptr, scale, N, h // 2, w // 2, l.cin, l.cout, st)
+                elif dx_ptr is not None:
                     L.dc_convT2x2_dgrad(dz, _ptr(self.wp_dgrad[l.name]), dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
 
         g, other = T['gA'], T['gB']      # g holds the gradient w.r.t. the current block's output

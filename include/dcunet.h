@@ -82,6 +82,11 @@ int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, fl
                          int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
                            int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, float* stats,
+                          const float* scale, const float* shift, int relu, const float* in_scale,
+                          int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+int dc_convT2x2_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
+                            int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 /* weight gradients: same workspace (dc_*_wgrad_ws_floats) and fixed-order slab reduction as the fp32 entry points;
  * dz_scale = device scalar from dc_pow2_scale_from_absmax (nullable). */
 int dc_conv3x3_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,

@@ -226,10 +226,26 @@ def test_convT2x2(dclib, N, H, W, Ci, Co):
     assert np.allclose(st[:, 1], (z_ref ** 2).sum((0, 1, 2)), rtol=1e-4)
     assert rel_err(dx.cpu().numpy(), dx_ref) < 2e-5
     assert rel_err(dw.cpu().numpy(), dK_ref) < 2e-5
-    # split-fp16 weight gradient on gradient-sized dz (scaled exactly by a power of two)
+    # split-fp16 variants on gradient-sized dz (scaled exactly by a power of two)
     dzs = (dz * 1e-7).astype(np.float32)
     scl = torch.empty(1, device='cuda')
     L.dc_pow2_scale_from_absmax(dev(np.array([np.abs(dzs).max()], np.float32)).data_ptr(), 1, 1024.0, scl.data_ptr(), None)
+    Kd = dev(K)
+    wp16 = torch.empty(L.dc_pack_weights_f16x3_floats(1, Ci, 4 * Co), device='cuda')
+    wpd16 = torch.empty(L.dc_pack_weights_f16x3_floats(4, Co, Ci), device='cuda')
+    L.dc_pack_weights_f16x3(Kd.data_ptr(), wp16.data_ptr(), 1, Ci, 4 * Co, 0, 1, Ci, 0, None)
+    L.dc_pack_weights_f16x3(Kd.data_ptr(), wpd16.data_ptr(), 4, Co, Ci, Co * Ci, Ci, 1, 0, None)
+    z2 = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device='cuda')
+    stats2 = torch.zeros(tiles * 4 * Co * 2, device='cuda')
+    L.dc_convT2x2_fwd_f16x3(dev(x).data_ptr(), wp16.data_ptr(), dev(b).data_ptr(), z2.data_ptr(), Co, stats2.data_ptr(),
+                            None, None, 0, None, N, H, W, Ci, Co, None)
+    dx2 = torch.full((N, H, W, Ci), float('nan'), device='cuda')
+    L.dc_convT2x2_dgrad_f16x3(dev(dzs).data_ptr(), wpd16.data_ptr(), dx2.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert rel_err(z2.cpu().numpy(), z_ref) < 2e-5
+    st2 = stats2.cpu().numpy().reshape(tiles, 4, Co, 2).astype(np.float64).sum((0, 1))
+    assert np.allclose(st2[:, 1], (z_ref ** 2).sum((0, 1, 2)), rtol=1e-4)
+    assert rel_err(dx2.cpu().numpy(), dx_ref * 1e-7) < 2e-5
     dw2 = torch.full((2, 2, Co, Ci), float('nan'), device='cuda')
     L.dc_convT2x2_wgrad_f16x3(dev(x).data_ptr(), dev(dzs).data_ptr(), dw2.data_ptr(), ws.data_ptr(), scl.data_ptr(),
                               N, H, W, Ci, Co, None)
