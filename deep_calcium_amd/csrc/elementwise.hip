@@ -485,14 +485,24 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
 }
 
-// partial rows are padded to C+4 floats to keep float4 alignment
-__global__ void head_grad_finalize_kernel(const float* __restrict__ partial, int blocks, int C, float* dkh, float* dbh) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c > C) return;
+// partial rows are padded to C+4 floats to keep float4 alignment; one block per output element, fixed order
+__global__ __launch_bounds__(256) void head_grad_finalize_kernel(const float* __restrict__ partial, int blocks, int C,
+                                                                float* dkh, float* dbh) {
+  __shared__ double sm[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
   double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += (double)partial[(long)b * (C + 4) + c];
-  if (c < C) { dkh[2 * c] = (float)(-s); dkh[2 * c + 1] = (float)s; }
-  else { dbh[0] = (float)(-s); dbh[1] = (float)s; }
+  for (int b = tid; b < blocks; b += 256) s += (double)partial[(long)b * (C + 4) + c];
+  sm[tid] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (tid < k) sm[tid] += sm[tid + k];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    s = sm[0];
+    if (c < C) { dkh[2 * c] = (float)(-s); dkh[2 * c + 1] = (float)s; }
+    else { dbh[0] = (float)(-s); dbh[1] = (float)s; }
+  }
 }
 
 static int head_blocks(long pixels) {
@@ -525,8 +535,8 @@ extern "C" int dc_head_bwd(const float* a, const float* p, const uint8_t* y, con
 }
 extern "C" int dc_head_grad_finalize(const float* partial, int blocks, int C, float* dkh, float* dbh, dc_stream_t stream) {
   DC_REQUIRE(partial && dkh && dbh && blocks > 0 && C > 0, DC_EINVAL, "dc_head_grad_finalize: bad arguments");
-  hipLaunchKernelGGL(head_grad_finalize_kernel, dim3(dc_cdiv(C + 1, 256)), dim3(256), 0, (hipStream_t)stream, partial,
-                     blocks, C, dkh, dbh);
+  hipLaunchKernelGGL(head_grad_finalize_kernel, dim3(C + 1), dim3(256), 0, (hipStream_t)stream, partial, blocks, C,
+                     dkh, dbh);
   DC_CHECK_LAUNCH("dc_head_grad_finalize");
   return DC_OK;
 }

@@ -163,30 +163,41 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
     __syncthreads();
     if (c0 + CK < p.Cin) load_chunk(c0 + CK);
 
-#pragma unroll
-    for (int tk = 0; tk < TAPS * (CK / 16); ++tk) {
+    // Software-pipelined operand fetch: the fragments of step tk+1 are requested from LDS before the 3*MB*NB
+    // MFMAs of step tk issue, so the ~100-cycle ds_read latency hides behind 12 x 32 MFMA cycles instead of
+    // stalling every group (hipcc otherwise sinks each ds_read next to its first use).
+    constexpr int NT = TAPS * (CK / 16);
+    f16x8 ah[2][MB], al[2][MB], bh[2][NB], bl[2][NB];
+    auto fetch = [&](int tk, int buf) {
       const int tap = tk / (CK / 16), ks = tk % (CK / 16);
       const int toff = (tap / KW) * TWI + (tap % KW) + 2 * ks * PS;
       const int boff = (tap * G8 + 2 * ks) * 2 * BN;
-      f16x8 ah[MB], al[MB], bh[NB], bl[NB];
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        ah[mb] = __builtin_bit_cast(f16x8, ldsA[a_base[mb] + toff]);
-        al[mb] = __builtin_bit_cast(f16x8, ldsA[a_base[mb] + toff + G8 * PS]);
+        ah[buf][mb] = __builtin_bit_cast(f16x8, ldsA[a_base[mb] + toff]);
+        al[buf][mb] = __builtin_bit_cast(f16x8, ldsA[a_base[mb] + toff + G8 * PS]);
       }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        bh[nb] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + nb * 32]);
-        bl[nb] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + BN + nb * 32]);
+        bh[buf][nb] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + nb * 32]);
+        bl[buf][nb] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + BN + nb * 32]);
       }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk) {
+      const int cur = tk & 1;
+      if (tk + 1 < NT) fetch(tk + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh[nb], acc[mb][nb], 0, 0, 0);
-          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl[nb], acc[mb][nb], 0, 0, 0);
-          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][mb], bh[cur][nb], acc[mb][nb], 0, 0, 0);
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][mb], bl[cur][nb], acc[mb][nb], 0, 0, 0);
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][mb], bh[cur][nb], acc[mb][nb], 0, 0, 0);
         }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }

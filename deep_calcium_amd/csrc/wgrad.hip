@@ -13,8 +13,8 @@
 // operand reads plain conflict-free ds_read_b32 (32 consecutive channels per half-wave).  The B
 // operand is shared by all taps; each tap is a shifted window of the same A tile (halo staged once).
 // A wave owns a 32x32 (m,n) block for ALL taps (taps*16 accumulator registers).  The pixel range is
-// split over CTAs (and over the WK waves of a CTA); every (split, wave) writes its own partial slab
-// and dc_reduce_partials sums the slabs in a fixed order => bit-reproducible, no atomics.
+// split over CTAs (and over the WK waves of a CTA, summed through LDS at the end); every CTA writes one
+// partial slab and dc_reduce_partials sums the slabs in a fixed order => bit-reproducible, no atomics.
 #include "common.h"
 
 struct WgradParams {
@@ -35,6 +35,49 @@ struct WgradCfg {
   static constexpr int A_FLOATS = THI * TWI * CM, B_FLOATS = TH * TW * CN;
   static constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS) * 4;
 };
+
+// Epilogue shared by both kernels: the WK waves of a CTA that own the same (m,n) block first add their
+// accumulators through LDS (free after the last barrier), then ONE slab per CTA goes to HBM.
+// C/D map of the 32x32 MFMA: col = lane&31 -> n, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> m.
+template <int TAPS, int WM, int WN, int WK>
+__device__ __forceinline__ void wgrad_store(const WgradParams& p, f32x16 (&acc)[TAPS], char* smem, int split, int m0,
+                                            int n0, int wm, int wn, int wk, int lane, float out_scale) {
+  const int li = lane & 31, h = lane >> 5;
+  if constexpr (WK > 1) {
+    float* red = reinterpret_cast<float*>(smem);   // [wk-1][wm*WN+wn][16 regs][64 lanes]
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      if (wk > 0) {
+        float* dst = red + ((((wk - 1) * WM * WN + wm * WN + wn) * 16) * 64) + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r * 64] = acc[tap][r];
+      }
+      __syncthreads();
+      if (wk == 0) {
+#pragma unroll
+        for (int k = 0; k < WK - 1; ++k) {
+          const float* src = red + (((k * WM * WN + wm * WN + wn) * 16) * 64) + lane;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[tap][r] += src[r * 64];
+        }
+      }
+      __syncthreads();
+    }
+    if (wk > 0) return;
+  }
+  const int n = n0 + wn * 32 + li;
+  if (n < p.Cn) {
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      float* dst = p.slabs + ((long)split * TAPS + tap) * p.Cm * p.Cn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < p.Cm) dst[(long)m * p.Cn + n] = acc[tap][r] * out_scale;
+      }
+    }
+  }
+}
 
 template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
@@ -115,20 +158,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     __syncthreads();
   }
 
-  // C/D map: col = lane&31 -> n, row = (r&3) + 8*(r>>2) + 4*h -> m
-  const int slab = split * WK + wk;
-  const int n = n0 + wn * 32 + li;
-  if (n < p.Cn) {
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      float* dst = p.slabs + ((long)slab * TAPS + tap) * p.Cm * p.Cn;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < p.Cm) dst[(long)m * p.Cn + n] = acc[tap][r];
-      }
-    }
-  }
+  wgrad_store<TAPS, WM, WN, WK>(p, acc, smem, split, m0, n0, wm, wn, wk, lane, 1.f);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -284,21 +314,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(WgradHParams hp) {
     __syncthreads();
   }
 
-  const float out_scale = 1.f / (a_scale * b_scale);
-  const int li = lane & 31;
-  const int slab = split * WK + wk;
-  const int n = n0 + wn * 32 + li;
-  if (n < p.Cn) {
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      float* dst = p.slabs + ((long)slab * TAPS + tap) * p.Cm * p.Cn;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < p.Cm) dst[(long)m * p.Cn + n] = acc[tap][r] * out_scale;
-      }
-    }
-  }
+  wgrad_store<TAPS, WM, WN, WK>(p, acc, smem, split, m0, n0, wm, wn, wk, lane, 1.f / (a_scale * b_scale));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -314,12 +330,12 @@ static WgradPlan wgrad_plan(int N, int Hb, int Wb, int Cm, int Cn) {
   pl.tilesY = dc_cdiv(Hb, Cfg::TH);
   pl.tilesTotal = N * pl.tilesX * pl.tilesY;
   const int blocks_mn = dc_cdiv(Cm, Cfg::CM) * dc_cdiv(Cn, Cfg::CN);
-  int want = dc_cdiv(1024, blocks_mn);  // ~2 CTAs/CU x 256 CUs x 2 waves of work
+  int want = dc_cdiv(512, blocks_mn);  // 2 CTAs/CU x 256 CUs: one resident wave of CTAs, fewest slabs
   if (want > pl.tilesTotal) want = pl.tilesTotal;
   if (want < 1) want = 1;
   pl.tilesPerSplit = dc_cdiv(pl.tilesTotal, want);
   pl.splits = dc_cdiv(pl.tilesTotal, pl.tilesPerSplit);
-  pl.slabs = pl.splits * Cfg::WK;
+  pl.slabs = pl.splits;  // the WK waves of a CTA are summed in LDS before the slab is written
   return pl;
 }
 

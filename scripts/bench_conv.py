@@ -1,6 +1,6 @@
 """Kernel micro-benchmark: conv3x3 fwd fp32-MFMA vs split-fp16 (f16x3) on the UNet2DS layer shapes (batch 16)."""
 import ctypes, sys, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deep_calcium_amd._lib import lib
 L = lib()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16

@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import unet_numpy as on
 from deep_calcium_amd.net import UNetEngine
 N,H,W,nfb = [int(v) for v in sys.argv[1:5]]
