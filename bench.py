@@ -28,36 +28,40 @@ H = W = 512
 NFB = 32
 
 
+PEAK_FP16_MFMA_TFLOPS = 2500.0    # same guide: dense fp16/bf16 matrix peak (the 2:1-sparse figure is not used)
+
+
 class KernelTimer(object):
     """Proxy around the C-ABI library that brackets every launch of ONE kernel symbol with HIP events
     (recorded on the stream the kernel is launched on) and tallies its algorithmic FLOPs."""
 
-    # the conv3x3 implicit-GEMM instantiation igemm_kernel<3,3,1,1,32,4,2,2,16> (256 px x 64 cols tiles) is what
-    # dc_conv3x3_fwd / dc_conv3x3_dgrad launch whenever W > 16 and the output has > 32 columns (csrc/igemm_conv.hip)
-    KERNEL = 'igemm_kernel<3,3,1,1,TW=32,WAVES_M=4,MB=2,NB=2,CK=16> (conv3x3 fwd+dgrad, 256px x 64col tiles)'
+    # Dominant kernel = the conv3x3 implicit GEMM with 256 px x 64 col tiles, launched by dc_conv3x3_fwd* /
+    # dc_conv3x3_dgrad* whenever W > 16 and the output has > 32 columns (csrc/igemm_conv.hip, igemm_f16x3.hip).
+    KERNELS = {
+        'f16x3': ('igemm_f16x3_kernel<3,3,1,1,32,4,2,2,16>', PEAK_FP16_MFMA_TFLOPS, 3),
+        'f32': ('igemm_kernel<3,3,1,1,32,4,2,2,16>', PEAK_FP32_MFMA_TFLOPS, 1),
+    }
+    # name -> index of N in the argument list (N, H, W, Cin, Cout follow), and which count is the column count
+    SITES = {'dc_conv3x3_fwd': (9, 'cout'), 'dc_conv3x3_dgrad': (3, 'cin'),
+             'dc_conv3x3_fwd_f16x3': (10, 'cout'), 'dc_conv3x3_dgrad_f16x3': (4, 'cin')}
 
     def __init__(self, lib):
         self._lib = lib
         self.records = []
         self.enabled = False
 
-    def _is_dominant(self, name, args):
-        if name == 'dc_conv3x3_fwd':
-            N, Hh, Ww, Cin, Cout = args[9:14]
-            return Ww > 16 and Cout > 32, 2.0 * 9 * Cin * Cout * N * Hh * Ww
-        if name == 'dc_conv3x3_dgrad':
-            N, Hh, Ww, Cin, Cout = args[3:8]
-            return Ww > 16 and Cin > 32, 2.0 * 9 * Cin * Cout * N * Hh * Ww
-        return False, 0.0
-
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
-        if name not in ('dc_conv3x3_fwd', 'dc_conv3x3_dgrad'):
+        if name not in self.SITES:
             return fn
+        i0, colkey = self.SITES[name]
 
         def wrapped(*args):
-            hit, flops = self._is_dominant(name, args) if self.enabled else (False, 0.0)
-            if not hit:
+            if not self.enabled:
+                return fn(*args)
+            N, Hh, Ww, Cin, Cout = args[i0:i0 + 5]
+            ncols = Cout if colkey == 'cout' else Cin
+            if not (Ww > 16 and ncols > 32):
                 return fn(*args)
             e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
             self._lib.dc_event_create(ctypes.byref(e0))
@@ -66,7 +70,7 @@ class KernelTimer(object):
             self._lib.dc_event_record(e0, stream)
             rc = fn(*args)
             self._lib.dc_event_record(e1, stream)
-            self.records.append((e0, e1, flops))
+            self.records.append((e0, e1, 2.0 * 9 * Cin * Cout * N * Hh * Ww))
             return rc
         return wrapped
 
@@ -151,7 +155,7 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, world, args.gpus))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -193,6 +197,7 @@ def main():
 
     if rank == 0:
         achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        kname, peak, mfma_per_flop = KernelTimer.KERNELS[eng.mfma]
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(tpath):
@@ -208,12 +213,16 @@ def main():
             'config': {'workload': 'UNet2DS train step (fwd+BCE+bwd+Keras-Adam), batch=%d 512x512 per GPU, nfb=32 '
                                    '(BASELINE.json configs[2]; configs[3] at 8 GPUs)' % B,
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'bn': 'local',
+                       'contraction': 'fp32 operands split exactly into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 '
+                                      'accumulate' if eng.mfma == 'f16x3' else 'fp32 MFMA',
                        'loss': float(vals[0])},
-            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
-                         'kernel': KernelTimer.KERNEL, 'launches': n_launch,
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': peak,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
+                         'kernel': kname, 'launches': n_launch,
                          'avg_launch_ms': round(k_ms / max(n_launch, 1), 4),
-                         'algorithmic_flops_per_launch': round(k_flops / max(n_launch, 1))},
+                         'algorithmic_flops_per_launch': round(k_flops / max(n_launch, 1)),
+                         'mfma_flops_per_algorithmic_flop': mfma_per_flop,
+                         'matrix_pipe_frac': round(mfma_per_flop * achieved / peak, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

@@ -33,10 +33,12 @@ def init_from_env(backend=None):
     local = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
     use_cuda = torch.cuda.is_available()
     if use_cuda:
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(local % torch.cuda.device_count())
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    dist.init_process_group(backend or ('nccl' if use_cuda else 'gloo'))
+    # DC_DIST_BACKEND=gloo lets several ranks share ONE GPU (functional testing of the N>1 path on a 1-GPU box)
+    backend = backend or os.environ.get('DC_DIST_BACKEND') or ('nccl' if use_cuda else 'gloo')
+    dist.init_process_group(backend)
     return rank(), world_size()
 
 
