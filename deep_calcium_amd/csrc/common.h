@@ -51,3 +51,13 @@ __device__ __forceinline__ float dc_keep_factor(uint64_t seed, uint64_t idx, flo
   float u = (float)(dc_hash32(seed, idx) >> 8) * (1.0f / 16777216.0f);
   return (u >= 1.0f - keep) ? inv_keep : 0.0f;
 }
+
+// Buffer descriptor from provably wave-uniform inputs (readfirstlane), so hipcc does not wrap every buffer op in a
+// waterfall loop.  Out-of-range offsets read zeros / drop stores (hardware bounds check on num_records = bytes).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dc_make_rsrc(const void* ptr, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}

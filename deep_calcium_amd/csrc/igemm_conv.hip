@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   f32x4* ldsB = ldsA + G * PS;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
   const int li = lane & 31, h = lane >> 5;
   const int wave_m = wave % WAVES_M, wave_n = wave / WAVES_M;
 

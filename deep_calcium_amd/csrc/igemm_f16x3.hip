@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   u32x4* ldsB = ldsA + Cfg::A_SLOTS;             // [tap][g8][hl][BN]
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: tile math goes to the SALU
   const int li = lane & 31, h = lane >> 5;
   const int wave_m = wave % WAVES_M, wave_n = wave / WAVES_M;
 
@@ -86,42 +87,54 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   const int Cin4 = p.Cin >> 2, Cin8 = (p.Cin + 7) >> 3;
   const float in_scale = p.inScale ? *p.inScale : 1.f;
 
-  const f32x4* in4 = reinterpret_cast<const f32x4*>(p.in) + (long)img * p.Hin * p.Win * Cin4;
-  const u32x4* wp4 = reinterpret_cast<const u32x4*>(p.wp);
+  // Staging addresses: one buffer descriptor per operand (this image's activations / the packed weight slabs) and
+  // ONE 32-bit byte offset per load, computed once.  Pixels outside the image, columns beyond Ncols and padding
+  // rows carry an out-of-range offset: the hardware bounds check returns zeros, so the loop has no branches, no
+  // selects and no 64-bit address arithmetic; a chunk only adds a wave-uniform constant to the offsets.
+  const __amdgpu_buffer_rsrc_t rsrcA =
+      dc_make_rsrc(p.in + (long)img * p.Hin * p.Win * p.Cin, (unsigned)(p.Hin * p.Win * p.Cin) * 4u);
+  const __amdgpu_buffer_rsrc_t rsrcB = dc_make_rsrc(p.wp, (unsigned)(TAPS * Cin8 * 2 * p.Ncols) * 16u);
+  constexpr unsigned OOB = 0x80000000u;
 
   constexpr int A_STEP = 256 / G4, B_STEP = 256 / BN;
   const int a_g = tid % G4, a_pix0 = tid / G4;
   const int b_j = tid % BN, b_row0 = tid / BN;
-  const bool b_col_ok = n0 + b_j < p.Ncols;
-  int a_goff[NA];
+  unsigned a_voff[NA], b_voff[NBV];
 #pragma unroll
   for (int it = 0; it < NA; ++it) {
     const int pix = a_pix0 + it * A_STEP;
     const int r = pix / TWI, c = pix - r * TWI;
     const int y = iy0 + r, x = ix0 + c;
     const bool in_img = pix < NPIXH && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
-    a_goff[it] = in_img ? ((y * p.Win + x) * Cin4 + a_g) : -1;
+    a_voff[it] = in_img ? (unsigned)(((y * p.Win + x) * p.Cin + 4 * a_g) * 4) : OOB;
+  }
+#pragma unroll
+  for (int it = 0; it < NBV; ++it) {
+    const int row = b_row0 + it * B_STEP;       // (tap, g8, hl)
+    const int tap = row / (2 * G8), g8 = (row >> 1) % G8, hl = row & 1;
+    const bool ok = row < BROWS && (n0 + b_j) < p.Ncols;
+    b_voff[it] = ok ? (unsigned)((((tap * Cin8 + g8) * 2 + hl) * p.Ncols + n0 + b_j) * 16) : OOB;
   }
 
   f32x4 ra[NA];
   u32x4 rb[NBV];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const u32x4 zeroi = {0u, 0u, 0u, 0u};
   auto load_chunk = [&](int c0) {
-    const int cg0 = c0 >> 2;
-    const bool a_ch_ok = (cg0 + a_g) < Cin4;
+    const unsigned a_add = (unsigned)c0 * 4u, b_add = (unsigned)(c0 >> 3) * 2u * (unsigned)p.Ncols * 16u;
+    const bool partial = c0 + CK > p.Cin;     // wave-uniform; only the ragged last chunk of Cin % 16 != 0
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
-      const bool ok = a_goff[it] >= 0 && a_ch_ok;
-      ra[it] = ok ? in4[a_goff[it] + cg0] : zero4;
+      unsigned off = a_voff[it] + a_add;
+      if (partial && c0 + 4 * a_g >= p.Cin) off = OOB;
+      ra[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0));
     }
-    const int c8 = c0 >> 3;
 #pragma unroll
     for (int it = 0; it < NBV; ++it) {
-      const int row = b_row0 + it * B_STEP;       // (tap, g8, hl)
-      const int tap = row / (2 * G8), g8 = (row >> 1) % G8, hl = row & 1;
-      const bool ok = b_col_ok && row < BROWS && (c8 + g8) < Cin8;
-      rb[it] = ok ? wp4[((long)(tap * Cin8 + c8 + g8) * 2 + hl) * p.Ncols + n0 + b_j] : zeroi;
+      unsigned off = b_voff[it] + b_add;
+      if (partial) {
+        const int row = b_row0 + it * B_STEP;
+        if ((c0 >> 3) + ((row >> 1) % G8) >= Cin8) off = OOB;
+      }
+      rb[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, off, 0, 0);
     }
   };
 
@@ -202,9 +215,17 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue (identical to the fp32 kernel, plus the exact un-scaling) ---------------------------------
+  // ---- epilogue: C/D col = lane&31 -> output column n, row m = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel --------
+  // Stores go through a buffer descriptor of this image's output; pixels outside the image / columns beyond
+  // Ncols get an out-of-range offset and are dropped by the bounds check (no branches, 32-bit offsets).
   const float out_scale = 1.f / in_scale;
   float* red = reinterpret_cast<float*>(smem);
+  const bool scatter = p.scatterCo > 0;
+  const long out_img_floats = scatter ? 4L * p.Hout * p.Wout * p.outLd : (long)p.Hout * p.Wout * p.outLd;
+  const __amdgpu_buffer_rsrc_t rsrcO = dc_make_rsrc(p.out + (long)img * out_img_floats, (unsigned)(out_img_floats * 4));
+  const int ld = (int)p.outLd;
+  const int sy = scatter ? 4 * p.Wout * ld : p.Wout * ld;   // floats per output-pixel row step
+  const int sx = scatter ? 2 * ld : ld;                     // floats per output-pixel column step
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int n = n0 + (wave_n * NB + nb) * 32 + li;
@@ -213,34 +234,28 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
     const float sc = (p.scale && n_ok) ? p.scale[n % p.biasMod] : 1.f;
     const float sh = (p.shift && n_ok) ? p.shift[n % p.biasMod] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    long obase, ostride_y, ostride_x;
-    if (p.scatterCo > 0) {
+    int colterm = n;
+    if (scatter) {
       const int ab = n / p.scatterCo, o = n - ab * p.scatterCo;
-      const int W2 = 2 * p.Wout;
-      obase = (((long)img * 2 * p.Hout + (ab >> 1)) * W2 + (ab & 1)) * p.outLd + o;
-      ostride_y = 2 * W2 * p.outLd;
-      ostride_x = 2 * p.outLd;
-    } else {
-      obase = (long)img * p.Hout * p.Wout * p.outLd + n;
-      ostride_y = p.Wout * p.outLd;
-      ostride_x = p.outLd;
+      colterm = ((ab >> 1) * 2 * p.Wout + (ab & 1)) * ld + o;
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      const int mblk = wave_m * MB + mb;
+      const int mblk = wave_m * MB + mb;                       // wave-uniform
+      const int oyb = oy0 + mblk * RPM, oxb = ox0 + 4 * h;
+      const unsigned base = (unsigned)((oyb * sy + oxb * sx + colterm) * 4);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int oy = oy0 + mblk * RPM + m / TW, ox = ox0 + m % TW;
-        const bool ok = n_ok && oy < p.Hout && ox < p.Wout;
+        const int mr = (r & 3) + 8 * (r >> 2);                 // compile-time; + 4h stays inside one tile row
+        const int rowc = mr / TW, colc = mr % TW;
+        const bool ok = n_ok && (oyb + rowc) < p.Hout && (oxb + colc) < p.Wout;
         float v = acc[mb][nb][r] * out_scale + bv;
-        if (ok) {
-          s1 += v;
-          s2 += v * v;
-          if (p.scale) v = v * sc + sh;
-          if (p.relu) v = fmaxf(v, 0.f);
-          p.out[obase + oy * ostride_y + ox * ostride_x] = v;
-        }
+        s1 += ok ? v : 0.f;
+        s2 += ok ? v * v : 0.f;
+        if (p.scale) v = v * sc + sh;
+        if (p.relu) v = fmaxf(v, 0.f);
+        const unsigned off = ok ? base + (unsigned)((rowc * sy + colc * sx) * 4) : OOB;   // scalar addend
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, off, 0, 0);
       }
     }
     if (p.stats) {

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   float* ldsA = reinterpret_cast<float*>(smem);
   float* ldsB = ldsA + Cfg::A_FLOATS;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
   const int wm = wave % WM, wn = (wave / WM) % WN, wk = wave / (WM * WN);
   const int m0 = blockIdx.y * CM, n0 = blockIdx.z * CN;
@@ -222,7 +223,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(WgradHParams hp) {
   char* ldsBh = smem + 2 * A_IMG;
   char* ldsBl = smem + 2 * A_IMG + B_IMG;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, cb = (lane >> 4) & 1, c = lane & 15, q = c >> 2, pp = c & 3;
   const int wm = wave % WM, wn = (wave / WM) % WN, wk = wave / (WM * WN);
   const int m0 = blockIdx.y * CM, n0 = blockIdx.z * CN;
@@ -257,36 +259,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(WgradHParams hp) {
     const int img = t / p.tilesY;
     const int py0 = ty * TH, px0 = tx * TW;
     const int ay0 = py0 * S - PAD, ax0 = px0 * S - PAD;
+    // Staging through buffer descriptors of this image's two tensors: 32-bit (24-bit multiply) offsets, rows above
+    // / below the image fall outside the descriptor and read as zeros; only the left/right edge needs a compare.
     {
-      constexpr int C4 = CM / 4, TOTAL = APIX * C4;
-      const f32x4* src = reinterpret_cast<const f32x4*>(p.A + (long)img * p.Ha * p.Wa * p.Cm);
-      for (int idx = tid; idx < TOTAL; idx += 256) {
-        const int pix = idx / C4, c4 = idx - pix * C4;
-        const int r = pix / TWI, cc = pix - r * TWI;
-        const int y = ay0 + r, x = ax0 + cc;
-        const bool ok = y >= 0 && y < p.Ha && x >= 0 && x < p.Wa && (m0 + 4 * c4) < p.Cm;
-        const f32x4 v = ok ? src[((long)(y * p.Wa + x) * p.Cm + m0) / 4 + c4] : zero4;
+      constexpr int C4 = CM / 4, TOTAL = APIX * C4, PSTEP = 256 / C4;
+      const __amdgpu_buffer_rsrc_t rs = dc_make_rsrc(p.A + (long)img * p.Ha * p.Wa * p.Cm, (unsigned)(p.Ha * p.Wa * p.Cm) * 4u);
+      const int c4 = tid % C4;
+      const bool ch_ok = (m0 + 4 * c4) < p.Cm;
+      const int rowb = p.Wa * p.Cm * 4;                                   // bytes per image row
+      const int base = (ay0 * p.Wa + ax0) * p.Cm * 4 + (m0 + 4 * c4) * 4;  // may be negative: wraps out of range
+      const int lbase = (c4 >> 3) * A_PLANE + (c4 & 7) * 8;
+#pragma unroll 3
+      for (int k = 0; k < (TOTAL + 255) / 256; ++k) {
+        const int pix = tid / C4 + k * PSTEP;
+        const int r = __umul24(pix, (65536 + TWI - 1) / TWI) >> 16;       // pix / TWI for pix < 4096
+        const int cc = pix - __umul24(r, TWI);
+        const bool ok = ch_ok && pix < APIX && (unsigned)(ax0 + cc) < (unsigned)p.Wa;
+        const unsigned off = ok ? (unsigned)(base + __mul24(r, rowb) + __mul24(cc, p.Cm * 4)) : 0x80000000u;
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
         u32x2 hi, lo;
         split4_f16(v, a_scale, hi, lo);
-        const int off = (c4 >> 3) * A_PLANE + pix * 64 + (c4 & 7) * 8;
-        *reinterpret_cast<u32x2*>(ldsAh + off) = hi;
-        *reinterpret_cast<u32x2*>(ldsAl + off) = lo;
+        if (pix < APIX) {
+          *reinterpret_cast<u32x2*>(ldsAh + lbase + pix * 64) = hi;
+          *reinterpret_cast<u32x2*>(ldsAl + lbase + pix * 64) = lo;
+        }
       }
     }
     {
-      constexpr int C4 = CN / 4, TOTAL = BPIX * C4;
-      const f32x4* src = reinterpret_cast<const f32x4*>(p.B + (long)img * p.Hb * p.Wb * p.Cn);
-      for (int idx = tid; idx < TOTAL; idx += 256) {
-        const int pix = idx / C4, c4 = idx - pix * C4;
-        const int r = pix / TW, cc = pix - r * TW;
-        const int y = py0 + r, x = px0 + cc;
-        const bool ok = y < p.Hb && x < p.Wb && (n0 + 4 * c4) < p.Cn;
-        const f32x4 v = ok ? src[((long)(y * p.Wb + x) * p.Cn + n0) / 4 + c4] : zero4;
+      constexpr int C4 = CN / 4, TOTAL = BPIX * C4, PSTEP = 256 / C4;
+      const __amdgpu_buffer_rsrc_t rs = dc_make_rsrc(p.B + (long)img * p.Hb * p.Wb * p.Cn, (unsigned)(p.Hb * p.Wb * p.Cn) * 4u);
+      const int c4 = tid % C4;
+      const bool ch_ok = (n0 + 4 * c4) < p.Cn;
+      const int rowb = p.Wb * p.Cn * 4;
+      const int base = (py0 * p.Wb + px0) * p.Cn * 4 + (n0 + 4 * c4) * 4;
+      const int lbase = (c4 >> 3) * B_PLANE + (c4 & 7) * 8;
+#pragma unroll 4
+      for (int k = 0; k < (TOTAL + 255) / 256; ++k) {
+        const int pix = tid / C4 + k * PSTEP;
+        const int r = pix / TW, cc = pix % TW;                           // TW is a power of two
+        const bool ok = ch_ok && pix < BPIX && (px0 + cc) < p.Wb;
+        const unsigned off = ok ? (unsigned)(base + __mul24(r, rowb) + __mul24(cc, p.Cn * 4)) : 0x80000000u;
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
         u32x2 hi, lo;
         split4_f16(v, b_scale, hi, lo);
-        const int off = (c4 >> 3) * B_PLANE + pix * 64 + (c4 & 7) * 8;
-        *reinterpret_cast<u32x2*>(ldsBh + off) = hi;
-        *reinterpret_cast<u32x2*>(ldsBl + off) = lo;
+        if (pix < BPIX) {
+          *reinterpret_cast<u32x2*>(ldsBh + lbase + pix * 64) = hi;
+          *reinterpret_cast<u32x2*>(ldsBl + lbase + pix * 64) = lo;
+        }
       }
     }
     __syncthreads();
