@@ -15,15 +15,7 @@
 // A wave owns a 32x32 (m,n) block for ALL taps (taps*16 accumulator registers).  The pixel range is
 // split over CTAs (and over the WK waves of a CTA, summed through LDS at the end); every CTA writes one
 // partial slab and dc_reduce_partials sums the slabs in a fixed order => bit-reproducible, no atomics.
-#include "common.h"
-
-struct WgradParams {
-  const float* A;
-  const float* B;
-  float* slabs;
-  int N, Ha, Wa, Cm, Hb, Wb, Cn;
-  int tilesX, tilesY, tilesTotal, tilesPerSplit;
-};
+#include "wgrad_common.h"
 
 template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WN>
 struct WgradCfg {
@@ -35,49 +27,6 @@ struct WgradCfg {
   static constexpr int A_FLOATS = THI * TWI * CM, B_FLOATS = TH * TW * CN;
   static constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS) * 4;
 };
-
-// Epilogue shared by both kernels: the WK waves of a CTA that own the same (m,n) block first add their
-// accumulators through LDS (free after the last barrier), then ONE slab per CTA goes to HBM.
-// C/D map of the 32x32 MFMA: col = lane&31 -> n, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> m.
-template <int TAPS, int WM, int WN, int WK>
-__device__ __forceinline__ void wgrad_store(const WgradParams& p, f32x16 (&acc)[TAPS], char* smem, int split, int m0,
-                                            int n0, int wm, int wn, int wk, int lane, float out_scale) {
-  const int li = lane & 31, h = lane >> 5;
-  if constexpr (WK > 1) {
-    float* red = reinterpret_cast<float*>(smem);   // [wk-1][wm*WN+wn][16 regs][64 lanes]
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      if (wk > 0) {
-        float* dst = red + ((((wk - 1) * WM * WN + wm * WN + wn) * 16) * 64) + lane;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dst[r * 64] = acc[tap][r];
-      }
-      __syncthreads();
-      if (wk == 0) {
-#pragma unroll
-        for (int k = 0; k < WK - 1; ++k) {
-          const float* src = red + (((k * WM * WN + wm * WN + wn) * 16) * 64) + lane;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[tap][r] += src[r * 64];
-        }
-      }
-      __syncthreads();
-    }
-    if (wk > 0) return;
-  }
-  const int n = n0 + wn * 32 + li;
-  if (n < p.Cn) {
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      float* dst = p.slabs + ((long)split * TAPS + tap) * p.Cm * p.Cn;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < p.Cm) dst[(long)m * p.Cn + n] = acc[tap][r] * out_scale;
-      }
-    }
-  }
-}
 
 template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
@@ -163,180 +112,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Split-fp16 variant (see igemm_f16x3.hip for the numerics): k = 16 pixels per v_mfma_f32_32x32x16_f16.
-// The contraction index (pixel) is the ROW index of the NHWC tiles, so the MFMA fragments (8 consecutive k per
-// lane) are fetched with the hardware-transposing ds_read_b64_tr_b16: each 16-lane group reads a 4-pixel x
-// 16-channel block and every lane receives its channel's 4 pixels.  LDS holds fp16 hi and lo images of both
-// tiles as 32-channel planes ([plane][pixel][32 ch] = 64-B rows): 4 consecutive pixel rows of one plane are 256
-// contiguous bytes, so the transposed reads are bank-conflict-free and every tap / k-step offset folds into the
-// instruction's immediate.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((__vector_size__(4 * sizeof(short)))) short tr_v4i16;
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-struct WgradHParams {
-  WgradParams g;
-  const float* aScale;  // nullable device scalars (powers of two)
-  const float* bScale;
-};
-
-__device__ __forceinline__ f16x8 tr_frag(const char* base, int off1, int off2) {
-  typedef __attribute__((address_space(3))) tr_v4i16* lds_p;
-  const tr_v4i16 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off1));
-  const tr_v4i16 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off2));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  s16x8 v = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
-  return __builtin_bit_cast(f16x8, v);
-}
-
-__device__ __forceinline__ void split4_f16(const f32x4 v, float s, u32x2& hi, u32x2& lo) {
-  f16x4 h, l;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float x = v[e] * s;
-    const _Float16 hh = (_Float16)x;
-    h[e] = hh;
-    l[e] = (_Float16)(x - (float)hh);
-  }
-  hi = __builtin_bit_cast(u32x2, h);
-  lo = __builtin_bit_cast(u32x2, l);
-}
-
-template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(WgradHParams hp) {
-  using Cfg = WgradCfg<KH, KW, S, PAD, TW, RW, WM, WN>;
-  constexpr int TAPS = Cfg::TAPS, WK = Cfg::WK, TH = Cfg::TH, CM = Cfg::CM, CN = Cfg::CN;
-  constexpr int THI = Cfg::THI, TWI = Cfg::TWI;
-  constexpr int APIX = THI * TWI, BPIX = TH * TW;
-  constexpr int A_PLANE = APIX * 64, B_PLANE = BPIX * 64;       // bytes of one 32-channel fp16 plane
-  constexpr int A_IMG = WM * A_PLANE, B_IMG = WN * B_PLANE;     // one (hi or lo) image
-  constexpr int KROWS = (TW >= 16) ? 1 : 16 / TW;               // pixel rows covered by one 16-pixel k-step
-  constexpr int KX = (TW >= 16) ? TW / 16 : 1;                  // k-steps along a row
-  static_assert(RW % KROWS == 0, "rows per wave must be a multiple of the k-step height");
-  static_assert(2 * (A_IMG + B_IMG) == Cfg::LDS_BYTES, "fp16 hi+lo images occupy the fp32 tile bytes");
-  const WgradParams& p = hp.g;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ldsAh = smem;
-  char* ldsAl = smem + A_IMG;
-  char* ldsBh = smem + 2 * A_IMG;
-  char* ldsBl = smem + 2 * A_IMG + B_IMG;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, cb = (lane >> 4) & 1, c = lane & 15, q = c >> 2, pp = c & 3;
-  const int wm = wave % WM, wn = (wave / WM) % WN, wk = wave / (WM * WN);
-  const int m0 = blockIdx.y * CM, n0 = blockIdx.z * CN;
-  const int split = blockIdx.x;
-  const float a_scale = hp.aScale ? *hp.aScale : 1.f;
-  const float b_scale = hp.bScale ? *hp.bScale : 1.f;
-
-  // lane-constant byte offsets of the two transposed reads of a k-step whose first pixel is (row 0, x 0)
-  int offA[2], offB[2];
-#pragma unroll
-  for (int r2 = 0; r2 < 2; ++r2) {
-    const int kpix = 8 * h + q + 4 * r2;
-    const int ky = (TW >= 16) ? 0 : kpix / TW, kx = (TW >= 16) ? kpix : kpix % TW;
-    offA[r2] = wm * A_PLANE + ((ky * S) * TWI + kx * S) * 64 + cb * 32 + pp * 8;
-    offB[r2] = wn * B_PLANE + (ky * TW + kx) * 64 + cb * 32 + pp * 8;
-  }
-
-  f32x16 acc[TAPS];
-#pragma unroll
-  for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  const int tile_beg = split * p.tilesPerSplit;
-  const int tile_end = min(tile_beg + p.tilesPerSplit, p.tilesTotal);
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-  for (int tile = tile_beg; tile < tile_end; ++tile) {
-    int t = tile;
-    const int tx = t % p.tilesX; t /= p.tilesX;
-    const int ty = t % p.tilesY;
-    const int img = t / p.tilesY;
-    const int py0 = ty * TH, px0 = tx * TW;
-    const int ay0 = py0 * S - PAD, ax0 = px0 * S - PAD;
-    // Staging through buffer descriptors of this image's two tensors: 32-bit (24-bit multiply) offsets, rows above
-    // / below the image fall outside the descriptor and read as zeros; only the left/right edge needs a compare.
-    {
-      constexpr int C4 = CM / 4, TOTAL = APIX * C4, PSTEP = 256 / C4;
-      const __amdgpu_buffer_rsrc_t rs = dc_make_rsrc(p.A + (long)img * p.Ha * p.Wa * p.Cm, (unsigned)(p.Ha * p.Wa * p.Cm) * 4u);
-      const int c4 = tid % C4;
-      const bool ch_ok = (m0 + 4 * c4) < p.Cm;
-      const int rowb = p.Wa * p.Cm * 4;                                   // bytes per image row
-      const int base = (ay0 * p.Wa + ax0) * p.Cm * 4 + (m0 + 4 * c4) * 4;  // may be negative: wraps out of range
-      const int lbase = (c4 >> 3) * A_PLANE + (c4 & 7) * 8;
-#pragma unroll 3
-      for (int k = 0; k < (TOTAL + 255) / 256; ++k) {
-        const int pix = tid / C4 + k * PSTEP;
-        const int r = __umul24(pix, (65536 + TWI - 1) / TWI) >> 16;       // pix / TWI for pix < 4096
-        const int cc = pix - __umul24(r, TWI);
-        const bool ok = ch_ok && pix < APIX && (unsigned)(ax0 + cc) < (unsigned)p.Wa;
-        const unsigned off = ok ? (unsigned)(base + __mul24(r, rowb) + __mul24(cc, p.Cm * 4)) : 0x80000000u;
-        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-        u32x2 hi, lo;
-        split4_f16(v, a_scale, hi, lo);
-        if (pix < APIX) {
-          *reinterpret_cast<u32x2*>(ldsAh + lbase + pix * 64) = hi;
-          *reinterpret_cast<u32x2*>(ldsAl + lbase + pix * 64) = lo;
-        }
-      }
-    }
-    {
-      constexpr int C4 = CN / 4, TOTAL = BPIX * C4, PSTEP = 256 / C4;
-      const __amdgpu_buffer_rsrc_t rs = dc_make_rsrc(p.B + (long)img * p.Hb * p.Wb * p.Cn, (unsigned)(p.Hb * p.Wb * p.Cn) * 4u);
-      const int c4 = tid % C4;
-      const bool ch_ok = (n0 + 4 * c4) < p.Cn;
-      const int rowb = p.Wb * p.Cn * 4;
-      const int base = (py0 * p.Wb + px0) * p.Cn * 4 + (n0 + 4 * c4) * 4;
-      const int lbase = (c4 >> 3) * B_PLANE + (c4 & 7) * 8;
-#pragma unroll 4
-      for (int k = 0; k < (TOTAL + 255) / 256; ++k) {
-        const int pix = tid / C4 + k * PSTEP;
-        const int r = pix / TW, cc = pix % TW;                           // TW is a power of two
-        const bool ok = ch_ok && pix < BPIX && (px0 + cc) < p.Wb;
-        const unsigned off = ok ? (unsigned)(base + __mul24(r, rowb) + __mul24(cc, p.Cn * 4)) : 0x80000000u;
-        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-        u32x2 hi, lo;
-        split4_f16(v, b_scale, hi, lo);
-        if (pix < BPIX) {
-          *reinterpret_cast<u32x2*>(ldsBh + lbase + pix * 64) = hi;
-          *reinterpret_cast<u32x2*>(ldsBl + lbase + pix * 64) = lo;
-        }
-      }
-    }
-    __syncthreads();
-
-#pragma unroll
-    for (int rr = 0; rr < RW; rr += KROWS) {
-      const int prow = wk * RW + rr;
-#pragma unroll
-      for (int xs = 0; xs < KX; ++xs) {
-        const int kb = (prow * TW + xs * 16) * 64;                       // B-tile byte offset of the k-step
-        const int ka = ((prow * S) * TWI + xs * 16 * S) * 64;            // A-tile byte offset (tap 0,0)
-        const f16x8 bh = tr_frag(ldsBh, offB[0] + kb, offB[1] + kb);
-        const f16x8 bl = tr_frag(ldsBl, offB[0] + kb, offB[1] + kb);
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-          const int toff = ((tap / KW) * TWI + (tap % KW)) * 64;
-          const f16x8 ah = tr_frag(ldsAh, offA[0] + ka + toff, offA[1] + ka + toff);
-          const f16x8 al = tr_frag(ldsAl, offA[0] + ka + toff, offA[1] + ka + toff);
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[tap], 0, 0, 0);
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[tap], 0, 0, 0);
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[tap], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  wgrad_store<TAPS, WM, WN, WK>(p, acc, smem, split, m0, n0, wm, wn, wk, lane, 1.f / (a_scale * b_scale));
-}
-
-// ---------------------------------------------------------------------------------------------------
 struct WgradPlan {
   int splits, slabs, tilesX, tilesY, tilesTotal, tilesPerSplit;
 };
@@ -390,32 +165,6 @@ static int wgrad_launch(const float* A, const float* B, float* dw, float* ws, in
   return dc_reduce_partials(ws, pl.slabs, L, 1.0f, dw, ws + (long)pl.slabs * L, (dc_stream_t)st);
 }
 
-template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WN>
-static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, const float* aScale, const float* bScale,
-                          int N, int Ha, int Wa, int Hb, int Wb, int Cm, int Cn, hipStream_t st, const char* name) {
-  using Cfg = WgradCfg<KH, KW, S, PAD, TW, RW, WM, WN>;
-  auto kern = wgrad_f16x3_kernel<KH, KW, S, PAD, TW, RW, WM, WN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    DC_REQUIRE(e == hipSuccess, DC_EHIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
-    attr_set = true;
-  }
-  WgradPlan pl = wgrad_plan<KH, KW, S, PAD, TW, RW, WM, WN>(N, Hb, Wb, Cm, Cn);
-  WgradHParams hp;
-  WgradParams& p = hp.g;
-  p.A = A; p.B = B; p.slabs = ws;
-  p.N = N; p.Ha = Ha; p.Wa = Wa; p.Cm = Cm; p.Hb = Hb; p.Wb = Wb; p.Cn = Cn;
-  p.tilesX = pl.tilesX; p.tilesY = pl.tilesY; p.tilesTotal = pl.tilesTotal; p.tilesPerSplit = pl.tilesPerSplit;
-  hp.aScale = aScale; hp.bScale = bScale;
-  dim3 grid((unsigned)pl.splits, (unsigned)dc_cdiv(Cm, Cfg::CM), (unsigned)dc_cdiv(Cn, Cfg::CN));
-  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, hp);
-  DC_CHECK_LAUNCH(name);
-  const long L = (long)KH * KW * Cm * Cn;
-  return dc_reduce_partials(ws, pl.slabs, L, 1.0f, dw, ws + (long)pl.slabs * L, (dc_stream_t)st);
-}
-
 // conv3x3: pick the (m,n) wave arrangement from the channel counts, the pixel tile from the width.
 #define CONV_WGRAD_DISPATCH(FN, ...)                                                   \
   if (W <= 8) return FN<3, 3, 1, 1, 8, 8, 2, 2>(__VA_ARGS__);                          \
@@ -436,16 +185,6 @@ static long conv_wgrad_ws_impl(int N, int H, int W, int Cin, int Cout) {
 static int conv_wgrad_impl(const float* x, const float* dz, float* dw, float* ws, int N, int H, int W, int Cin,
                            int Cout, hipStream_t st) {
   CONV_WGRAD_DISPATCH(wgrad_launch, x, dz, dw, ws, N, H, W, H, W, Cin, Cout, st, "conv3x3_wgrad")
-}
-static int conv_wgrad_h_impl(const float* x, const float* dz, float* dw, float* ws, const float* dzScale, int N, int H,
-                             int W, int Cin, int Cout, hipStream_t st) {
-  const float* none = nullptr;
-  CONV_WGRAD_DISPATCH(wgrad_h_launch, x, dz, dw, ws, none, dzScale, N, H, W, H, W, Cin, Cout, st, "conv3x3_wgrad_f16x3")
-}
-static int convT_wgrad_h_impl(const float* x, const float* dz, float* dw, float* ws, const float* dzScale, int N, int H,
-                              int W, int Cin, int Cout, hipStream_t st) {
-  const float* none = nullptr;
-  CONVT_WGRAD_DISPATCH(wgrad_h_launch, dz, x, dw, ws, dzScale, none, N, 2 * H, 2 * W, H, W, Cout, Cin, st, "convT2x2_wgrad_f16x3")
 }
 static long convT_wgrad_ws_impl(int N, int H, int W, int Cin, int Cout) {
   CONVT_WGRAD_DISPATCH(wgrad_ws, N, H, W, Cout, Cin)
@@ -471,9 +210,14 @@ long dc_conv3x3_c1_wgrad_ws(int N, int H, int W, int Cout);
 int dc_conv3x3_c1_wgrad(const float* x, const float* dz, float* dw, float* ws, int N, int H, int W, int Cout,
                         hipStream_t st);
 
+// the split-fp16 kernels (wgrad_f16x3.hip) tile differently: one workspace size serves both
+long dc_conv3x3_wgrad_f16x3_ws(int N, int H, int W, int Cin, int Cout);
+long dc_convT2x2_wgrad_f16x3_ws(int N, int H, int W, int Cin, int Cout);
+
 extern "C" long dc_conv3x3_wgrad_ws_floats(int N, int H, int W, int Cin, int Cout) {
   if (Cin == 1) return dc_conv3x3_c1_wgrad_ws(N, H, W, Cout);
-  return conv_wgrad_ws_impl(N, H, W, Cin, Cout);
+  const long a = conv_wgrad_ws_impl(N, H, W, Cin, Cout), b = dc_conv3x3_wgrad_f16x3_ws(N, H, W, Cin, Cout);
+  return a > b ? a : b;
 }
 extern "C" int dc_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* ws, int N, int H, int W, int Cin,
                                 int Cout, dc_stream_t stream) {
@@ -486,7 +230,8 @@ extern "C" int dc_conv3x3_wgrad(const float* x, const float* dz, float* dw, floa
   return conv_wgrad_impl(x, dz, dw, ws, N, H, W, Cin, Cout, (hipStream_t)stream);
 }
 extern "C" long dc_convT2x2_wgrad_ws_floats(int N, int H, int W, int Cin, int Cout) {
-  return convT_wgrad_ws_impl(N, H, W, Cin, Cout);
+  const long a = convT_wgrad_ws_impl(N, H, W, Cin, Cout), b = dc_convT2x2_wgrad_f16x3_ws(N, H, W, Cin, Cout);
+  return a > b ? a : b;
 }
 extern "C" int dc_convT2x2_wgrad(const float* x, const float* dz, float* dw, float* ws, int N, int H, int W, int Cin,
                                  int Cout, dc_stream_t stream) {
@@ -495,21 +240,3 @@ extern "C" int dc_convT2x2_wgrad(const float* x, const float* dz, float* dw, flo
   return convT_wgrad_impl(x, dz, dw, ws, N, H, W, Cin, Cout, (hipStream_t)stream);
 }
 
-// split-fp16 variants: same workspace sizes (dc_*_wgrad_ws_floats) and slab reduction; dz_scale = device scalar
-// from dc_pow2_scale_from_absmax (nullable).
-extern "C" int dc_conv3x3_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,
-                                      int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
-  if (Cin == 1) {
-    DC_REQUIRE(x && dz && dw && ws, DC_EINVAL, "dc_conv3x3_wgrad_f16x3: null pointer");
-    return dc_conv3x3_c1_wgrad(x, dz, dw, ws, N, H, W, Cout, (hipStream_t)stream);
-  }
-  int rc = check_wgrad("dc_conv3x3_wgrad_f16x3", x, dz, dw, ws, N, H, W, Cin, Cout);
-  if (rc) return rc;
-  return conv_wgrad_h_impl(x, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
-}
-extern "C" int dc_convT2x2_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,
-                                       int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
-  int rc = check_wgrad("dc_convT2x2_wgrad_f16x3", x, dz, dw, ws, N, H, W, Cin, Cout);
-  if (rc) return rc;
-  return convT_wgrad_h_impl(x, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
-}

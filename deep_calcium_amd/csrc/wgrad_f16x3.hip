@@ -1,0 +1,374 @@
+// Weight-gradient contraction with fp32-grade accuracy on the fp16 matrix cores (numerics: igemm_f16x3.hip).
+//
+//   out[tap][m][n] = sum over pixels p of  A[S*p + tap - PAD][m] * B[p][n]
+//   conv3x3 wgrad : A = layer input x (m = Cin), B = dz (n = Cout, pow2-scaled)  -> HWIO (3,3,Cin,Cout)
+//   convT2x2 wgrad: A = dz (2H x 2W, m = Cout, S = 2, pow2-scaled), B = x (n = Cin) -> Keras (2,2,Cout,Cin)
+//
+// k = 16 pixels per v_mfma_f32_32x32x16_f16.  The contraction index (pixel) is the ROW index of the NHWC tiles, so
+// the MFMA fragments (8 consecutive k per lane) come from the hardware-transposing ds_read_b64_tr_b16: each 16-lane
+// group reads a 4-pixel x 16-channel block and every lane receives its channel's 4 pixels.  LDS holds fp16 hi and
+// lo images of both tiles as 32-channel planes ([plane][pixel][32 ch] = 64-B rows): 4 consecutive pixel rows of a
+// plane are 256 contiguous bytes => conflict-free transposed reads, every tap / k-step offset is an immediate.
+//
+// Pipeline (ONE CTA per CU, one wave per SIMD, the whole 512-register file; the earlier 2-CTA/CU version parked
+// 56 % of its wave-cycles in s_waitcnt and was issue-bound at 1.6 LDS + 2.6 VALU instructions per MFMA):
+//   * a wave owns 32 m-channels x (32*WN) n-channels for ALL taps: every A fragment pair feeds 3*WN MFMAs;
+//   * two LDS image sets: tile t is consumed from set t&1 while tile t+1 is produced into the other;
+//   * the raw fp32 rows of tile t+1 are requested (bounds-checked buffer loads) right after the barrier, stay in
+//     registers through the first MFMA groups, and are split + written to LDS piece by piece BETWEEN the MFMAs of
+//     the last groups (an MFMA holds the issue port 8 of its 32 cycles);
+//   * operand fragments of group g+1 are requested from LDS before the MFMAs of group g issue;
+//   * one barrier per tile; the WK waves that share an (m,n) block are summed through LDS at the end, one slab per
+//     CTA goes to HBM and dc_reduce_partials adds the slabs in a fixed order (bit-reproducible, no atomics).
+#include "wgrad_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short tr_v4i16;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct WgradHParams {
+  WgradParams g;
+  const float* aScale;  // nullable device scalars (powers of two)
+  const float* bScale;
+};
+
+// WM x WNW waves tile the CTA's (m, n) block, each wave covering 32 m x (32*NBW) n; the remaining
+// WK = 4/(WM*WNW) waves split the pixel rows of a tile.
+template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW>
+struct WgradHCfg {
+  static constexpr int TAPS = KH * KW;
+  static constexpr int WN = WNW * NBW;              // 32-column blocks of the CTA
+  static constexpr int WK = 4 / (WM * WNW);
+  static constexpr int TH = WK * RW;
+  static constexpr int CM = 32 * WM, CN = 32 * WN;
+  static constexpr int THI = (TH - 1) * S + KH, TWI = (TW - 1) * S + KW;
+  static constexpr int APIX = THI * TWI, BPIX = TH * TW;
+  static constexpr int A_PLANE = APIX * 64, B_PLANE = BPIX * 64;
+  static constexpr int A_IMG = WM * A_PLANE, B_IMG = WN * B_PLANE;
+  static constexpr int SET = 2 * (A_IMG + B_IMG);
+  static constexpr int LDS_BYTES = 2 * SET;
+  static_assert(LDS_BYTES <= 160 * 1024, "two image sets must fit the 160 KiB LDS");
+};
+
+__device__ __forceinline__ f16x8 tr_frag(const char* base, int off1, int off2) {
+  typedef __attribute__((address_space(3))) tr_v4i16* lds_p;
+  const tr_v4i16 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off1));
+  const tr_v4i16 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off2));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+  return __builtin_bit_cast(f16x8, v);
+}
+
+template <bool SCALED>
+__device__ __forceinline__ void split4_f16(const f32x4 v, float s, u32x2& hi, u32x2& lo) {
+  f16x4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x = SCALED ? v[e] * s : v[e];
+    const _Float16 hh = (_Float16)x;
+    h[e] = hh;
+    l[e] = (_Float16)(x - (float)hh);
+  }
+  hi = __builtin_bit_cast(u32x2, h);
+  lo = __builtin_bit_cast(u32x2, l);
+}
+
+template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW, bool A_SCALED>
+__global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
+  using Cfg = WgradHCfg<KH, KW, S, PAD, TW, RW, WM, WNW, NBW>;
+  constexpr int TAPS = Cfg::TAPS, WK = Cfg::WK, TH = Cfg::TH, CM = Cfg::CM, CN = Cfg::CN;
+  constexpr int TWI = Cfg::TWI, APIX = Cfg::APIX, BPIX = Cfg::BPIX;
+  constexpr int A_PLANE = Cfg::A_PLANE, B_PLANE = Cfg::B_PLANE, A_IMG = Cfg::A_IMG, B_IMG = Cfg::B_IMG, SET = Cfg::SET;
+  constexpr int KROWS = (TW >= 16) ? 1 : 16 / TW;               // pixel rows covered by one 16-pixel k-step
+  constexpr int KX = (TW >= 16) ? TW / 16 : 1;                  // k-steps along a row
+  constexpr int AC4 = CM / 4, BC4 = CN / 4;
+  constexpr int NA = (APIX * AC4 + 255) / 256, NB = (BPIX * BC4 + 255) / 256;   // float4 loads per thread
+  constexpr int KSTEPS = (RW / KROWS) * KX;
+  constexpr int GROUPS = KSTEPS * TAPS;                         // (k-step, tap) MFMA groups per tile
+  constexpr int PIECES = NA + NB;
+  constexpr int PPG = (PIECES + GROUPS - 1) / GROUPS;           // staging pieces carried per MFMA group
+  constexpr int G0 = GROUPS - (PIECES + PPG - 1) / PPG;         // first group that carries pieces
+  static_assert(RW % KROWS == 0, "rows per wave must be a multiple of the k-step height");
+  const WgradParams& p = hp.g;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, cb = (lane >> 4) & 1, c = lane & 15, q = c >> 2, pp = c & 3;
+  const int wm = wave % WM, wnw = (wave / WM) % WNW, wk = wave / (WM * WNW);
+  const int m0 = blockIdx.y * CM, n0 = blockIdx.z * CN;
+  const int split = blockIdx.x;
+  const float a_scale = hp.aScale ? *hp.aScale : 1.f;
+  const float b_scale = hp.bScale ? *hp.bScale : 1.f;
+
+  // lane-constant byte offsets of the two transposed reads of a k-step whose first pixel is (row 0, x 0)
+  int offA[2], offB[2];
+#pragma unroll
+  for (int r2 = 0; r2 < 2; ++r2) {
+    const int kpix = 8 * h + q + 4 * r2;
+    const int ky = (TW >= 16) ? 0 : kpix / TW, kx = (TW >= 16) ? kpix : kpix % TW;
+    offA[r2] = wm * A_PLANE + ((ky * S) * TWI + kx * S) * 64 + cb * 32 + pp * 8;
+    offB[r2] = 2 * A_IMG + (ky * TW + kx) * 64 + cb * 32 + pp * 8;
+  }
+
+  // tile-invariant staging coordinates of this thread
+  const int a_c4 = tid % AC4, b_c4 = tid % BC4;
+  const bool a_ch_ok = (m0 + 4 * a_c4) < p.Cm, b_ch_ok = (n0 + 4 * b_c4) < p.Cn;
+  const int a_rowb = p.Wa * p.Cm * 4, b_rowb = p.Wb * p.Cn * 4;
+  const int a_lbase = (a_c4 >> 3) * A_PLANE + (a_c4 & 7) * 8;
+  const int b_lbase = 2 * A_IMG + (b_c4 >> 3) * B_PLANE + (b_c4 & 7) * 8;
+
+  f32x16 acc[NBW][TAPS];
+#pragma unroll
+  for (int w = 0; w < NBW; ++w)
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[w][t][r] = 0.f;
+
+  const int tile_beg = split * p.tilesPerSplit;
+  const int tile_end = min(tile_beg + p.tilesPerSplit, p.tilesTotal);
+
+  f32x4 ra[NA], rb[NB];
+  // request tile `tile`'s raw rows (zeros outside the image: rows via the descriptor bounds, columns by compare)
+  auto request = [&](int tile) {
+    int t = tile;
+    const int tx = t % p.tilesX; t /= p.tilesX;
+    const int ty = t % p.tilesY;
+    const int img = t / p.tilesY;
+    const int py0 = ty * TH, px0 = tx * TW;
+    const int ay0 = py0 * S - PAD, ax0 = px0 * S - PAD;
+    const __amdgpu_buffer_rsrc_t rsA = dc_make_rsrc(p.A + (long)img * p.Ha * p.Wa * p.Cm, (unsigned)(p.Ha * p.Wa * p.Cm) * 4u);
+    const __amdgpu_buffer_rsrc_t rsB = dc_make_rsrc(p.B + (long)img * p.Hb * p.Wb * p.Cn, (unsigned)(p.Hb * p.Wb * p.Cn) * 4u);
+    const int abase = (ay0 * p.Wa + ax0) * p.Cm * 4 + (m0 + 4 * a_c4) * 4;   // may be negative: wraps out of range
+    const int bbase = (py0 * p.Wb + px0) * p.Cn * 4 + (n0 + 4 * b_c4) * 4;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      const int pix = tid / AC4 + k * (256 / AC4);
+      const int r = __umul24(pix, (65536 + TWI - 1) / TWI) >> 16;          // pix / TWI for pix < 4096
+      const int cc = pix - __umul24(r, TWI);
+      const bool ok = a_ch_ok && pix < APIX && (unsigned)(ax0 + cc) < (unsigned)p.Wa;
+      const unsigned off = ok ? (unsigned)(abase + __mul24(r, a_rowb) + __mul24(cc, p.Cm * 4)) : 0x80000000u;
+      ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int pix = tid / BC4 + k * (256 / BC4);
+      const int r = pix / TW, cc = pix % TW;
+      const bool ok = b_ch_ok && pix < BPIX && (px0 + cc) < p.Wb;
+      const unsigned off = ok ? (unsigned)(bbase + __mul24(r, b_rowb) + __mul24(cc, p.Cn * 4)) : 0x80000000u;
+      rb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
+    }
+  };
+  // split one requested float4 into fp16 hi/lo and write it into image set `set` (j is a compile-time index)
+  auto stage_piece = [&](int j, char* set) {
+    u32x2 hi, lo;
+    if (j < NA) {
+      const int pix = tid / AC4 + j * (256 / AC4);
+      split4_f16<A_SCALED>(ra[j], a_scale, hi, lo);
+      if (pix < APIX) {
+        *reinterpret_cast<u32x2*>(set + a_lbase + pix * 64) = hi;
+        *reinterpret_cast<u32x2*>(set + A_IMG + a_lbase + pix * 64) = lo;
+      }
+    } else {
+      const int k = j - NA;
+      const int pix = tid / BC4 + k * (256 / BC4);
+      split4_f16<!A_SCALED>(rb[k], b_scale, hi, lo);
+      if (pix < BPIX) {
+        *reinterpret_cast<u32x2*>(set + b_lbase + pix * 64) = hi;
+        *reinterpret_cast<u32x2*>(set + B_IMG + b_lbase + pix * 64) = lo;
+      }
+    }
+  };
+
+  if (tile_beg < tile_end) {
+    request(tile_beg);
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) stage_piece(j, smem);
+  }
+  __syncthreads();
+
+  // byte offset of group g's A fragment block / of k-step ks's B fragment block
+  auto a_off = [&](int g) {
+    const int ks = g / TAPS, tap = g % TAPS;
+    const int prow = wk * RW + (ks / KX) * KROWS, xs = ks % KX;
+    return ((prow * S) * TWI + xs * 16 * S) * 64 + ((tap / KW) * TWI + (tap % KW)) * 64;
+  };
+  auto b_off = [&](int ks, int w) {
+    const int prow = wk * RW + (ks / KX) * KROWS, xs = ks % KX;
+    return (wnw * NBW + w) * B_PLANE + (prow * TW + xs * 16) * 64;
+  };
+
+  for (int tile = tile_beg; tile < tile_end; ++tile) {
+    char* cur = smem + ((tile - tile_beg) & 1) * SET;
+    char* nxt = smem + (((tile - tile_beg) & 1) ^ 1) * SET;
+    const bool more = tile + 1 < tile_end;       // wave-uniform
+    if (more) request(tile + 1);
+
+    f16x8 ah[2], al[2], bh[2][NBW], bl[2][NBW];
+    ah[0] = tr_frag(cur, offA[0] + a_off(0), offA[1] + a_off(0));
+    al[0] = tr_frag(cur + A_IMG, offA[0] + a_off(0), offA[1] + a_off(0));
+#pragma unroll
+    for (int w = 0; w < NBW; ++w) {
+      bh[0][w] = tr_frag(cur, offB[0] + b_off(0, w), offB[1] + b_off(0, w));
+      bl[0][w] = tr_frag(cur + B_IMG, offB[0] + b_off(0, w), offB[1] + b_off(0, w));
+    }
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+      const int ca = g & 1, ks = g / TAPS, tap = g % TAPS, cbuf = ks & 1;
+      if (g + 1 < GROUPS) {
+        ah[ca ^ 1] = tr_frag(cur, offA[0] + a_off(g + 1), offA[1] + a_off(g + 1));
+        al[ca ^ 1] = tr_frag(cur + A_IMG, offA[0] + a_off(g + 1), offA[1] + a_off(g + 1));
+        if ((g + 1) % TAPS == 0) {
+#pragma unroll
+          for (int w = 0; w < NBW; ++w) {
+            bh[cbuf ^ 1][w] = tr_frag(cur, offB[0] + b_off(ks + 1, w), offB[1] + b_off(ks + 1, w));
+            bl[cbuf ^ 1][w] = tr_frag(cur + B_IMG, offB[0] + b_off(ks + 1, w), offB[1] + b_off(ks + 1, w));
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int w = 0; w < NBW; ++w) {
+        acc[w][tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ca], bh[cbuf][w], acc[w][tap], 0, 0, 0);
+        acc[w][tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cbuf][w], acc[w][tap], 0, 0, 0);
+        acc[w][tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cbuf][w], acc[w][tap], 0, 0, 0);
+      }
+      // the last groups each carry PPG conversion pieces of the next tile in the MFMA shadow
+      if (g >= G0 && more) {
+#pragma unroll
+        for (int u = 0; u < PPG; ++u)
+          if ((g - G0) * PPG + u < PIECES) stage_piece((g - G0) * PPG + u, nxt);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  const float out_scale = 1.f / (a_scale * b_scale);
+#pragma unroll
+  for (int w = 0; w < NBW; ++w)   // one 32x32 block at a time through the shared cross-wave reduction + store
+    wgrad_store<TAPS, WM, WNW, WK>(p, acc[w], smem, split, m0, n0 + 32 * (wnw * NBW + w) - 32 * wnw, wm, wnw, wk, lane,
+                                   out_scale);
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct WgradHPlan {
+  int splits, tilesX, tilesY, tilesTotal, tilesPerSplit;
+};
+
+template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW>
+static WgradHPlan wgrad_h_plan(int N, int Hb, int Wb, int Cm, int Cn) {
+  using Cfg = WgradHCfg<KH, KW, S, PAD, TW, RW, WM, WNW, NBW>;
+  WgradHPlan pl;
+  pl.tilesX = dc_cdiv(Wb, TW);
+  pl.tilesY = dc_cdiv(Hb, Cfg::TH);
+  pl.tilesTotal = N * pl.tilesX * pl.tilesY;
+  const int blocks_mn = dc_cdiv(Cm, Cfg::CM) * dc_cdiv(Cn, Cfg::CN);
+  int want = dc_cdiv(512, blocks_mn);   // one CTA per CU: two even rounds over the 256 CUs, few slabs
+  if (want > pl.tilesTotal) want = pl.tilesTotal;
+  if (want < 1) want = 1;
+  pl.tilesPerSplit = dc_cdiv(pl.tilesTotal, want);
+  pl.splits = dc_cdiv(pl.tilesTotal, pl.tilesPerSplit);
+  return pl;
+}
+
+template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW>
+static long wgrad_h_ws(int N, int Hb, int Wb, int Cm, int Cn) {
+  WgradHPlan pl = wgrad_h_plan<KH, KW, S, PAD, TW, RW, WM, WNW, NBW>(N, Hb, Wb, Cm, Cn);
+  const long L = (long)KH * KW * Cm * Cn;
+  return (long)pl.splits * L + 32 * L;
+}
+
+template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW, bool A_SCALED>
+static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, const float* aScale, const float* bScale,
+                          int N, int Ha, int Wa, int Hb, int Wb, int Cm, int Cn, hipStream_t st, const char* name) {
+  using Cfg = WgradHCfg<KH, KW, S, PAD, TW, RW, WM, WNW, NBW>;
+  auto kern = wgrad_f16x3_kernel<KH, KW, S, PAD, TW, RW, WM, WNW, NBW, A_SCALED>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    DC_REQUIRE(e == hipSuccess, DC_EHIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+    attr_set = true;
+  }
+  WgradHPlan pl = wgrad_h_plan<KH, KW, S, PAD, TW, RW, WM, WNW, NBW>(N, Hb, Wb, Cm, Cn);
+  WgradHParams hp;
+  WgradParams& p = hp.g;
+  p.A = A; p.B = B; p.slabs = ws;
+  p.N = N; p.Ha = Ha; p.Wa = Wa; p.Cm = Cm; p.Hb = Hb; p.Wb = Wb; p.Cn = Cn;
+  p.tilesX = pl.tilesX; p.tilesY = pl.tilesY; p.tilesTotal = pl.tilesTotal; p.tilesPerSplit = pl.tilesPerSplit;
+  hp.aScale = aScale; hp.bScale = bScale;
+  dim3 grid((unsigned)pl.splits, (unsigned)dc_cdiv(Cm, Cfg::CM), (unsigned)dc_cdiv(Cn, Cfg::CN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, hp);
+  DC_CHECK_LAUNCH(name);
+  const long L = (long)KH * KW * Cm * Cn;
+  return dc_reduce_partials(ws, pl.splits, L, 1.0f, dw, ws + (long)pl.splits * L, (dc_stream_t)st);
+}
+
+// conv3x3 (A = x unscaled, B = dz scaled).  <KH,KW,S,PAD, TW, RW, WM, WNW, NBW>: CTA block 32*WM x 32*WNW*NBW.
+#define CONV_H_DISPATCH(FN, ...)                                                       \
+  if (W <= 8) return FN<3, 3, 1, 1, 8, 8, 2, 2, 1 __VA_ARGS__;                         \
+  if (W <= 16) return FN<3, 3, 1, 1, 16, 4, 2, 2, 1 __VA_ARGS__;                       \
+  if (Cin > 32 && Cout > 32) return FN<3, 3, 1, 1, 32, 2, 2, 2, 1 __VA_ARGS__;         \
+  if (Cin > 32) return FN<3, 3, 1, 1, 32, 2, 2, 1, 1 __VA_ARGS__;                      \
+  if (Cout > 32) return FN<3, 3, 1, 1, 32, 2, 1, 2, 1 __VA_ARGS__;                     \
+  return FN<3, 3, 1, 1, 32, 2, 1, 1, 1 __VA_ARGS__;
+
+// convT2x2 (A = dz scaled, m = Cout; B = x, n = Cin >= 64); 16-wide tiles: the stride-2 A image is 4x the B tile
+#define CONVT_H_DISPATCH(FN, ...)                                                      \
+  if (W <= 8) return FN<2, 2, 2, 0, 8, 4, 1, 2, 1 __VA_ARGS__;                         \
+  return FN<2, 2, 2, 0, 16, 2, 1, 2, 1 __VA_ARGS__;
+
+long dc_conv3x3_wgrad_f16x3_ws(int N, int H, int W, int Cin, int Cout) {
+  CONV_H_DISPATCH(wgrad_h_ws, >(N, H, W, Cin, Cout))
+}
+long dc_convT2x2_wgrad_f16x3_ws(int N, int H, int W, int Cin, int Cout) {
+  CONVT_H_DISPATCH(wgrad_h_ws, >(N, H, W, Cout, Cin))
+}
+
+int dc_conv3x3_c1_wgrad(const float* x, const float* dz, float* dw, float* ws, int N, int H, int W, int Cout,
+                        hipStream_t st);
+
+static int check_h(const char* fn, const void* a, const void* b, const void* c, const void* d, int N, int H, int W,
+                   int Cin, int Cout) {
+  DC_REQUIRE(a && b && c && d, DC_EINVAL, "%s: null pointer", fn);
+  DC_REQUIRE(dc_aligned16(a) && dc_aligned16(b) && dc_aligned16(c) && dc_aligned16(d), DC_EINVAL,
+             "%s: pointers must be 16-byte aligned", fn);
+  DC_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, DC_EINVAL, "%s: non-positive dimension", fn);
+  DC_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, DC_EUNSUP, "%s: channel counts must be multiples of 4 (Cin=%d Cout=%d)", fn,
+             Cin, Cout);
+  return DC_OK;
+}
+
+static int conv_h_impl(const float* x, const float* dz, float* dw, float* ws, const float* dzScale, int N, int H, int W,
+                       int Cin, int Cout, hipStream_t st) {
+  const float* none = nullptr;
+  CONV_H_DISPATCH(wgrad_h_launch, , false>(x, dz, dw, ws, none, dzScale, N, H, W, H, W, Cin, Cout, st, "conv3x3_wgrad_f16x3"))
+}
+static int convT_h_impl(const float* x, const float* dz, float* dw, float* ws, const float* dzScale, int N, int H, int W,
+                        int Cin, int Cout, hipStream_t st) {
+  const float* none = nullptr;
+  CONVT_H_DISPATCH(wgrad_h_launch, , true>(dz, x, dw, ws, dzScale, none, N, 2 * H, 2 * W, H, W, Cout, Cin, st, "convT2x2_wgrad_f16x3"))
+}
+
+// same workspace (dc_*_wgrad_ws_floats) as the fp32 entry points; dz_scale = device scalar from
+// dc_pow2_scale_from_absmax (nullable).
+extern "C" int dc_conv3x3_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,
+                                      int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
+  if (Cin == 1) {
+    DC_REQUIRE(x && dz && dw && ws, DC_EINVAL, "dc_conv3x3_wgrad_f16x3: null pointer");
+    return dc_conv3x3_c1_wgrad(x, dz, dw, ws, N, H, W, Cout, (hipStream_t)stream);
+  }
+  int rc = check_h("dc_conv3x3_wgrad_f16x3", x, dz, dw, ws, N, H, W, Cin, Cout);
+  if (rc) return rc;
+  return conv_h_impl(x, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
+}
+extern "C" int dc_convT2x2_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,
+                                       int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
+  int rc = check_h("dc_convT2x2_wgrad_f16x3", x, dz, dw, ws, N, H, W, Cin, Cout);
+  if (rc) return rc;
+  return convT_h_impl(x, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
+}
