@@ -77,11 +77,19 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   const int li = lane & 31, h = lane >> 5;
   const int wave_m = wave % WAVES_M, wave_n = wave / WAVES_M;
 
-  int t = blockIdx.x;
+  // XCD-aware rasterisation: workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an L2), so
+  // each XCD walks a contiguous range of (pixel tile, column block) pairs with the column block fastest: the CTAs
+  // that re-read one input patch for different output columns run back to back on ONE L2 (speed only; any
+  // placement computes the same result).  Bijective for every grid size.
+  const int nblk = (p.Ncols + BN - 1) / BN, total = (int)gridDim.x;
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3, qq = total >> 3, rr = total & 7;
+  const int work = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + seq;
+  const int tile_id = work / nblk;
+  int t = tile_id;
   const int tx = t % p.tilesX; t /= p.tilesX;
   const int ty = t % p.tilesY;
   const int img = t / p.tilesY;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = (work - tile_id * nblk) * BN;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
   const int Cin4 = p.Cin >> 2, Cin8 = (p.Cin + 7) >> 3;
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
       }
       const int n = n0 + (wn * NB + nb) * 32 + l;
       if (n < p.Ncols) {
-        float* dst = p.stats + ((long)blockIdx.x * p.Ncols + n) * 2;
+        float* dst = p.stats + ((long)tile_id * p.Ncols + n) * 2;
         dst[0] = s1;
         dst[1] = s2;
       }
@@ -303,7 +311,7 @@ static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name) {
   }
   p.tilesX = dc_cdiv(p.Wout, TW);
   p.tilesY = dc_cdiv(p.Hout, Cfg::TH);
-  dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)dc_cdiv(p.Ncols, Cfg::BN));
+  dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY * dc_cdiv(p.Ncols, Cfg::BN)));
   hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, p);
   DC_CHECK_LAUNCH(name);
   return DC_OK;

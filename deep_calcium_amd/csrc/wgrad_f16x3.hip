@@ -98,8 +98,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, cb = (lane >> 4) & 1, c = lane & 15, q = c >> 2, pp = c & 3;
   const int wm = wave % WM, wnw = (wave / WM) % WNW, wk = wave / (WM * WNW);
-  const int m0 = blockIdx.y * CM, n0 = blockIdx.z * CN;
-  const int split = blockIdx.x;
+  // XCD-aware rasterisation (speed only): ids b and b+8 share an L2, so each XCD walks a contiguous range of
+  // (pixel split, channel block) pairs with the channel block fastest -- the CTAs that stream the same pixel range
+  // for different (m,n) blocks run side by side on one L2.
+  const int nbm = (p.Cm + CM - 1) / CM, nbn = (p.Cn + CN - 1) / CN, total = (int)gridDim.x;
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3, qq = total >> 3, rr8 = total & 7;
+  const int work = (xcd < rr8 ? xcd * (qq + 1) : rr8 * (qq + 1) + (xcd - rr8) * qq) + seq;
+  const int split = work / (nbm * nbn), blk = work - split * (nbm * nbn);
+  const int m0 = (blk / nbn) * CM, n0 = (blk % nbn) * CN;
   const float a_scale = hp.aScale ? *hp.aScale : 1.f;
   const float b_scale = hp.bScale ? *hp.bScale : 1.f;
 
@@ -301,7 +307,7 @@ static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, 
   p.N = N; p.Ha = Ha; p.Wa = Wa; p.Cm = Cm; p.Hb = Hb; p.Wb = Wb; p.Cn = Cn;
   p.tilesX = pl.tilesX; p.tilesY = pl.tilesY; p.tilesTotal = pl.tilesTotal; p.tilesPerSplit = pl.tilesPerSplit;
   hp.aScale = aScale; hp.bScale = bScale;
-  dim3 grid((unsigned)pl.splits, (unsigned)dc_cdiv(Cm, Cfg::CM), (unsigned)dc_cdiv(Cn, Cfg::CN));
+  dim3 grid((unsigned)(pl.splits * dc_cdiv(Cm, Cfg::CM) * dc_cdiv(Cn, Cfg::CN)));
   hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, hp);
   DC_CHECK_LAUNCH(name);
   const long L = (long)KH * KW * Cm * Cn;
