@@ -144,6 +144,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='per-GPU batch (default 16 = BASELINE config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', default='train', choices=['train', 'infer'],
+                    help="'infer' times the forward-only path (BASELINE configs[1]) for information; the contract line is 'train'")
     args = ap.parse_args()
 
     import torch
@@ -167,6 +169,21 @@ def main():
     # synthetic shard of the global batch, resident in HBM (SURVEY 8d seeds, offset per rank)
     x, y = on.synthetic_batch(B, H, W, seed_x=865 + 1000 * rank, seed_y=866 + 1000 * rank)
     xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+
+    if args.mode == 'infer':
+        for _ in range(args.warmup):
+            eng.forward_infer(xd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.forward_infer(xd)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            print(json.dumps({'metric': '512x512 summary images/sec (forward only, informational)', 'value': round(B * args.steps / dt, 2),
+                              'unit': 'images/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+                              'ms_per_step': round(dt / args.steps * 1e3, 3), 'config': {'workload': 'UNet2DS forward, batch=%d 512x512' % B}}))
+        return
 
     timer = KernelTimer(eng.L)
     eng.L = timer

@@ -401,12 +401,14 @@ class UNetEngine(object):
         T['part_ws'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['part_ws2'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['absmax'] = torch.empty(4096, dtype=torch.float32, device=dev)
-        T['dz_scale'] = torch.ones(4, dtype=torch.float32, device=dev)
+        T['dz_scale'] = torch.ones(3 * 4, dtype=torch.float32, device=dev)      # one (16-B aligned) scalar per dz buffer
         T['red_tmp'] = torch.empty(32 * 1024, dtype=torch.float32, device=dev)
         T['wgrad_ws'] = torch.empty(ws_floats, dtype=torch.float32, device=dev)
         T['sums'] = torch.zeros(8, dtype=torch.float64, device=dev)
         big = N * self.H * self.W * nfb
-        T['dz'] = torch.empty(big, dtype=torch.float32, device=dev)
+        # dz rotates over 3 buffers: the weight-gradient kernels run on a side stream and may still be reading the
+        # dz of block L while the main stream already produces the dz of block L-1 / L-2
+        T['dz'] = [torch.empty(big, dtype=torch.float32, device=dev) for _ in range(3)]
         T['gA'] = torch.empty(big, dtype=torch.float32, device=dev)
         T['gB'] = torch.empty(big, dtype=torch.float32, device=dev)
         for lvl in range(4):
@@ -488,6 +490,18 @@ class UNetEngine(object):
         L.dc_head_grad_finalize(_ptr(T['part_ws']), hb, nfb, self.pview(self.gflat, lo, 'k'),
                                 self.pview(self.gflat, lo, 'b'), st)
 
+        # Two HIP streams: the critical path (BN backward -> dgrad -> next block) stays on the caller's stream; the
+        # weight gradients -- off the critical path, matrix-pipe bound, light on HBM -- go to a side stream where they
+        # overlap with the HBM-bound BatchNorm passes of the following blocks.  Hand-offs are stream events.
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._dz_free = [None, None, None]
+        side = self._side
+        sw = side.cuda_stream
+        side.wait_stream(main)            # everything queued so far (forward, head) precedes the first wgrad
+        self._dz_turn = getattr(self, '_dz_turn', 0)
+
         def block_bwd(l, x_in, da_ptr, da_ld, dx_ptr):
             """da (strided) -> grads of l; dx written to dx_ptr (dense [.., cin]) unless None."""
             h, w = self._hw(l.lvl)
@@ -498,37 +512,51 @@ class UNetEngine(object):
             gamma, beta = self.pview(self.pflat, l, 'gamma'), self.pview(self.pflat, l, 'beta')
             dgamma, dbeta = self.pview(self.gflat, l, 'gamma'), self.pview(self.gflat, l, 'beta')
             blocks = L.dc_bn_bwd_blocks(pixels, l.cout)
+            k = self._dz_turn
+            self._dz_turn = (k + 1) % 3
+            dz, scale = _ptr(T['dz'][k]), _ptr(T['dz_scale'], 4 * k)
             L.dc_bn_bwd_reduce(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed,
                                _ptr(T['part_ws']), pixels, l.cout, st)
             L.dc_bn_bwd_finalize(_ptr(T['part_ws']), blocks, l.cout, dgamma, dbeta, st)
+            if self._dz_free[k] is not None:
+                main.wait_event(self._dz_free[k])       # the wgrad that last read this dz buffer has finished
             L.dc_bn_bwd_apply(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed, dgamma, dbeta,
-                              _ptr(T['dz']), _ptr(T['part_ws2']), _ptr(T['absmax']), pixels, l.cout, st)
-            if self.mfma == 'f16x3':
+                              dz, _ptr(T['part_ws2']), _ptr(T['absmax']), pixels, l.cout, st)
+            f16 = self.mfma == 'f16x3'
+            if f16:
                 # exact power-of-two scale that brings max|dz| to [512, 1024] before the fp16 split
-                L.dc_pow2_scale_from_absmax(_ptr(T['absmax']), blocks, 1024.0, _ptr(T['dz_scale']), st)
+                L.dc_pow2_scale_from_absmax(_ptr(T['absmax']), blocks, 1024.0, scale, st)
+            ready = torch.cuda.Event()
+            ready.record(main)
             L.dc_reduce_partials(_ptr(T['part_ws2']), blocks, l.cout, 1.0, self.pview(self.gflat, l, 'b'),
                                  _ptr(T['red_tmp']), st)
-            dk = self.pview(self.gflat, l, 'k')
-            dz, ws, f16 = _ptr(T['dz']), _ptr(T['wgrad_ws']), self.mfma == 'f16x3'
-            scale = _ptr(T['dz_scale'])
+            # ---- side stream: weight gradient of this block -------------------------------------------------------
+            side.wait_event(ready)
+            dk, ws = self.pview(self.gflat, l, 'k'), _ptr(T['wgrad_ws'])
             if l.kind == 'conv':
                 if f16:
-                    L.dc_conv3x3_wgrad_f16x3(x_in, dz, dk, ws, scale, N, h, w, l.cin, l.cout, st)
+                    L.dc_conv3x3_wgrad_f16x3(x_in, dz, dk, ws, scale, N, h, w, l.cin, l.cout, sw)
                 else:
-                    L.dc_conv3x3_wgrad(x_in, dz, dk, ws, N, h, w, l.cin, l.cout, st)
-                if dx_ptr is not None and f16:
-                    L.dc_conv3x3_dgrad_f16x3(dz, _ptr(self.wp_dgrad[l.name]), dx_ptr, scale, N, h, w, l.cin, l.cout, st)
-                elif dx_ptr is not None:
-                    L.dc_conv3x3_dgrad(dz, _ptr(self.wp_dgrad[l.name]), dx_ptr, N, h, w, l.cin, l.cout, st)
+                    L.dc_conv3x3_wgrad(x_in, dz, dk, ws, N, h, w, l.cin, l.cout, sw)
+            elif f16:
+                L.dc_convT2x2_wgrad_f16x3(x_in, dz, dk, ws, scale, N, h // 2, w // 2, l.cin, l.cout, sw)
             else:
+                L.dc_convT2x2_wgrad(x_in, dz, dk, ws, N, h // 2, w // 2, l.cin, l.cout, sw)
+            self._dz_free[k] = torch.cuda.Event()
+            self._dz_free[k].record(side)
+            # ---- main stream: data gradient feeds the next block -------------------------------------------------
+            if dx_ptr is None:
+                return
+            wpd = _ptr(self.wp_dgrad[l.name])
+            if l.kind == 'conv':
                 if f16:
-                    L.dc_convT2x2_wgrad_f16x3(x_in, dz, dk, ws, scale, N, h // 2, w // 2, l.cin, l.cout, st)
+                    L.dc_conv3x3_dgrad_f16x3(dz, wpd, dx_ptr, scale, N, h, w, l.cin, l.cout, st)
                 else:
-                    L.dc_convT2x2_wgrad(x_in, dz, dk, ws, N, h // 2, w // 2, l.cin, l.cout, st)
-                if dx_ptr is not None and f16:
-                    L.dc_convT2x2_dgrad_f16x3(dz, _ptr(self.wp_dgrad[l.name]), dx_ptr, scale, N, h // 2, w // 2, l.cin, l.cout, st)
-                elif dx_ptr is not None:
-                    L.dc_convT2x2_dgrad(dz, _ptr(self.wp_dgrad[l.name]), dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
+                    L.dc_conv3x3_dgrad(dz, wpd, dx_ptr, N, h, w, l.cin, l.cout, st)
+            elif f16:
+                L.dc_convT2x2_dgrad_f16x3(dz, wpd, dx_ptr, scale, N, h // 2, w // 2, l.cin, l.cout, st)
+            else:
+                L.dc_convT2x2_dgrad(dz, wpd, dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
 
         g, other = T['gA'], T['gB']      # g holds the gradient w.r.t. the current block's output
         for lvl in (0, 1, 2, 3):
@@ -555,6 +583,12 @@ class UNetEngine(object):
             else:
                 block_bwd(self.by_name[tag + 'a'], _ptr(A['pool%d' % (lvl - 1)]), _ptr(g), c, _ptr(other))
                 g, other = other, g
+        main.wait_stream(side)            # gflat is complete once both streams have drained
+
+    def _join_side(self):
+        side = getattr(self, '_side', None)
+        if side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(side)
 
     def adam_step(self, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-8, grad_scale=1.0):
         """Keras-2.0.6 Adam over the flat buffers; `iterations` counts completed steps."""
