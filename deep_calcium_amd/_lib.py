@@ -10,7 +10,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, '..', 'include', 'dcunet.h')
-LIB_PATH = os.path.join(HERE, 'lib', 'libdcunet.so')
+LIB_PATH = os.environ.get('DC_LIB_PATH') or os.path.join(HERE, 'lib', 'libdcunet.so')   # DC_LIB_PATH: A/B builds
 
 
 class DcunetError(RuntimeError):

@@ -389,20 +389,23 @@ extern "C" int dc_maxpool2x2_bwd(const float* dy, const uint8_t* idx, const floa
 
 // ------------------------------------------------------------------------------------------------
 // Head: C/4 lanes per pixel, xor-shuffle the two partial logits, lane q==0 finishes the pixel.
+#define DC_HEAD_SUMS 12   // bce, tp, sum round(p), fn, sum y, sum y*p, sum p^2, sum y^2, sum p, weighted-bce, 2 spare
 __device__ __forceinline__ float round_half_even(float x) { return rintf(x); }  // default RN mode = half to even
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ a, const float* __restrict__ kh,
                                                       const float* __restrict__ bh, const uint8_t* __restrict__ y,
                                                       float* __restrict__ p, float* __restrict__ partial, long pixels,
                                                       int C) {
-  __shared__ float sm[256][8];
+  __shared__ float sm[256][DC_HEAD_SUMS];
   const int C4 = C >> 2, PPB = 256 / C4;
   const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
   float k0[4], k1[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { k0[e] = kh[(4 * q + e) * 2]; k1[e] = kh[(4 * q + e) * 2 + 1]; }
   const float b0 = bh[0], b1 = bh[1];
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float acc[DC_HEAD_SUMS];
+#pragma unroll
+  for (int k = 0; k < DC_HEAD_SUMS; ++k) acc[k] = 0.f;
   const long iters = (pixels + (long)gridDim.x * PPB - 1) / ((long)gridDim.x * PPB);
   for (long it = 0; it < iters; ++it) {  // uniform trip count: the shuffles below need every lane
     const long pix = (it * gridDim.x + blockIdx.x) * PPB + pl;
@@ -432,26 +435,34 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
         acc[5] += yt * pr;
         acc[6] += pr * pr;
         acc[7] += yt * yt;
+        acc[8] += pr;
+        // weighted_binary_crossentropy (utils/neurons.py:13-29): -(2*y*log(p+1e-7) + (1-y)*log(1-p+1e-7))
+        acc[9] -= 2.f * yt * logf(pr + 1e-7f) + (1.f - yt) * logf(1.f - pr + 1e-7f);
       }
     }
   }
   if (partial) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sm[tid][k] = (q == 0) ? acc[k] : 0.f;
+    for (int k = 0; k < DC_HEAD_SUMS; ++k) sm[tid][k] = (q == 0) ? acc[k] : 0.f;
     __syncthreads();
-    if (tid < 8) {
+    if (tid < DC_HEAD_SUMS) {
       double s = 0.0;
       for (int t = 0; t < 256; ++t) s += (double)sm[t][tid];
-      partial[(long)blockIdx.x * 8 + tid] = (float)s;
+      partial[(long)blockIdx.x * DC_HEAD_SUMS + tid] = (float)s;
     }
   }
 }
 
-// s = dL/dlogit1 = (p - y)/M where the clip is inactive, else 0 ; dlogit0 = -s
+// s = dL/dlogit1 (dlogit0 = -s).  loss_kind 0: Keras binary_crossentropy, s = (p - y)/M where the clip is inactive.
+// Kinds 1..3 (utils/neurons.py:13-29,78-94) go through dL/dp * p(1-p); the global sums they need come from the
+// forward's reduced sums (device memory, no host round trip):
+//   1 weighted_binary_crossentropy: dL/dp = -(2y/(p+1e-7) - (1-y)/(1-p+1e-7)) / M
+//   2 dice_loss   = 1 - 2I/D,  I = sum y*p, D = sum y + sum p + 1e-7:        dL/dp = -2 (y D - I) / D^2
+//   3 dicesq_loss = -2I/D,     D = sum y^2 + sum p^2 + 1e-7:                 dL/dp = -2 (y D - 2 p I) / D^2
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ a, const float* __restrict__ p,
                                                       const uint8_t* __restrict__ y, const float* __restrict__ kh,
                                                       float* __restrict__ da, float* __restrict__ partial, long pixels,
-                                                      int C) {
+                                                      int C, int loss_kind, const double* __restrict__ sums) {
   __shared__ f32x4 sm[256];
   __shared__ float sms[256];
   const int C4 = C >> 2, PPB = 256 / C4;
@@ -460,12 +471,25 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 #pragma unroll
   for (int e = 0; e < 4; ++e) kd[e] = kh[(4 * q + e) * 2 + 1] - kh[(4 * q + e) * 2];
   const float invM = 1.f / (float)pixels;
+  float I = 0.f, D = 1.f;
+  if (loss_kind == 2) { I = (float)sums[5]; D = (float)(sums[4] + sums[8] + 1e-7); }
+  if (loss_kind == 3) { I = (float)sums[5]; D = (float)(sums[7] + sums[6] + 1e-7); }
+  const float invD2 = 1.f / (D * D);
   f32x4 sa = {0.f, 0.f, 0.f, 0.f};
   float ss = 0.f;
   for (long pix = (long)blockIdx.x * PPB + pl; pix < pixels; pix += (long)gridDim.x * PPB) {
-    const float pr = p[pix];
-    const bool inside = pr > 1e-7f && pr < 1.f - 1e-7f;
-    const float s = inside ? (pr - (float)y[pix]) * invM : 0.f;
+    const float pr = p[pix], yt = (float)y[pix];
+    float s;
+    if (loss_kind == 0) {
+      const bool inside = pr > 1e-7f && pr < 1.f - 1e-7f;
+      s = inside ? (pr - yt) * invM : 0.f;
+    } else {
+      float dp;
+      if (loss_kind == 1) dp = -(2.f * yt / (pr + 1e-7f) - (1.f - yt) / (1.f - pr + 1e-7f)) * invM;
+      else if (loss_kind == 2) dp = -2.f * (yt * D - I) * invD2;
+      else dp = -2.f * (yt * D - 2.f * pr * I) * invD2;
+      s = dp * pr * (1.f - pr);
+    }
     const f32x4 v = ld4(a + pix * C + 4 * q);
     st4(da + pix * C + 4 * q, kd * s);
     sa += v * s;
@@ -524,12 +548,13 @@ extern "C" int dc_head_fwd(const float* a, const float* kh, const float* bh, con
   return DC_OK;
 }
 extern "C" int dc_head_bwd(const float* a, const float* p, const uint8_t* y, const float* kh, float* da, float* partial,
-                           long pixels, int C, dc_stream_t stream) {
+                           int loss_kind, const double* sums, long pixels, int C, dc_stream_t stream) {
   DC_REQUIRE(a && p && y && kh && da && partial && pixels > 0, DC_EINVAL, "dc_head_bwd: bad arguments");
+  DC_REQUIRE(loss_kind >= 0 && loss_kind <= 3 && (loss_kind < 2 || sums), DC_EINVAL, "dc_head_bwd: bad loss_kind / sums");
   int rc = chan_check("dc_head_bwd", C);
   if (rc) return rc;
   hipLaunchKernelGGL(head_bwd_kernel, dim3(head_blocks(pixels)), dim3(256), 0, (hipStream_t)stream, a, p, y, kh, da,
-                     partial, pixels, C);
+                     partial, pixels, C, loss_kind, sums);
   DC_CHECK_LAUNCH("dc_head_bwd");
   return DC_OK;
 }

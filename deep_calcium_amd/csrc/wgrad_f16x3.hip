@@ -261,6 +261,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+#ifndef DC_WGRAD_CTAS
+#define DC_WGRAD_CTAS 512
+#endif
 struct WgradHPlan {
   int splits, tilesX, tilesY, tilesTotal, tilesPerSplit;
 };
@@ -273,7 +276,7 @@ static WgradHPlan wgrad_h_plan(int N, int Hb, int Wb, int Cm, int Cn) {
   pl.tilesY = dc_cdiv(Hb, Cfg::TH);
   pl.tilesTotal = N * pl.tilesX * pl.tilesY;
   const int blocks_mn = dc_cdiv(Cm, Cfg::CM) * dc_cdiv(Cn, Cfg::CN);
-  int want = dc_cdiv(512, blocks_mn);   // one CTA per CU: two even rounds over the 256 CUs, few slabs
+  int want = dc_cdiv(DC_WGRAD_CTAS, blocks_mn);   // one CTA per CU
   if (want > pl.tilesTotal) want = pl.tilesTotal;
   if (want < 1) want = 1;
   pl.tilesPerSplit = dc_cdiv(pl.tilesTotal, want);

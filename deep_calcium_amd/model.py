@@ -26,14 +26,23 @@ K_EPS = 1e-7
 METRIC_NAMES = ['F1', 'prec', 'reca', 'dice', 'dicesq', 'posyt', 'posyp']
 
 
-def metrics_from_sums(s, count):
-    """The loss + 7 compile() metrics (deepcalcium/utils/neurons.py:32-50,70-75,86-90,97-106) from the head
-    kernel's 8 sums {bce, tp, sum round(p), fn, sum y, sum y*p, sum p^2, sum y^2} over `count` pixels."""
-    bce, tp, spr, fn, sy, syp, sp2, sy2 = [float(v) for v in s]
+LOSS_KINDS = {'binary_crossentropy': 0, 'weighted_binary_crossentropy': 1, 'dice_loss': 2, 'dicesq_loss': 3}
+
+
+def metrics_from_sums(s, count, loss='binary_crossentropy'):
+    """The loss + 7 compile() metrics (deepcalcium/utils/neurons.py:13-106) from the head kernel's sums
+    {bce, tp, sum round(p), fn, sum y, sum y*p, sum p^2, sum y^2[, sum p, weighted-bce]} over `count` pixels."""
+    s = [float(v) for v in s]
+    bce, tp, spr, fn, sy, syp, sp2, sy2 = s[:8]
+    sp, wbce = (s[8], s[9]) if len(s) > 9 else (0.0, 0.0)
     prec = tp / (spr + K_EPS)
     reca = tp / (tp + fn + K_EPS)
+    loss_value = {'binary_crossentropy': bce / count,
+                  'weighted_binary_crossentropy': wbce / count,
+                  'dice_loss': 1.0 - 2.0 * syp / (sy + sp + 1e-7),
+                  'dicesq_loss': -2.0 * syp / (sy2 + sp2 + K_EPS)}[loss]
     return {
-        'loss': bce / count,
+        'loss': loss_value,
         'F1': 2 * prec * reca / (prec + reca + K_EPS),
         'prec': prec,
         'reca': reca,
@@ -213,11 +222,11 @@ class Model(object):
 
     def compile(self, optimizer, loss='binary_crossentropy', metrics=None):
         name = loss if isinstance(loss, str) else getattr(loss, '__name__', str(loss))
-        if name != 'binary_crossentropy':
-            raise NotImplementedError("loss %r: only the default 'binary_crossentropy' is built; the alternates "
-                                      "(utils/neurons.py:13-29,78-94) are a 'next' row (SURVEY 8f)" % name)
+        if name not in LOSS_KINDS:      # the reference's `losses` dict, unet_2d_summary.py:372-377
+            raise ValueError('loss %r is not one of %s' % (name, sorted(LOSS_KINDS)))
         self.optimizer = optimizer if optimizer is not None else Adam(0.002)
         self.loss = name
+        self.engine.loss_kind = LOSS_KINDS[name]
         self.metrics_names = ['loss'] + list(METRIC_NAMES)
 
     def get_weights(self):
@@ -269,7 +278,7 @@ class Model(object):
             parallel.all_reduce_sum(sums)
         o = self.optimizer
         eng.adam_step(o.lr, o.beta_1, o.beta_2, o.epsilon, grad_scale=1.0 / world)
-        m = metrics_from_sums(sums.cpu().numpy(), float(world * xd.shape[0] * xd.shape[1] * xd.shape[2]))
+        m = metrics_from_sums(sums.cpu().numpy(), float(world * xd.shape[0] * xd.shape[1] * xd.shape[2]), self.loss)
         return [m[k] for k in self.metrics_names]
 
     def fit_generator(self, generator, steps_per_epoch, epochs=1, verbose=1, callbacks=None, max_queue_size=10,

@@ -72,6 +72,7 @@ class UNetEngine(object):
         if self.mfma not in ('f16x3', 'f32'):
             raise ValueError("mfma must be 'f16x3' or 'f32', got %r" % self.mfma)
         self.streams = 1 if os.environ.get('DC_STREAMS', '2') == '1' else 2     # 2: weight gradients on a side stream
+        self.loss_kind = 0      # 0 binary_crossentropy, 1 weighted_binary_crossentropy, 2 dice_loss, 3 dicesq_loss
         H, W = window_shape
         if H % 16 or W % 16:
             raise ValueError('window_shape must be a multiple of 16 (4 max-pools), got %r' % (window_shape,))
@@ -397,7 +398,7 @@ class UNetEngine(object):
             blocks = L.dc_bn_bwd_blocks(N * h * w, l.cout)
             part_floats = max(part_floats, blocks * l.cout * 2)
         hb = L.dc_head_blocks(N * self.H * self.W)
-        part_floats = max(part_floats, hb * (nfb + 4), hb * 8)
+        part_floats = max(part_floats, hb * (nfb + 4), hb * 12)
         T['stats_ws'] = torch.empty(stats_floats, dtype=torch.float32, device=dev)
         T['part_ws'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['part_ws2'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
@@ -405,7 +406,7 @@ class UNetEngine(object):
         T['dz_scale'] = torch.ones(3 * 4, dtype=torch.float32, device=dev)      # one (16-B aligned) scalar per dz buffer
         T['red_tmp'] = torch.empty(32 * 1024, dtype=torch.float32, device=dev)
         T['wgrad_ws'] = torch.empty(ws_floats, dtype=torch.float32, device=dev)
-        T['sums'] = torch.zeros(8, dtype=torch.float64, device=dev)
+        T['sums'] = torch.zeros(12, dtype=torch.float64, device=dev)
         big = N * self.H * self.W * nfb
         # dz rotates over 3 buffers: the weight-gradient kernels run on a side stream and may still be reading the
         # dz of block L while the main stream already produces the dz of block L-1 / L-2
@@ -474,7 +475,7 @@ class UNetEngine(object):
         hb = L.dc_head_blocks(pixels)
         L.dc_head_fwd(_ptr(A['d0b']), self.pview(self.pflat, lo, 'k'), self.pview(self.pflat, lo, 'b'),
                       y_dev.data_ptr(), _ptr(A['p']), _ptr(T['part_ws']), pixels, self.nfb, st)
-        L.dc_reduce_partials_f64(_ptr(T['part_ws']), hb, 8, T['sums'].data_ptr(), st)
+        L.dc_reduce_partials_f64(_ptr(T['part_ws']), hb, 12, T['sums'].data_ptr(), st)
         return A['p']
 
     def backward(self):
@@ -487,7 +488,7 @@ class UNetEngine(object):
         lo = self.by_name['out']
         hb = L.dc_head_blocks(pixels0)
         L.dc_head_bwd(_ptr(A['d0b']), _ptr(A['p']), y_dev.data_ptr(), self.pview(self.pflat, lo, 'k'),
-                      _ptr(T['gA']), _ptr(T['part_ws']), pixels0, nfb, st)
+                      _ptr(T['gA']), _ptr(T['part_ws']), self.loss_kind, T['sums'].data_ptr(), pixels0, nfb, st)
         L.dc_head_grad_finalize(_ptr(T['part_ws']), hb, nfb, self.pview(self.gflat, lo, 'k'),
                                 self.pview(self.gflat, lo, 'b'), st)
 
@@ -612,7 +613,7 @@ class UNetEngine(object):
         self._fold_dirty = True
 
     def read_sums(self):
-        """Host copy of the 8 loss/metric sums of the last forward_train (synchronises the stream)."""
+        """Host copy of the 12 loss/metric sums of the last forward_train (synchronises the stream)."""
         N = self._last[0]
         return self._train_bufs(N)['sums'].cpu().numpy().copy()
 

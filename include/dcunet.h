@@ -146,16 +146,20 @@ int dc_maxpool2x2_fwd(const float* in, long in_ld, float* out, uint8_t* idx,
 int dc_maxpool2x2_bwd(const float* dy, const uint8_t* idx, const float* skip, long skip_ld, float* dx,
                       int N, int H, int W, int C, dc_stream_t stream);
 
-/* ---- Conv2D(2,1,softmax) + Lambda(x[...,-1]) + binary_crossentropy + metrics  :221-222,:398-399 ---
- * p = softmax(a.Kh + bh)[...,1].  y != NULL: also partial[blocks][8] =
- *   {bce_sum, sum round(p)*y, sum round(p), sum clip(y-round(p),0,1), sum y, sum y*p, sum p*p, sum y*y}
- * (Keras clip/logit BCE form; round half to even).  blocks = dc_head_blocks(pixels). */
+/* ---- Conv2D(2,1,softmax) + Lambda(x[...,-1]) + loss + metrics  :221-222,:372-380,:398-399 ------------------
+ * p = softmax(a.Kh + bh)[...,1].  y != NULL: also partial[blocks][DC_HEAD_SUMS = 12] =
+ *   {bce_sum, sum round(p)*y, sum round(p), sum clip(y-round(p),0,1), sum y, sum y*p, sum p*p, sum y*y,
+ *    sum p, weighted_bce_sum, 0, 0}
+ * (Keras clip/logit BCE form; round half to even; weighted BCE of utils/neurons.py:13-29).
+ * blocks = dc_head_blocks(pixels); reduce with dc_reduce_partials_f64(partial, blocks, 12, sums). */
 int dc_head_blocks(long pixels);
 int dc_head_fwd(const float* a, const float* kh, const float* bh, const uint8_t* y, float* p, float* partial,
                 long pixels, int C, dc_stream_t stream);
-/* da = dlogits.Kh^T; partial[blocks][C+4] = (sum a[c]*s ..., sum s, pad) with s = dL/dlogit1 = -dL/dlogit0. */
+/* da = dlogits.Kh^T; partial[blocks][C+4] = (sum a[c]*s ..., sum s, pad) with s = dL/dlogit1 = -dL/dlogit0.
+ * loss_kind: 0 binary_crossentropy (mean), 1 weighted_binary_crossentropy (mean), 2 dice_loss, 3 dicesq_loss
+ * (unet_2d_summary.py:372-377); kinds 2,3 read the forward's reduced sums (device double[12]). */
 int dc_head_bwd(const float* a, const float* p, const uint8_t* y, const float* kh, float* da, float* partial,
-                long pixels, int C, dc_stream_t stream);
+                int loss_kind, const double* sums, long pixels, int C, dc_stream_t stream);
 /* head gradient from partial: dkh[c][0] = -S_c, dkh[c][1] = S_c, dbh = (-S, S) */
 int dc_head_grad_finalize(const float* partial, int blocks, int C, float* dkh, float* dbh, dc_stream_t stream);
 

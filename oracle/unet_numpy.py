@@ -219,6 +219,22 @@ def bce_keras_grad(p, y):
     return inside * (pc - y) / (pc * (1 - pc)) / p.size
 
 
+def alt_loss(name, p, y):
+    """The reference's selectable alternates (unet_2d_summary.py:372-377 -> utils/neurons.py:13-29,78-94) as
+    (scalar loss, dL/dp).  Keras means the weighted-BCE matrix over everything; dice losses are already scalars."""
+    if name == 'weighted_binary_crossentropy':
+        l = -(2.0 * y * np.log(p + 1e-7) + (1 - y) * np.log(1 - p + 1e-7))
+        return l.mean(), -(2.0 * y / (p + 1e-7) - (1 - y) / (1 - p + 1e-7)) / p.size
+    inter = (y * p).sum()
+    if name == 'dice_loss':
+        D = y.sum() + p.sum() + 1e-7
+        return 1 - 2 * inter / D, -2 * (y * D - inter) / D ** 2
+    if name == 'dicesq_loss':
+        D = (y ** 2).sum() + (p ** 2).sum() + K_EPS
+        return -2 * inter / D, -2 * (y * D - 2 * p * inter) / D ** 2
+    raise ValueError(name)
+
+
 def keras_metrics(y, p):
     """The 7 compile() metrics, /root/reference/deepcalcium/utils/neurons.py:32-50,70-75,86-90,97-106."""
     y = y.astype(np.float64)
@@ -316,13 +332,15 @@ class UNetOracle(object):
             cache['out'] = (x, sm)
         return p
 
-    def loss_and_grads(self, x, y, masks=None, taps=None):
+    def loss_and_grads(self, x, y, masks=None, taps=None, loss='binary_crossentropy'):
         """One training-mode forward + backward.  Returns (loss, p, grads{name:[dK,db,dgamma,dbeta]}, batch_stats)."""
         cache = {}
         p = self.forward(x, True, masks, cache)
         yf = np.asarray(y, self.dtype)
-        loss = bce_keras(p, yf)
-        dp = bce_keras_grad(p, yf)
+        if loss == 'binary_crossentropy':
+            loss, dp = bce_keras(p, yf), bce_keras_grad(p, yf)
+        else:
+            loss, dp = alt_loss(loss, p, yf)
         a, sm = cache['out']
         # p = sm1 ; dsm1/dz1 = sm1*sm0 ; dsm1/dz0 = -sm1*sm0
         s = dp * sm[..., 1] * sm[..., 0]

@@ -50,8 +50,15 @@ def test_model_duck_type_and_checkpoint_roundtrip(tmp_path):
         assert np.array_equal(a, b)
     x64, _ = on.synthetic_batch(1, 64, 64)
     assert np.abs(m2.predict(x64) - on.UNetOracle(m.get_weights(), 8).forward(x64)).max() < 1e-4
-    with pytest.raises(NotImplementedError):
-        m.compile(Adam(), loss='dice_loss')
+    with pytest.raises(ValueError):
+        m.compile(Adam(), loss='hinge')
+    # the reference's alternate losses train too (unet_2d_summary.py:372-377)
+    for name in ('weighted_binary_crossentropy', 'dice_loss', 'dicesq_loss'):
+        m.compile(Adam(0.002), loss=name)
+        v0 = m.train_on_batch(x, y)
+        for _ in range(4):
+            v1 = m.train_on_batch(x, y)
+        assert np.isfinite(v1).all() and v1[0] < v0[0], (name, v0[0], v1[0])
 
 
 def test_fit_and_predict_end_to_end(tmp_path):

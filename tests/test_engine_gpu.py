@@ -121,6 +121,26 @@ def test_train_forward_backward_matches_oracle(N, H, W, nfb, mfma):
     print('relu gate flips: %d, gradient cosine %.7f' % (flips, cos))
 
 
+@pytest.mark.parametrize('loss', ['weighted_binary_crossentropy', 'dice_loss', 'dicesq_loss'])
+def test_alternate_losses_match_oracle(loss):
+    from deep_calcium_amd.model import LOSS_KINDS, metrics_from_sums
+    N, H, W, nfb = 2, 32, 32, 8
+    eng, Wt = make_engine(H, W, nfb)
+    eng.loss_kind = LOSS_KINDS[loss]
+    x, y = on.synthetic_batch(N, H, W)
+    masks = on.make_drop_masks(nfb, N, H, W)
+    loss_ref, p_ref, G_ref, _ = on.UNetOracle(Wt, nfb).loss_and_grads(x, y, masks, loss=loss)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    eng.forward_train(xd, yd, dev_masks(masks), update_moving=False)
+    eng.backward()
+    assert abs(metrics_from_sums(eng.read_sums(), N * H * W, loss)['loss'] - loss_ref) < 1e-4
+    G = eng.grads()
+    fg = np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(G[n]) if not (j == 1 and n != 'out')]).astype(np.float64)
+    fr = np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(G_ref[n]) if not (j == 1 and n != 'out')])
+    assert fg.dot(fr) / (np.linalg.norm(fg) * np.linalg.norm(fr)) > 0.9995
+    assert np.linalg.norm(fg - fr) < 0.05 * np.linalg.norm(fr)
+
+
 @pytest.mark.parametrize('mfma', MODES)
 def test_train_steps_loss_matches_oracle(mfma):
     """Two full train steps (fwd + bwd + Keras Adam + BN moving stats), explicit dropout masks: BCE loss and

@@ -410,11 +410,11 @@ def test_head_fwd_bwd_metrics(dclib, C, pixels):
     p_ref, sm = on.head_fwd(a.astype(np.float64), Kh.astype(np.float64), bh.astype(np.float64))
     blocks = L.dc_head_blocks(pixels)
     p = torch.empty(pixels, device='cuda')
-    part = torch.empty(blocks * 8, device='cuda')
-    sums = torch.empty(8, dtype=torch.float64, device='cuda')
+    part = torch.empty(blocks * 12, device='cuda')
+    sums = torch.empty(12, dtype=torch.float64, device='cuda')
     ad, yd, kd = dev(a), dev(y), dev(Kh)
     L.dc_head_fwd(ad.data_ptr(), kd.data_ptr(), dev(bh).data_ptr(), yd.data_ptr(), p.data_ptr(), part.data_ptr(), pixels, C, None)
-    L.dc_reduce_partials_f64(part.data_ptr(), blocks, 8, sums.data_ptr(), None)
+    L.dc_reduce_partials_f64(part.data_ptr(), blocks, 12, sums.data_ptr(), None)
     torch.cuda.synchronize()
     pg = p.cpu().numpy()
     assert np.abs(pg - p_ref).max() < 1e-6
@@ -432,7 +432,7 @@ def test_head_fwd_bwd_metrics(dclib, C, pixels):
     da = torch.empty((pixels, C), device='cuda')
     part2 = torch.empty(blocks * (C + 4), device='cuda')
     dk, db = torch.empty((1, 1, C, 2), device='cuda'), torch.empty(2, device='cuda')
-    L.dc_head_bwd(ad.data_ptr(), p.data_ptr(), yd.data_ptr(), kd.data_ptr(), da.data_ptr(), part2.data_ptr(), pixels, C, None)
+    L.dc_head_bwd(ad.data_ptr(), p.data_ptr(), yd.data_ptr(), kd.data_ptr(), da.data_ptr(), part2.data_ptr(), 0, sums.data_ptr(), pixels, C, None)
     L.dc_head_grad_finalize(part2.data_ptr(), blocks, C, dk.data_ptr(), db.data_ptr(), None)
     torch.cuda.synchronize()
     # the backward consumes the stored fp32 p: evaluate the oracle's formula at that p (a saturated pixel whose
@@ -444,6 +444,20 @@ def test_head_fwd_bwd_metrics(dclib, C, pixels):
     assert np.abs(da.cpu().numpy() - dlog @ Kh[0, 0].astype(np.float64).T).max() < 1e-6
     assert np.abs(dk.cpu().numpy()[0, 0] - a.astype(np.float64).T @ dlog).max() < 2e-5
     assert np.abs(db.cpu().numpy() - dlog.sum(0)).max() < 2e-5
+    # alternate losses (unet_2d_summary.py:372-377): value from the sums, gradient through the same kernel
+    from deep_calcium_amd.model import metrics_from_sums, LOSS_KINDS
+    assert abs(s[8] - p64.sum()) < 1e-3 * p64.sum()
+    for name, kind in LOSS_KINDS.items():
+        if kind == 0:
+            continue
+        l_ref, dp_ref = on.alt_loss(name, p64, yf)
+        assert abs(metrics_from_sums(s, pixels, name)['loss'] - l_ref) < 2e-5 * max(1.0, abs(l_ref)), name
+        L.dc_head_bwd(ad.data_ptr(), p.data_ptr(), yd.data_ptr(), kd.data_ptr(), da.data_ptr(), part2.data_ptr(), kind,
+                      sums.data_ptr(), pixels, C, None)
+        torch.cuda.synchronize()
+        sref = dp_ref * p64 * (1 - p64)
+        ref = np.stack([-sref, sref], -1) @ Kh[0, 0].astype(np.float64).T
+        assert np.abs(da.cpu().numpy() - ref).max() < 2e-5 * max(np.abs(ref).max(), 1e-12), name
 
 
 def test_adam_keras_form(dclib):
