@@ -388,6 +388,97 @@ extern "C" int dc_maxpool2x2_bwd(const float* dy, const uint8_t* idx, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// UpSampling2D() + Dropout  (the `upsampling_or_transpose != 'transpose'` branch, unet_2d_summary.py:160-161,:198):
+// nearest-neighbour 2x, then dropout on the up-sampled tensor.  in dense [N,H,W,C] -> out strided [N,2H,2W,C].
+// The dropout element index is that of the dense up-sampled tensor.
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          long out_ld, const uint8_t* __restrict__ mask, float keep,
+                                                          uint64_t seed, int N, int H, int W, int C) {
+  const int C4 = C >> 2;
+  const long total = (long)N * 4 * H * W * C4;
+  const bool drop = keep < 1.f;
+  const float inv_keep = drop ? 1.f / keep : 1.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int q = (int)(i % C4);
+    long r = i / C4;
+    const int x = (int)(r % (2 * W)); r /= (2 * W);
+    const int y = (int)(r % (2 * H));
+    const long n = r / (2 * H);
+    f32x4 v = ld4(in + ((n * H + (y >> 1)) * W + (x >> 1)) * C + 4 * q);
+    const long pix = (n * 2 * H + y) * 2 * W + x;
+    if (drop) {
+      const long elem = pix * C + 4 * q;
+      if (mask) {
+        const uchar4 m = *reinterpret_cast<const uchar4*>(mask + elem);
+        v[0] *= m.x ? inv_keep : 0.f; v[1] *= m.y ? inv_keep : 0.f; v[2] *= m.z ? inv_keep : 0.f; v[3] *= m.w ? inv_keep : 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= dc_keep_factor(seed, (uint64_t)(elem + e), keep, inv_keep);
+      }
+    }
+    st4(out + pix * out_ld + 4 * q, v);
+  }
+}
+
+// din[n,i,j,c] = sum_{a,b} dout[n,2i+a,2j+b,c] * dropfactor ; dout strided (dout_ld), din dense
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dout, long dout_ld,
+                                                          const uint8_t* __restrict__ mask, float keep, uint64_t seed,
+                                                          float* __restrict__ din, int N, int H, int W, int C) {
+  const int C4 = C >> 2;
+  const long total = (long)N * H * W * C4;
+  const bool drop = keep < 1.f;
+  const float inv_keep = drop ? 1.f / keep : 1.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int q = (int)(i % C4);
+    long r = i / C4;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const long n = r / H;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+      const long pix = (n * 2 * H + 2 * y + (pos >> 1)) * 2 * W + 2 * x + (pos & 1);
+      f32x4 g = ld4(dout + pix * dout_ld + 4 * q);
+      if (drop) {
+        const long elem = pix * C + 4 * q;
+        if (mask) {
+          const uchar4 m = *reinterpret_cast<const uchar4*>(mask + elem);
+          g[0] *= m.x ? inv_keep : 0.f; g[1] *= m.y ? inv_keep : 0.f; g[2] *= m.z ? inv_keep : 0.f; g[3] *= m.w ? inv_keep : 0.f;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] *= dc_keep_factor(seed, (uint64_t)(elem + e), keep, inv_keep);
+        }
+      }
+      acc += g;
+    }
+    st4(din + i * 4, acc);
+  }
+}
+
+extern "C" int dc_upsample2x_drop_fwd(const float* in, float* out, long out_ld, const uint8_t* mask, float keep,
+                                      uint64_t seed, int N, int H, int W, int C, dc_stream_t stream) {
+  DC_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0 && out_ld >= C && out_ld % 4 == 0 && keep > 0.f,
+             DC_EINVAL, "dc_upsample2x_drop_fwd: bad arguments");
+  const long total = (long)N * 4 * H * W * (C / 4);
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, out_ld, mask, keep,
+                     seed, N, H, W, C);
+  DC_CHECK_LAUNCH("dc_upsample2x_drop_fwd");
+  return DC_OK;
+}
+extern "C" int dc_upsample2x_drop_bwd(const float* dout, long dout_ld, const uint8_t* mask, float keep, uint64_t seed,
+                                      float* din, int N, int H, int W, int C, dc_stream_t stream) {
+  DC_REQUIRE(dout && din && N > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0 && dout_ld >= C && dout_ld % 4 == 0 && keep > 0.f,
+             DC_EINVAL, "dc_upsample2x_drop_bwd: bad arguments");
+  const long total = (long)N * H * W * (C / 4);
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, dout_ld, mask, keep,
+                     seed, din, N, H, W, C);
+  DC_CHECK_LAUNCH("dc_upsample2x_drop_bwd");
+  return DC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Head: C/4 lanes per pixel, xor-shuffle the two partial logits, lane q==0 finishes the pixel.
 #define DC_HEAD_SUMS 12   // bce, tp, sum round(p), fn, sum y, sum y*p, sum p^2, sum y^2, sum p, weighted-bce, 2 spare
 __device__ __forceinline__ float round_half_even(float x) { return rintf(x); }  // default RN mode = half to even

@@ -191,11 +191,10 @@ class Model(object):
                  upsampling_or_transpose='transpose', device=None, seed=7535):
         if conv_kernel_init != 'he_normal':
             raise NotImplementedError("only conv_kernel_init='he_normal' (the reference default) is built")
-        if upsampling_or_transpose != 'transpose':
-            raise NotImplementedError("the UpSampling2D branch (unet_2d_summary.py:160-161) is a 'next' row (SURVEY 8f)")
         self.config = dict(window_shape=tuple(int(v) for v in window_shape), nb_filters_base=int(nb_filters_base),
-                           prop_dropout_base=float(prop_dropout_base))
-        self.engine = UNetEngine(self.config['window_shape'], nb_filters_base, prop_dropout_base, device=device, seed=seed)
+                           prop_dropout_base=float(prop_dropout_base), upsampling_or_transpose=str(upsampling_or_transpose))
+        self.engine = UNetEngine(self.config['window_shape'], nb_filters_base, prop_dropout_base, device=device, seed=seed,
+                                 upsampling=(upsampling_or_transpose != 'transpose'))      # unet_2d_summary.py:155,:160
         self.optimizer = None
         self.loss = None
         self.metrics_names = ['loss']
@@ -391,6 +390,7 @@ def load_model_with_new_input_shape(model_path, input_shape, **load_model_args):
     if meta.get('format') != 'dcunet-npz-1':
         raise ValueError('%s is not a dcunet checkpoint' % model_path)
     cfg = meta['config']
-    model = Model(tuple(input_shape), cfg['nb_filters_base'], prop_dropout_base=cfg['prop_dropout_base'])
+    model = Model(tuple(input_shape), cfg['nb_filters_base'], prop_dropout_base=cfg['prop_dropout_base'],
+                  upsampling_or_transpose=cfg.get('upsampling_or_transpose', 'transpose'))
     model.load_state(model_path, with_optimizer=bool(load_model_args.get('compile', True)))
     return model

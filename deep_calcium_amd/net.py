@@ -45,8 +45,9 @@ class LayerSpec(object):
         return (1, 1, self.cin, self.cout)
 
 
-def build_layer_table(nfb=32, drp=0.25):
-    """Weighted layers in graph-creation order (= Keras get_weights order), unet_2d_summary.py:172-221."""
+def build_layer_table(nfb=32, drp=0.25, upsampling=False):
+    """Weighted layers in graph-creation order (= Keras get_weights order), unet_2d_summary.py:172-221.
+    upsampling=True: the UpSampling2D branch (:160-161) -- no up-conv layers, first decoder conv sees 3c inputs."""
     enc = [nfb << i for i in range(5)]
     rates = {'e1b': drp, 'e2b': 2 * drp, 'e3b': 2 * drp, 'u3': 2 * drp, 'u2': 2 * drp, 'u1': 2 * drp, 'u0': drp}
     L = []
@@ -58,15 +59,17 @@ def build_layer_table(nfb=32, drp=0.25):
         cin = c
     for lvl in (3, 2, 1, 0):
         c = enc[lvl]
-        L.append(LayerSpec('u%d' % lvl, 'convT', 2 * c, c, 0.5, lvl, rates.get('u%d' % lvl, 0.0), len(L)))
-        L.append(LayerSpec('d%da' % lvl, 'conv', 2 * c, c, 0.99, lvl, 0.0, len(L)))
+        if not upsampling:
+            L.append(LayerSpec('u%d' % lvl, 'convT', 2 * c, c, 0.5, lvl, rates.get('u%d' % lvl, 0.0), len(L)))
+        L.append(LayerSpec('d%da' % lvl, 'conv', 3 * c if upsampling else 2 * c, c, 0.99, lvl, 0.0, len(L)))
         L.append(LayerSpec('d%db' % lvl, 'conv', c, c, 0.99, lvl, 0.0, len(L)))
     L.append(LayerSpec('out', 'head', nfb, 2, None, 0, 0.0, len(L)))
     return L
 
 
 class UNetEngine(object):
-    def __init__(self, window_shape, nb_filters_base=32, prop_dropout_base=0.25, device=None, seed=7535, mfma=None):
+    def __init__(self, window_shape, nb_filters_base=32, prop_dropout_base=0.25, device=None, seed=7535, mfma=None,
+                 upsampling=False):
         # mfma: 'f16x3' (default; fp32-grade split-fp16 products on the fp16 matrix cores) or 'f32' (fp32 MFMA)
         self.mfma = mfma or os.environ.get('DC_MFMA', 'f16x3')
         if self.mfma not in ('f16x3', 'f32'):
@@ -84,7 +87,10 @@ class UNetEngine(object):
         self.L = lib()
         self.H, self.W, self.nfb, self.drp = H, W, nfb, float(prop_dropout_base)
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
-        self.layers = build_layer_table(nfb, self.drp)
+        self.upsampling = bool(upsampling)
+        self.layers = build_layer_table(nfb, self.drp, self.upsampling)
+        # dropout after the up layer of each level (unet_2d_summary.py:198,204,210,216)
+        self.up_drop = {3: 2 * self.drp, 2: 2 * self.drp, 1: 2 * self.drp, 0: self.drp}
         self.by_name = {l.name: l for l in self.layers}
         # ---- flat parameter layout -----------------------------------------------------------------
         off = 0
@@ -285,6 +291,10 @@ class UNetEngine(object):
     def _hw(self, lvl):
         return self.H >> lvl, self.W >> lvl
 
+    def _cup(self, lvl):
+        """Channels of the up-path half of level lvl's concat buffer (conv-transpose: c, UpSampling2D: 2c)."""
+        return (2 if self.upsampling else 1) * (self.nfb << lvl)
+
     def _acts(self, N):
         """Activation tensors for batch size N (allocated once per N)."""
         key = ('acts', N)
@@ -304,7 +314,7 @@ class UNetEngine(object):
             tag = 'b' if lvl == 4 else 'e%d' % lvl
             A[tag + 'a'] = new(N, h, w, c)
             if lvl < 4:
-                A['cat%d' % lvl] = new(N, h, w, 2 * c)      # [up path | skip]  (unet_2d_summary.py:200)
+                A['cat%d' % lvl] = new(N, h, w, self._cup(lvl) + c)   # [up path | skip]  (unet_2d_summary.py:200)
                 A['pool%d' % lvl] = new(N, h // 2, w // 2, c)
                 A['idx%d' % lvl] = new(N, h // 2, w // 2, c, dtype=torch.uint8)
                 A['d%da' % lvl] = new(N, h, w, c)
@@ -327,8 +337,9 @@ class UNetEngine(object):
             la, lb = self.by_name[tag + 'a'], self.by_name[tag + 'b']
             plan.append(('block', la, prev, A[tag + 'a'], 0, c, h, w))
             if lvl < 4:
-                plan.append(('block', lb, A[tag + 'a'], A['cat%d' % lvl], c, 2 * c, h, w))
-                plan.append(('pool', lvl, A['cat%d' % lvl], c, 2 * c, h, w))
+                cup = self._cup(lvl)
+                plan.append(('block', lb, A[tag + 'a'], A['cat%d' % lvl], cup, cup + c, h, w))
+                plan.append(('pool', lvl, A['cat%d' % lvl], cup, cup + c, h, w))
                 prev = A['pool%d' % lvl]
             else:
                 plan.append(('block', lb, A[tag + 'a'], A['bb'], 0, c, h, w))
@@ -336,8 +347,11 @@ class UNetEngine(object):
         for lvl in (3, 2, 1, 0):
             h, w = self._hw(lvl)
             c = nfb << lvl
-            lu, la, lb = self.by_name['u%d' % lvl], self.by_name['d%da' % lvl], self.by_name['d%db' % lvl]
-            plan.append(('block', lu, prev, A['cat%d' % lvl], 0, 2 * c, h, w))   # convT: h,w are OUTPUT dims
+            la, lb = self.by_name['d%da' % lvl], self.by_name['d%db' % lvl]
+            if self.upsampling:
+                plan.append(('up', lvl, prev, A['cat%d' % lvl], 3 * c, h, w))    # h,w are OUTPUT dims
+            else:
+                plan.append(('block', self.by_name['u%d' % lvl], prev, A['cat%d' % lvl], 0, 2 * c, h, w))   # convT: OUTPUT dims
             plan.append(('block', la, A['cat%d' % lvl], A['d%da' % lvl], 0, c, h, w))
             plan.append(('block', lb, A['d%da' % lvl], A['d%db' % lvl], 0, c, h, w))
             prev = A['d%db' % lvl]
@@ -356,6 +370,10 @@ class UNetEngine(object):
             if step[0] == 'pool':
                 _, lvl, src, coff, ld, h, w = step
                 L.dc_maxpool2x2_fwd(_ptr(src, coff), ld, _ptr(A['pool%d' % lvl]), None, N, h, w, self.nfb << lvl, st)
+                continue
+            if step[0] == 'up':
+                _, lvl, src, dst, ld, h, w = step
+                L.dc_upsample2x_drop_fwd(_ptr(src), _ptr(dst), ld, None, 1.0, 0, N, h // 2, w // 2, self._cup(lvl), st)
                 continue
             _, l, src, dst, coff, ld, h, w = step
             sc, sh = self.stat_ptr(l, 2), self.stat_ptr(l, 3)
@@ -415,7 +433,7 @@ class UNetEngine(object):
         T['gB'] = torch.empty(big, dtype=torch.float32, device=dev)
         for lvl in range(4):
             h, w = self._hw(lvl)
-            T['dcat%d' % lvl] = torch.empty(N * h * w * 2 * (nfb << lvl), dtype=torch.float32, device=dev)
+            T['dcat%d' % lvl] = torch.empty(N * h * w * (self._cup(lvl) + (nfb << lvl)), dtype=torch.float32, device=dev)
         self._bufs[key] = T
         return T
 
@@ -428,6 +446,16 @@ class UNetEngine(object):
             assert m.dtype == torch.uint8 and m.is_contiguous()
             return m.data_ptr(), keep, 0
         return None, keep, (step_seed * 1000003 + l.index * 7919) & 0xFFFFFFFFFFFFFFFF
+
+    def _up_drop_args(self, lvl, masks, step_seed):
+        rate = self.up_drop[lvl]
+        if rate <= 0.0:
+            return None, 1.0, 0
+        if masks is not None:
+            m = masks['u%d' % lvl]
+            assert m.dtype == torch.uint8 and m.is_contiguous()
+            return m.data_ptr(), 1.0 - rate, 0
+        return None, 1.0 - rate, (step_seed * 1000003 + (100 + lvl) * 7919) & 0xFFFFFFFFFFFFFFFF
 
     def forward_train(self, x_dev, y_dev, masks=None, update_moving=True):
         """Training-mode forward (batch statistics, dropout).  Returns p; loss/metric sums land in T['sums']."""
@@ -442,6 +470,11 @@ class UNetEngine(object):
                 _, lvl, src, coff, ld, h, w = step
                 L.dc_maxpool2x2_fwd(_ptr(src, coff), ld, _ptr(A['pool%d' % lvl]), A['idx%d' % lvl].data_ptr(),
                                     N, h, w, self.nfb << lvl, st)
+                continue
+            if step[0] == 'up':
+                _, lvl, src, dst, ld, h, w = step
+                mptr, keep, seed = self._up_drop_args(lvl, masks, step_seed)
+                L.dc_upsample2x_drop_fwd(_ptr(src), _ptr(dst), ld, mptr, keep, seed, N, h // 2, w // 2, self._cup(lvl), st)
                 continue
             _, l, src, dst, coff, ld, h, w = step
             z = T['z_' + l.name]
@@ -577,14 +610,20 @@ class UNetEngine(object):
             g, other = other, g
             block_bwd(self.by_name['d%da' % lvl], _ptr(cat), _ptr(g), c, _ptr(dcat))
             x_up = A['bb'] if lvl == 3 else A['d%db' % (lvl + 1)]
-            block_bwd(self.by_name['u%d' % lvl], _ptr(x_up), _ptr(dcat), 2 * c, _ptr(g))
+            if self.upsampling:
+                h, w = self._hw(lvl)
+                mptr, keep, seed = self._up_drop_args(lvl, masks, step_seed)
+                L.dc_upsample2x_drop_bwd(_ptr(dcat), 3 * c, mptr, keep, seed, _ptr(g), N, h // 2, w // 2, 2 * c, st)
+            else:
+                block_bwd(self.by_name['u%d' % lvl], _ptr(x_up), _ptr(dcat), 2 * c, _ptr(g))
         for lvl in (4, 3, 2, 1, 0):
             c = nfb << lvl
             h, w = self._hw(lvl)
             tag = 'b' if lvl == 4 else 'e%d' % lvl
             if lvl < 4:
                 # g = d(pool output); route through the argmax and add the skip gradient (second half of dcat)
-                L.dc_maxpool2x2_bwd(_ptr(g), A['idx%d' % lvl].data_ptr(), _ptr(T['dcat%d' % lvl], c), 2 * c,
+                cup = self._cup(lvl)
+                L.dc_maxpool2x2_bwd(_ptr(g), A['idx%d' % lvl].data_ptr(), _ptr(T['dcat%d' % lvl], cup), cup + c,
                                     _ptr(other), N, h, w, c, st)
                 g, other = other, g
             block_bwd(self.by_name[tag + 'b'], _ptr(A[tag + 'a']), _ptr(g), c, _ptr(other))

@@ -146,6 +146,15 @@ int dc_maxpool2x2_fwd(const float* in, long in_ld, float* out, uint8_t* idx,
 int dc_maxpool2x2_bwd(const float* dy, const uint8_t* idx, const float* skip, long skip_ld, float* dx,
                       int N, int H, int W, int C, dc_stream_t stream);
 
+/* ---- UpSampling2D() + Dropout  :160-161,:198 (the upsampling_or_transpose != 'transpose' branch) -------------
+ * nearest 2x of in [N,H,W,C] (dense) into out [N,2H,2W,C] (pixel stride out_ld), dropout applied to the
+ * up-sampled tensor (mask uint8 [N,2H,2W,C] or counter RNG(seed); keep >= 1: none). */
+int dc_upsample2x_drop_fwd(const float* in, float* out, long out_ld, const uint8_t* mask, float keep, uint64_t seed,
+                           int N, int H, int W, int C, dc_stream_t stream);
+/* din[N,H,W,C] (dense) = sum over each 2x2 block of dout (pixel stride dout_ld) * dropout factor */
+int dc_upsample2x_drop_bwd(const float* dout, long dout_ld, const uint8_t* mask, float keep, uint64_t seed, float* din,
+                           int N, int H, int W, int C, dc_stream_t stream);
+
 /* ---- Conv2D(2,1,softmax) + Lambda(x[...,-1]) + loss + metrics  :221-222,:372-380,:398-399 ------------------
  * p = softmax(a.Kh + bh)[...,1].  y != NULL: also partial[blocks][DC_HEAD_SUMS = 12] =
  *   {bce_sum, sum round(p)*y, sum round(p), sum clip(y-round(p),0,1), sum y, sum y*p, sum p*p, sum y*y,

@@ -25,11 +25,13 @@ CLIP_HI = float(np.float32(1.0) - np.float32(1e-7))
 # ----------------------------------------------------------------------------
 # Topology  (unet_2d_summary.py:169-223)
 # ----------------------------------------------------------------------------
-def layer_table(nfb=32):
+def layer_table(nfb=32, upsampling=False):
     """Weighted layers in graph-creation (= Keras get_weights) order.
 
     Returns a list of (name, kind, cin, cout, bn_momentum) with kind in
-    {'conv', 'convT', 'head'}.  unet_2d_summary.py:172-221.
+    {'conv', 'convT', 'head'}.  unet_2d_summary.py:172-221.  upsampling=True is the
+    `upsampling_or_transpose != 'transpose'` branch (:160-161): up_layer = UpSampling2D(), no weights, the
+    up-sampled tensor keeps its 2c channels, so the first decoder conv of a level sees 3c inputs.
     """
     L = []
     enc = [nfb, nfb * 2, nfb * 4, nfb * 8, nfb * 16]
@@ -41,8 +43,9 @@ def layer_table(nfb=32):
         cin = c
     for lvl in (3, 2, 1, 0):                           # :197-220
         c = enc[lvl]
-        L.append(('u%d' % lvl, 'convT', c * 2, c, 0.5))      # up_layer :154-161
-        L.append(('d%da' % lvl, 'conv', c * 2, c, 0.99))     # after concat :200
+        if not upsampling:
+            L.append(('u%d' % lvl, 'convT', c * 2, c, 0.5))  # up_layer :154-161
+        L.append(('d%da' % lvl, 'conv', c * 3 if upsampling else c * 2, c, 0.99))     # after concat :200
         L.append(('d%db' % lvl, 'conv', c, c, 0.99))
     L.append(('out', 'head', nfb, 2, None))            # :221
     return L
@@ -54,10 +57,10 @@ def dropout_rates(drp=0.25):
             'u3': 2 * drp, 'u2': 2 * drp, 'u1': 2 * drp, 'u0': drp}
 
 
-def weight_shapes(nfb=32):
-    """Shapes of the 134 get_weights() arrays."""
+def weight_shapes(nfb=32, upsampling=False):
+    """Shapes of the 134 (110 with upsampling) get_weights() arrays."""
     shapes = []
-    for name, kind, cin, cout, _ in layer_table(nfb):
+    for name, kind, cin, cout, _ in layer_table(nfb, upsampling):
         if kind == 'conv':
             shapes += [(3, 3, cin, cout), (cout,)] + [(cout,)] * 4
         elif kind == 'convT':
@@ -77,11 +80,11 @@ def _trunc_normal(rs, shape, std):
     return out * std
 
 
-def init_weights(nfb=32, seed=7535, dtype=np.float32, randomize_bn=False):
+def init_weights(nfb=32, seed=7535, dtype=np.float32, randomize_bn=False, upsampling=False):
     """he_normal conv kernels (fan_in = prod(shape[:-2])*shape[-2]), glorot-uniform head, BN identity."""
     rs = np.random.RandomState(seed)
     W = []
-    for name, kind, cin, cout, _ in layer_table(nfb):
+    for name, kind, cin, cout, _ in layer_table(nfb, upsampling):
         if kind == 'conv':
             W.append(_trunc_normal(rs, (3, 3, cin, cout), np.sqrt(2.0 / (9 * cin))))
         elif kind == 'convT':
@@ -266,9 +269,10 @@ def adam_keras(p, g, m, v, it, lr=0.002, b1=0.9, b2=0.999, eps=1e-8):
 class UNetOracle(object):
     """Float64 forward/backward of unet() (unet_2d_summary.py:123-224) on a Keras-ordered weight list."""
 
-    def __init__(self, weights, nfb=32, drp=0.25, dtype=np.float64):
+    def __init__(self, weights, nfb=32, drp=0.25, dtype=np.float64, upsampling=False):
         self.nfb = nfb
-        self.table = layer_table(nfb)
+        self.upsampling = upsampling
+        self.table = layer_table(nfb, upsampling)
         self.drop = dropout_rates(drp) if drp else {}
         self.dtype = dtype
         self.P = {}
@@ -321,7 +325,13 @@ class UNetOracle(object):
                     taps['p%d' % lvl] = x
                     taps['p%d_idx' % lvl] = idx
         for lvl in (3, 2, 1, 0):
-            x = self._block('u%d' % lvl, 'convT', x, training, masks, cache)
+            if self.upsampling:                            # UpSampling2D() then Dropout (:160-161, :198)
+                x = np.repeat(np.repeat(x, 2, axis=1), 2, axis=2)
+                name = 'u%d' % lvl
+                if training and self.drop.get(name, 0) > 0:
+                    x = x * masks[name].astype(self.dtype) / (1.0 - self.drop[name])
+            else:
+                x = self._block('u%d' % lvl, 'convT', x, training, masks, cache)
             x = np.concatenate([x, skips[lvl]], axis=-1)   # up path first (:200)
             x = self._block('d%da' % lvl, 'conv', x, training, masks, cache)
             x = self._block('d%db' % lvl, 'conv', x, training, masks, cache)
@@ -372,6 +382,15 @@ class UNetOracle(object):
         for lvl in (0, 1, 2, 3):
             da = block_bwd('d%db' % lvl, 'conv', da)
             dcat = block_bwd('d%da' % lvl, 'conv', da)
+            if self.upsampling:
+                C = dcat.shape[-1] // 3
+                dskip[lvl] = dcat[..., 2 * C:]
+                name = 'u%d' % lvl
+                dup = dcat[..., :2 * C]
+                if self.drop.get(name, 0) > 0:
+                    dup = dup * cache['_masks'][name] / (1.0 - self.drop[name])
+                da = dup[:, 0::2, 0::2] + dup[:, 0::2, 1::2] + dup[:, 1::2, 0::2] + dup[:, 1::2, 1::2]
+                continue
             C = dcat.shape[-1] // 2
             dskip[lvl] = dcat[..., C:]
             da = block_bwd('u%d' % lvl, 'convT', dcat[..., :C])
@@ -402,12 +421,13 @@ class UNetOracle(object):
         return loss, p
 
 
-def make_drop_masks(nfb, N, H, W, drp=0.25, seed=7):
+def make_drop_masks(nfb, N, H, W, drp=0.25, seed=7, upsampling=False):
     """Explicit Bernoulli(keep) masks, identical bits for oracle and HIP path."""
     rs = np.random.RandomState(seed)
     out = {}
+    k = 2 if upsampling else 1          # the up-sampled tensor keeps the 2c channels of the level below
     shp = {'e1b': (H // 2, nfb * 2), 'e2b': (H // 4, nfb * 4), 'e3b': (H // 8, nfb * 8),
-           'u3': (H // 8, nfb * 8), 'u2': (H // 4, nfb * 4), 'u1': (H // 2, nfb * 2), 'u0': (H, nfb)}
+           'u3': (H // 8, nfb * 8 * k), 'u2': (H // 4, nfb * 4 * k), 'u1': (H // 2, nfb * 2 * k), 'u0': (H, nfb * k)}
     for name, rate in dropout_rates(drp).items():
         h, c = shp[name]
         w = h * W // H

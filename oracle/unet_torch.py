@@ -26,8 +26,9 @@ def _to_t(w, dtype, requires_grad=False):
 
 
 class UNetTorch(object):
-    def __init__(self, weights, nfb=32, drp=0.25, dtype=torch.float64, requires_grad=True):
-        self.table = layer_table(nfb)
+    def __init__(self, weights, nfb=32, drp=0.25, dtype=torch.float64, requires_grad=True, upsampling=False):
+        self.upsampling = upsampling
+        self.table = layer_table(nfb, upsampling)
         self.drop = dropout_rates(drp) if drp else {}
         self.dtype = dtype
         self.P = {}
@@ -74,7 +75,14 @@ class UNetTorch(object):
                 skips[lvl] = x
                 x = F.max_pool2d(x, 2, 2)
         for lvl in (3, 2, 1, 0):
-            x = self._block('u%d' % lvl, 'convT', x, training, masks, stats)
+            if self.upsampling:
+                x = F.interpolate(x, scale_factor=2, mode='nearest')
+                name = 'u%d' % lvl
+                if training and self.drop.get(name, 0) > 0:
+                    m = torch.as_tensor(np.asarray(masks[name]), dtype=self.dtype).permute(0, 3, 1, 2)
+                    x = x * m / (1.0 - self.drop[name])
+            else:
+                x = self._block('u%d' % lvl, 'convT', x, training, masks, stats)
             x = torch.cat([x, skips[lvl]], dim=1)
             x = self._block('d%da' % lvl, 'conv', x, training, masks, stats)
             x = self._block('d%db' % lvl, 'conv', x, training, masks, stats)

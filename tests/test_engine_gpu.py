@@ -121,6 +121,35 @@ def test_train_forward_backward_matches_oracle(N, H, W, nfb, mfma):
     print('relu gate flips: %d, gradient cosine %.7f' % (flips, cos))
 
 
+def test_upsampling_branch_matches_oracle():
+    """unet(upsampling_or_transpose='upsampling') (unet_2d_summary.py:160-161): UpSampling2D + dropout instead of the
+    transposed conv; 110 weight arrays, 3c-channel concat."""
+    from deep_calcium_amd.net import UNetEngine
+    N, H, W, nfb = 2, 32, 32, 8
+    eng = UNetEngine((H, W), nfb, upsampling=True)
+    Wt = on.init_weights(nfb, randomize_bn=True, upsampling=True)
+    assert len(Wt) == 110 and len(eng.weight_shapes()) == 110
+    eng.set_weights(Wt)
+    x, y = on.synthetic_batch(N, H, W)
+    masks = on.make_drop_masks(nfb, N, H, W, upsampling=True)
+    orc = on.UNetOracle(Wt, nfb, upsampling=True)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    assert np.abs(eng.forward_infer(xd).cpu().numpy() - orc.forward(x)).max() < 1e-4
+    loss_ref, p_ref, G_ref, _ = orc.loss_and_grads(x, y, masks)
+    p = eng.forward_train(xd, yd, dev_masks(masks), update_moving=False).cpu().numpy()
+    eng.backward()
+    assert np.abs(p - p_ref).max() < 1e-4 and abs(eng.read_sums()[0] / p.size - loss_ref) < 1e-4
+    G = eng.grads()
+    fg = np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(G[n]) if not (j == 1 and n != 'out')]).astype(np.float64)
+    fr = np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(G_ref[n]) if not (j == 1 and n != 'out')])
+    assert fg.dot(fr) / (np.linalg.norm(fg) * np.linalg.norm(fr)) > 0.9995
+    assert np.linalg.norm(fg - fr) < 0.05 * np.linalg.norm(fr)
+    # random-RNG dropout path runs and is reproducible in backward (same seed regenerates the masks)
+    eng.forward_train(xd, yd, None, update_moving=False)
+    eng.backward()
+    assert np.isfinite(eng.gflat.cpu().numpy()).all()
+
+
 @pytest.mark.parametrize('loss', ['weighted_binary_crossentropy', 'dice_loss', 'dicesq_loss'])
 def test_alternate_losses_match_oracle(loss):
     from deep_calcium_amd.model import LOSS_KINDS, metrics_from_sums
