@@ -10,16 +10,19 @@
 // lo images of both tiles as 32-channel planes ([plane][pixel][32 ch] = 64-B rows): 4 consecutive pixel rows of a
 // plane are 256 contiguous bytes => conflict-free transposed reads, every tap / k-step offset is an immediate.
 //
-// Pipeline (ONE CTA per CU, one wave per SIMD, the whole 512-register file; the earlier 2-CTA/CU version parked
-// 56 % of its wave-cycles in s_waitcnt and was issue-bound at 1.6 LDS + 2.6 VALU instructions per MFMA):
-//   * a wave owns 32 m-channels x (32*WN) n-channels for ALL taps: every A fragment pair feeds 3*WN MFMAs;
-//   * two LDS image sets: tile t is consumed from set t&1 while tile t+1 is produced into the other;
-//   * the raw fp32 rows of tile t+1 are requested (bounds-checked buffer loads) right after the barrier, stay in
-//     registers through the first MFMA groups, and are split + written to LDS piece by piece BETWEEN the MFMAs of
-//     the last groups (an MFMA holds the issue port 8 of its 32 cycles);
-//   * operand fragments of group g+1 are requested from LDS before the MFMAs of group g issue;
-//   * one barrier per tile; the WK waves that share an (m,n) block are summed through LDS at the end, one slab per
-//     CTA goes to HBM and dc_reduce_partials adds the slabs in a fixed order (bit-reproducible, no atomics).
+// Pipeline (ONE 512-thread CTA per CU = two waves per SIMD with fixed roles):
+//   * waves 0-3 (consumers) own the matrix pipe: a wave owns 32 m-channels x (32*NBW) n-channels for ALL taps, so
+//     every A fragment pair feeds 3*NBW MFMAs; fragments of group g+1 are requested from LDS before the MFMAs of
+//     group g issue.  With nothing else in their instruction stream they run at the MFMA-only rate (measured by
+//     ablation: 440-480 TF/s-equivalent; the earlier single-role version, whose waves also staged, ran at the SUM
+//     of its MFMA-only and staging-only times, 210-300).
+//   * waves 4-7 (producers, the SIMD partners of 0-3) request the raw fp32 rows of tile t+2 (bounds-checked buffer
+//     loads into a second register set) and then split tile t+1 into fp16 hi/lo and write it to the other LDS
+//     image set: their VALU / VMEM / LDS-write work fills the issue slots the consumers' MFMAs leave free
+//     (an MFMA holds the issue port 8 of its 32 cycles).
+//   * two LDS image sets, one barrier per tile; the WK consumer waves that share an (m,n) block are summed through
+//     LDS at the end, one slab per CTA goes to HBM and dc_reduce_partials adds the slabs in a fixed order
+//     (bit-reproducible, no atomics).
 #include "wgrad_common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -75,7 +78,7 @@ __device__ __forceinline__ void split4_f16(const f32x4 v, float s, u32x2& hi, u3
 }
 
 template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW, bool A_SCALED>
-__global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
+__global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
   using Cfg = WgradHCfg<KH, KW, S, PAD, TW, RW, WM, WNW, NBW>;
   constexpr int TAPS = Cfg::TAPS, WK = Cfg::WK, TH = Cfg::TH, CM = Cfg::CM, CN = Cfg::CN;
   constexpr int TWI = Cfg::TWI, APIX = Cfg::APIX, BPIX = Cfg::BPIX;
@@ -83,21 +86,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
   constexpr int KROWS = (TW >= 16) ? 1 : 16 / TW;               // pixel rows covered by one 16-pixel k-step
   constexpr int KX = (TW >= 16) ? TW / 16 : 1;                  // k-steps along a row
   constexpr int AC4 = CM / 4, BC4 = CN / 4;
-  constexpr int NA = (APIX * AC4 + 255) / 256, NB = (BPIX * BC4 + 255) / 256;   // float4 loads per thread
+  constexpr int NA = (APIX * AC4 + 255) / 256, NB = (BPIX * BC4 + 255) / 256;   // float4 loads per producer thread
   constexpr int KSTEPS = (RW / KROWS) * KX;
   constexpr int GROUPS = KSTEPS * TAPS;                         // (k-step, tap) MFMA groups per tile
-  constexpr int PIECES = NA + NB;
-  constexpr int PPG = (PIECES + GROUPS - 1) / GROUPS;           // staging pieces carried per MFMA group
-  constexpr int G0 = GROUPS - (PIECES + PPG - 1) / PPG;         // first group that carries pieces
   static_assert(RW % KROWS == 0, "rows per wave must be a multiple of the k-step height");
   const WgradParams& p = hp.g;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, cb = (lane >> 4) & 1, c = lane & 15, q = c >> 2, pp = c & 3;
-  const int wm = wave % WM, wnw = (wave / WM) % WNW, wk = wave / (WM * WNW);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // 0..7, provably wave-uniform
   // XCD-aware rasterisation (speed only): ids b and b+8 share an L2, so each XCD walks a contiguous range of
   // (pixel split, channel block) pairs with the channel block fastest -- the CTAs that stream the same pixel range
   // for different (m,n) blocks run side by side on one L2.
@@ -106,8 +104,101 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
   const int work = (xcd < rr8 ? xcd * (qq + 1) : rr8 * (qq + 1) + (xcd - rr8) * qq) + seq;
   const int split = work / (nbm * nbn), blk = work - split * (nbm * nbn);
   const int m0 = (blk / nbn) * CM, n0 = (blk % nbn) * CN;
-  const float a_scale = hp.aScale ? *hp.aScale : 1.f;
-  const float b_scale = hp.bScale ? *hp.bScale : 1.f;
+  const int tile_beg = split * p.tilesPerSplit;
+  const int nt = min(tile_beg + p.tilesPerSplit, p.tilesTotal) - tile_beg;   // tiles of this CTA (>= 1)
+
+  if (wave >= 4) {
+    // ================= producer waves: HBM -> registers -> fp16 hi/lo images in LDS =========================
+    const int st = tid & 255;
+    const float a_scale = hp.aScale ? *hp.aScale : 1.f;
+    const float b_scale = hp.bScale ? *hp.bScale : 1.f;
+    const int a_c4 = st % AC4, b_c4 = st % BC4;
+    const bool a_ch_ok = (m0 + 4 * a_c4) < p.Cm, b_ch_ok = (n0 + 4 * b_c4) < p.Cn;
+    const int a_rowb = p.Wa * p.Cm * 4, b_rowb = p.Wb * p.Cn * 4;
+    const int a_lbase = (a_c4 >> 3) * A_PLANE + (a_c4 & 7) * 8;
+    const int b_lbase = 2 * A_IMG + (b_c4 >> 3) * B_PLANE + (b_c4 & 7) * 8;
+
+    // request tile `tile`'s raw rows (zeros outside the image: rows via the descriptor bounds, columns by compare)
+    auto request = [&](int tile, f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
+      int t = tile;
+      const int tx = t % p.tilesX; t /= p.tilesX;
+      const int ty = t % p.tilesY;
+      const int img = t / p.tilesY;
+      const int py0 = ty * TH, px0 = tx * TW;
+      const int ay0 = py0 * S - PAD, ax0 = px0 * S - PAD;
+      const __amdgpu_buffer_rsrc_t rsA = dc_make_rsrc(p.A + (long)img * p.Ha * p.Wa * p.Cm, (unsigned)(p.Ha * p.Wa * p.Cm) * 4u);
+      const __amdgpu_buffer_rsrc_t rsB = dc_make_rsrc(p.B + (long)img * p.Hb * p.Wb * p.Cn, (unsigned)(p.Hb * p.Wb * p.Cn) * 4u);
+      const int abase = (ay0 * p.Wa + ax0) * p.Cm * 4 + (m0 + 4 * a_c4) * 4;   // may be negative: wraps out of range
+      const int bbase = (py0 * p.Wb + px0) * p.Cn * 4 + (n0 + 4 * b_c4) * 4;
+#pragma unroll
+      for (int k = 0; k < NA; ++k) {
+        const int pix = st / AC4 + k * (256 / AC4);
+        const int r = __umul24(pix, (65536 + TWI - 1) / TWI) >> 16;          // pix / TWI for pix < 4096
+        const int cc = pix - __umul24(r, TWI);
+        const bool ok = a_ch_ok && pix < APIX && (unsigned)(ax0 + cc) < (unsigned)p.Wa;
+        const unsigned off = ok ? (unsigned)(abase + __mul24(r, a_rowb) + __mul24(cc, p.Cm * 4)) : 0x80000000u;
+        ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int pix = st / BC4 + k * (256 / BC4);
+        const int r = pix / TW, cc = pix % TW;
+        const bool ok = b_ch_ok && pix < BPIX && (px0 + cc) < p.Wb;
+        const unsigned off = ok ? (unsigned)(bbase + __mul24(r, b_rowb) + __mul24(cc, p.Cn * 4)) : 0x80000000u;
+        rb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
+      }
+    };
+    // split the requested rows into fp16 hi/lo and write them into image set `set`
+    auto stage = [&](const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], char* set) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int pix = st / AC4 + j * (256 / AC4);
+        u32x2 hi, lo;
+        split4_f16<A_SCALED>(ra[j], a_scale, hi, lo);
+        if (pix < APIX) {
+          *reinterpret_cast<u32x2*>(set + a_lbase + pix * 64) = hi;
+          *reinterpret_cast<u32x2*>(set + A_IMG + a_lbase + pix * 64) = lo;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int pix = st / BC4 + k * (256 / BC4);
+        u32x2 hi, lo;
+        split4_f16<!A_SCALED>(rb[k], b_scale, hi, lo);
+        if (pix < BPIX) {
+          *reinterpret_cast<u32x2*>(set + b_lbase + pix * 64) = hi;
+          *reinterpret_cast<u32x2*>(set + B_IMG + b_lbase + pix * 64) = lo;
+        }
+      }
+    };
+
+    // Two register sets: while tile i+1 is split into LDS, tile i+2's rows are already in flight (a full tile of
+    // MFMA time plus the split covers the HBM latency even when a bandwidth-bound kernel shares the chip).
+    f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+    request(tile_beg, ra0, rb0);
+    if (nt > 1) request(tile_beg + 1, ra1, rb1);
+    stage(ra0, rb0, smem);
+    __syncthreads();
+    for (int i = 0; i < nt; i += 2) {
+      if (i + 2 < nt) request(tile_beg + i + 2, ra0, rb0);
+      if (i + 1 < nt) stage(ra1, rb1, smem + SET);
+      __syncthreads();
+      if (i + 1 < nt) {
+        if (i + 3 < nt) request(tile_beg + i + 3, ra1, rb1);
+        if (i + 2 < nt) stage(ra0, rb0, smem);
+        __syncthreads();
+      }
+    }
+    if constexpr (WK > 1) {   // keep in step with the barriers of the consumers' cross-wave reduction
+#pragma unroll 1
+      for (int k = 0; k < 2 * TAPS * NBW; ++k) __syncthreads();
+    }
+    return;
+  }
+
+  // ===================== consumer waves: transposed LDS fragments -> MFMA ====================================
+  const int h = lane >> 5, cb = (lane >> 4) & 1, c = lane & 15, q = c >> 2, pp = c & 3;
+  const int wm = wave % WM, wnw = (wave / WM) % WNW, wk = wave / (WM * WNW);
 
   // lane-constant byte offsets of the two transposed reads of a k-step whose first pixel is (row 0, x 0)
   int offA[2], offB[2];
@@ -119,13 +210,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
     offB[r2] = 2 * A_IMG + (ky * TW + kx) * 64 + cb * 32 + pp * 8;
   }
 
-  // tile-invariant staging coordinates of this thread
-  const int a_c4 = tid % AC4, b_c4 = tid % BC4;
-  const bool a_ch_ok = (m0 + 4 * a_c4) < p.Cm, b_ch_ok = (n0 + 4 * b_c4) < p.Cn;
-  const int a_rowb = p.Wa * p.Cm * 4, b_rowb = p.Wb * p.Cn * 4;
-  const int a_lbase = (a_c4 >> 3) * A_PLANE + (a_c4 & 7) * 8;
-  const int b_lbase = 2 * A_IMG + (b_c4 >> 3) * B_PLANE + (b_c4 & 7) * 8;
-
   f32x16 acc[NBW][TAPS];
 #pragma unroll
   for (int w = 0; w < NBW; ++w)
@@ -133,68 +217,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[w][t][r] = 0.f;
-
-  const int tile_beg = split * p.tilesPerSplit;
-  const int tile_end = min(tile_beg + p.tilesPerSplit, p.tilesTotal);
-
-  f32x4 ra[NA], rb[NB];
-  // request tile `tile`'s raw rows (zeros outside the image: rows via the descriptor bounds, columns by compare)
-  auto request = [&](int tile) {
-    int t = tile;
-    const int tx = t % p.tilesX; t /= p.tilesX;
-    const int ty = t % p.tilesY;
-    const int img = t / p.tilesY;
-    const int py0 = ty * TH, px0 = tx * TW;
-    const int ay0 = py0 * S - PAD, ax0 = px0 * S - PAD;
-    const __amdgpu_buffer_rsrc_t rsA = dc_make_rsrc(p.A + (long)img * p.Ha * p.Wa * p.Cm, (unsigned)(p.Ha * p.Wa * p.Cm) * 4u);
-    const __amdgpu_buffer_rsrc_t rsB = dc_make_rsrc(p.B + (long)img * p.Hb * p.Wb * p.Cn, (unsigned)(p.Hb * p.Wb * p.Cn) * 4u);
-    const int abase = (ay0 * p.Wa + ax0) * p.Cm * 4 + (m0 + 4 * a_c4) * 4;   // may be negative: wraps out of range
-    const int bbase = (py0 * p.Wb + px0) * p.Cn * 4 + (n0 + 4 * b_c4) * 4;
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      const int pix = tid / AC4 + k * (256 / AC4);
-      const int r = __umul24(pix, (65536 + TWI - 1) / TWI) >> 16;          // pix / TWI for pix < 4096
-      const int cc = pix - __umul24(r, TWI);
-      const bool ok = a_ch_ok && pix < APIX && (unsigned)(ax0 + cc) < (unsigned)p.Wa;
-      const unsigned off = ok ? (unsigned)(abase + __mul24(r, a_rowb) + __mul24(cc, p.Cm * 4)) : 0x80000000u;
-      ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
-    }
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      const int pix = tid / BC4 + k * (256 / BC4);
-      const int r = pix / TW, cc = pix % TW;
-      const bool ok = b_ch_ok && pix < BPIX && (px0 + cc) < p.Wb;
-      const unsigned off = ok ? (unsigned)(bbase + __mul24(r, b_rowb) + __mul24(cc, p.Cn * 4)) : 0x80000000u;
-      rb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
-    }
-  };
-  // split one requested float4 into fp16 hi/lo and write it into image set `set` (j is a compile-time index)
-  auto stage_piece = [&](int j, char* set) {
-    u32x2 hi, lo;
-    if (j < NA) {
-      const int pix = tid / AC4 + j * (256 / AC4);
-      split4_f16<A_SCALED>(ra[j], a_scale, hi, lo);
-      if (pix < APIX) {
-        *reinterpret_cast<u32x2*>(set + a_lbase + pix * 64) = hi;
-        *reinterpret_cast<u32x2*>(set + A_IMG + a_lbase + pix * 64) = lo;
-      }
-    } else {
-      const int k = j - NA;
-      const int pix = tid / BC4 + k * (256 / BC4);
-      split4_f16<!A_SCALED>(rb[k], b_scale, hi, lo);
-      if (pix < BPIX) {
-        *reinterpret_cast<u32x2*>(set + b_lbase + pix * 64) = hi;
-        *reinterpret_cast<u32x2*>(set + B_IMG + b_lbase + pix * 64) = lo;
-      }
-    }
-  };
-
-  if (tile_beg < tile_end) {
-    request(tile_beg);
-#pragma unroll
-    for (int j = 0; j < PIECES; ++j) stage_piece(j, smem);
-  }
-  __syncthreads();
 
   // byte offset of group g's A fragment block / of k-step ks's B fragment block
   auto a_off = [&](int g) {
@@ -207,12 +229,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
     return (wnw * NBW + w) * B_PLANE + (prow * TW + xs * 16) * 64;
   };
 
-  for (int tile = tile_beg; tile < tile_end; ++tile) {
-    char* cur = smem + ((tile - tile_beg) & 1) * SET;
-    char* nxt = smem + (((tile - tile_beg) & 1) ^ 1) * SET;
-    const bool more = tile + 1 < tile_end;       // wave-uniform
-    if (more) request(tile + 1);
-
+  __syncthreads();   // image set 0 is ready
+  for (int i = 0; i < nt; ++i) {
+    char* cur = smem + (i & 1) * SET;
     f16x8 ah[2], al[2], bh[2][NBW], bl[2][NBW];
     ah[0] = tr_frag(cur, offA[0] + a_off(0), offA[1] + a_off(0));
     al[0] = tr_frag(cur + A_IMG, offA[0] + a_off(0), offA[1] + a_off(0));
@@ -224,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
 #pragma unroll
     for (int g = 0; g < GROUPS; ++g) {
       const int ca = g & 1, ks = g / TAPS, tap = g % TAPS, cbuf = ks & 1;
-      if (g + 1 < GROUPS) {
+      if (g + 1 < GROUPS) {      // fragments of group g+1 are requested before the MFMAs of group g issue
         ah[ca ^ 1] = tr_frag(cur, offA[0] + a_off(g + 1), offA[1] + a_off(g + 1));
         al[ca ^ 1] = tr_frag(cur + A_IMG, offA[0] + a_off(g + 1), offA[1] + a_off(g + 1));
         if ((g + 1) % TAPS == 0) {
@@ -242,18 +261,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
         acc[w][tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cbuf][w], acc[w][tap], 0, 0, 0);
         acc[w][tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cbuf][w], acc[w][tap], 0, 0, 0);
       }
-      // the last groups each carry PPG conversion pieces of the next tile in the MFMA shadow
-      if (g >= G0 && more) {
-#pragma unroll
-        for (int u = 0; u < PPG; ++u)
-          if ((g - G0) * PPG + u < PIECES) stage_piece((g - G0) * PPG + u, nxt);
-      }
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    __syncthreads();   // this set may be overwritten, the other one is complete
   }
 
-  const float out_scale = 1.f / (a_scale * b_scale);
+  const float out_scale = 1.f / ((hp.aScale ? *hp.aScale : 1.f) * (hp.bScale ? *hp.bScale : 1.f));
 #pragma unroll
   for (int w = 0; w < NBW; ++w)   // one 32x32 block at a time through the shared cross-wave reduction + store
     wgrad_store<TAPS, WM, WNW, WK>(p, acc[w], smem, split, m0, n0 + 32 * (wnw * NBW + w) - 32 * wnw, wm, wnw, wk, lane,
@@ -311,7 +324,7 @@ static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, 
   p.tilesX = pl.tilesX; p.tilesY = pl.tilesY; p.tilesTotal = pl.tilesTotal; p.tilesPerSplit = pl.tilesPerSplit;
   hp.aScale = aScale; hp.bScale = bScale;
   dim3 grid((unsigned)(pl.splits * dc_cdiv(Cm, Cfg::CM) * dc_cdiv(Cn, Cfg::CN)));
-  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, hp);
+  hipLaunchKernelGGL(kern, grid, dim3(512), Cfg::LDS_BYTES, st, hp);
   DC_CHECK_LAUNCH(name);
   const long L = (long)KH * KW * Cm * Cn;
   return dc_reduce_partials(ws, pl.splits, L, 1.0f, dw, ws + (long)pl.splits * L, (dc_stream_t)st);

@@ -75,6 +75,8 @@ class UNetEngine(object):
         if self.mfma not in ('f16x3', 'f32'):
             raise ValueError("mfma must be 'f16x3' or 'f32', got %r" % self.mfma)
         self.streams = 1 if os.environ.get('DC_STREAMS', '2') == '1' else 2     # 2: weight gradients on a side stream
+        self.wgrad_after_dgrad = os.environ.get('DC_WGRAD_AFTER_DGRAD', '0') == '1'
+        self.dz_bufs = int(os.environ.get('DC_DZ_BUFS', '3'))
         self.loss_kind = 0      # 0 binary_crossentropy, 1 weighted_binary_crossentropy, 2 dice_loss, 3 dicesq_loss
         H, W = window_shape
         if H % 16 or W % 16:
@@ -421,14 +423,14 @@ class UNetEngine(object):
         T['part_ws'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['part_ws2'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['absmax'] = torch.empty(4096, dtype=torch.float32, device=dev)
-        T['dz_scale'] = torch.ones(3 * 4, dtype=torch.float32, device=dev)      # one (16-B aligned) scalar per dz buffer
+        T['dz_scale'] = torch.ones(self.dz_bufs * 4, dtype=torch.float32, device=dev)      # one (16-B aligned) scalar per dz buffer
         T['red_tmp'] = torch.empty(32 * 1024, dtype=torch.float32, device=dev)
         T['wgrad_ws'] = torch.empty(ws_floats, dtype=torch.float32, device=dev)
         T['sums'] = torch.zeros(12, dtype=torch.float64, device=dev)
         big = N * self.H * self.W * nfb
         # dz rotates over 3 buffers: the weight-gradient kernels run on a side stream and may still be reading the
         # dz of block L while the main stream already produces the dz of block L-1 / L-2
-        T['dz'] = [torch.empty(big, dtype=torch.float32, device=dev) for _ in range(3)]
+        T['dz'] = [torch.empty(big, dtype=torch.float32, device=dev) for _ in range(self.dz_bufs)]
         T['gA'] = torch.empty(big, dtype=torch.float32, device=dev)
         T['gB'] = torch.empty(big, dtype=torch.float32, device=dev)
         for lvl in range(4):
@@ -533,15 +535,26 @@ class UNetEngine(object):
         main = torch.cuda.current_stream(self.device)
         if getattr(self, '_side_stream', None) is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
-            self._dz_free = [None, None, None]
+            self._dz_free = [None] * self.dz_bufs
         if self.streams == 1:
-            self._dz_free = [None, None, None]
+            self._dz_free = [None] * self.dz_bufs
         side = self._side_stream if self.streams == 2 else main
         sw = side.cuda_stream
         two = side is not main
         if two:
             side.wait_stream(main)        # everything queued so far (forward, head) precedes the first wgrad
         self._dz_turn = getattr(self, '_dz_turn', 0)
+
+        def launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16):
+            if l.kind == 'conv':
+                if f16:
+                    L.dc_conv3x3_dgrad_f16x3(dz, wpd, dx_ptr, scale, N, h, w, l.cin, l.cout, st)
+                else:
+                    L.dc_conv3x3_dgrad(dz, wpd, dx_ptr, N, h, w, l.cin, l.cout, st)
+            elif f16:
+                L.dc_convT2x2_dgrad_f16x3(dz, wpd, dx_ptr, scale, N, h // 2, w // 2, l.cin, l.cout, st)
+            else:
+                L.dc_convT2x2_dgrad(dz, wpd, dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
 
         def block_bwd(l, x_in, da_ptr, da_ld, dx_ptr):
             """da (strided) -> grads of l; dx written to dx_ptr (dense [.., cin]) unless None."""
@@ -554,7 +567,7 @@ class UNetEngine(object):
             dgamma, dbeta = self.pview(self.gflat, l, 'gamma'), self.pview(self.gflat, l, 'beta')
             blocks = L.dc_bn_bwd_blocks(pixels, l.cout)
             k = self._dz_turn
-            self._dz_turn = (k + 1) % 3
+            self._dz_turn = (k + 1) % self.dz_bufs
             dz, scale = _ptr(T['dz'][k]), _ptr(T['dz_scale'], 4 * k)
             L.dc_bn_bwd_reduce(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed,
                                _ptr(T['part_ws']), pixels, l.cout, st)
@@ -572,6 +585,13 @@ class UNetEngine(object):
                 ready.record(main)
             L.dc_reduce_partials(_ptr(T['part_ws2']), blocks, l.cout, 1.0, self.pview(self.gflat, l, 'b'),
                                  _ptr(T['red_tmp']), st)
+            # ---- main stream first: the data gradient feeds the next block ---------------------------------------
+            wpd = _ptr(self.wp_dgrad[l.name]) if dx_ptr is not None else None
+            if dx_ptr is not None and self.wgrad_after_dgrad:
+                launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16)
+                if two:
+                    ready = torch.cuda.Event()
+                    ready.record(main)
             # ---- side stream: weight gradient of this block -------------------------------------------------------
             if two:
                 side.wait_event(ready)
@@ -588,19 +608,8 @@ class UNetEngine(object):
             if two:
                 self._dz_free[k] = torch.cuda.Event()
                 self._dz_free[k].record(side)
-            # ---- main stream: data gradient feeds the next block -------------------------------------------------
-            if dx_ptr is None:
-                return
-            wpd = _ptr(self.wp_dgrad[l.name])
-            if l.kind == 'conv':
-                if f16:
-                    L.dc_conv3x3_dgrad_f16x3(dz, wpd, dx_ptr, scale, N, h, w, l.cin, l.cout, st)
-                else:
-                    L.dc_conv3x3_dgrad(dz, wpd, dx_ptr, N, h, w, l.cin, l.cout, st)
-            elif f16:
-                L.dc_convT2x2_dgrad_f16x3(dz, wpd, dx_ptr, scale, N, h // 2, w // 2, l.cin, l.cout, st)
-            else:
-                L.dc_convT2x2_dgrad(dz, wpd, dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
+            if dx_ptr is not None and not self.wgrad_after_dgrad:
+                launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16)
 
         g, other = T['gA'], T['gB']      # g holds the gradient w.r.t. the current block's output
         for lvl in (0, 1, 2, 3):
