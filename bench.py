@@ -43,7 +43,8 @@ class KernelTimer(object):
     }
     # name -> index of N in the argument list (N, H, W, Cin, Cout follow), and which count is the column count
     SITES = {'dc_conv3x3_fwd': (9, 'cout'), 'dc_conv3x3_dgrad': (3, 'cin'),
-             'dc_conv3x3_fwd_f16x3': (10, 'cout'), 'dc_conv3x3_dgrad_f16x3': (4, 'cin')}
+             'dc_conv3x3_fwd_f16x3': (10, 'cout'), 'dc_conv3x3_dgrad_f16x3': (4, 'cin'),
+             'dc_conv3x3_fwd_bnin_f16x3': (11, 'cout')}
 
     def __init__(self, lib):
         self._lib = lib

@@ -52,6 +52,17 @@ __device__ __forceinline__ float dc_keep_factor(uint64_t seed, uint64_t idx, flo
   return (u >= 1.0f - keep) ? inv_keep : 0.0f;
 }
 
+// Training-mode BatchNorm as ONE fused multiply-add per element: y = fmaf(z, sc, sh) -- the form TensorFlow's
+// tf.nn.batch_normalization (the op behind Keras-2.0.x BatchNormalization on the TF backend) evaluates:
+// inv = gamma*rsqrt(var+eps); y = x*inv + (beta - mean*inv).  Every kernel that applies BN
+// (bn_relu_drop_fwd, the BN-backward ReLU gate, and the consumers that apply BN + ReLU while staging a
+// non-materialised activation) derives (sc, sh) with exactly these two operations, so the ReLU gate is the same
+// bit pattern everywhere.
+__host__ __device__ __forceinline__ void dc_bn_affine(float mu, float is, float ga, float be, float& sc, float& sh) {
+  sc = ga * is;
+  sh = __builtin_fmaf(-mu, sc, be);
+}
+
 // Buffer descriptor from provably wave-uniform inputs (readfirstlane), so hipcc does not wrap every buffer op in a
 // waterfall loop.  Out-of-range offsets read zeros / drop stores (hardware bounds check on num_records = bytes).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t dc_make_rsrc(const void* ptr, unsigned bytes) {

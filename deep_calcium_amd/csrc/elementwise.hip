@@ -11,6 +11,21 @@
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 static const int kMaxBlocks = 2048;
+__device__ __forceinline__ void bn_affine4(const f32x4& mu, const f32x4& is, const f32x4& ga, const f32x4& be, f32x4& sc,
+                                           f32x4& sh) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float a, b;
+    dc_bn_affine(mu[e], is[e], ga[e], be[e], a, b);
+    sc[e] = a; sh[e] = b;
+  }
+}
+__device__ __forceinline__ f32x4 fma4(const f32x4& a, const f32x4& b, const f32x4& c) {
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(a[e], b[e], c[e]);
+  return r;
+}
 
 static int chan_check(const char* fn, int C) {
   DC_REQUIRE(C >= 4 && C <= 1024 && dc_is_pow2(C), DC_EUNSUP, "%s: C=%d must be a power of two in [4,1024]", fn, C);
@@ -26,7 +41,9 @@ static int ew_blocks(long pixels, int C) {
 // BN statistics finalize: one block per channel, double accumulation over all partials.
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int parts, int groups,
                                                                int C, double count, float eps, float momentum,
-                                                               float* mean, float* invstd, float* mmean, float* mvar) {
+                                                               float* mean, float* invstd, float* mmean, float* mvar,
+                                                               const float* gamma, const float* beta, float* scale,
+                                                               float* shift) {
   __shared__ double sh1[256], sh2[256];
   const int c = blockIdx.x, tid = threadIdx.x;
   const int Ct = groups * C;
@@ -47,8 +64,10 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
     const double mu = sh1[0] / count;
     double var = sh2[0] / count - mu * mu;  // population (biased) variance, Keras 2.0.6 / tf.nn.moments
     if (var < 0.0) var = 0.0;
-    mean[c] = (float)mu;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    const float muf = (float)mu, isf = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = muf;
+    invstd[c] = isf;
+    if (scale) dc_bn_affine(muf, isf, gamma[c], beta[c], scale[c], shift[c]);
     if (momentum >= 0.f && mmean && mvar) {
       mmean[c] = (float)((double)mmean[c] * momentum + mu * (1.0 - (double)momentum));
       mvar[c] = (float)((double)mvar[c] * momentum + var * (1.0 - (double)momentum));
@@ -62,8 +81,22 @@ extern "C" int dc_bn_stats_finalize(const float* partial, int parts, int groups,
   DC_REQUIRE(partial && mean && invstd, DC_EINVAL, "dc_bn_stats_finalize: null pointer");
   DC_REQUIRE(parts > 0 && groups > 0 && C > 0 && count > 0, DC_EINVAL, "dc_bn_stats_finalize: bad sizes");
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C,
-                     count, eps, momentum, mean, invstd, moving_mean, moving_var);
+                     count, eps, momentum, mean, invstd, moving_mean, moving_var, (const float*)nullptr,
+                     (const float*)nullptr, (float*)nullptr, (float*)nullptr);
   DC_CHECK_LAUNCH("dc_bn_stats_finalize");
+  return DC_OK;
+}
+
+extern "C" int dc_bn_stats_finalize_affine(const float* partial, int parts, int groups, int C, double count, float eps,
+                                           float momentum, float* mean, float* invstd, float* moving_mean,
+                                           float* moving_var, const float* gamma, const float* beta, float* scale,
+                                           float* shift, dc_stream_t stream) {
+  DC_REQUIRE(partial && mean && invstd && gamma && beta && scale && shift, DC_EINVAL,
+             "dc_bn_stats_finalize_affine: null pointer");
+  DC_REQUIRE(parts > 0 && groups > 0 && C > 0 && count > 0, DC_EINVAL, "dc_bn_stats_finalize_affine: bad sizes");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C,
+                     count, eps, momentum, mean, invstd, moving_mean, moving_var, gamma, beta, scale, shift);
+  DC_CHECK_LAUNCH("dc_bn_stats_finalize_affine");
   return DC_OK;
 }
 
@@ -117,10 +150,12 @@ __global__ __launch_bounds__(256) void bn_relu_drop_fwd_kernel(BnParams p) {
   const f32x4 mu = ld4(p.mean + 4 * q), is = ld4(p.invstd + 4 * q), ga = ld4(p.gamma + 4 * q), be = ld4(p.beta + 4 * q);
   const bool drop = p.keep < 1.f;
   const float inv_keep = drop ? 1.f / p.keep : 1.f;
+  f32x4 sc, sh;
+  bn_affine4(mu, is, ga, be, sc, sh);
   for (long pix = (long)blockIdx.x * PPB + pl; pix < p.pixels; pix += (long)gridDim.x * PPB) {
     const long elem = pix * p.C + 4 * q;
     const f32x4 z = ld4(p.z + elem);
-    f32x4 y = (z - mu) * is * ga + be;
+    f32x4 y = fma4(z, sc, sh);
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
     if (drop) y *= drop_factor(p, elem, inv_keep);
@@ -145,13 +180,13 @@ extern "C" int dc_bn_relu_drop_fwd(const float* z, const float* mean, const floa
 
 // dy = da * [y > 0] * dropfactor ; xhat = (z - mean) * invstd
 __device__ __forceinline__ void bn_bwd_elem(const BnParams& p, long pix, int q, const f32x4& mu, const f32x4& is,
-                                            const f32x4& ga, const f32x4& be, bool drop, float inv_keep, f32x4& dy,
+                                            const f32x4& sc, const f32x4& sh, bool drop, float inv_keep, f32x4& dy,
                                             f32x4& xh) {
   const long elem = pix * p.C + 4 * q;
   const f32x4 z = ld4(p.z + elem);
   const f32x4 da = ld4(p.da + pix * p.da_ld + 4 * q);
   xh = (z - mu) * is;
-  const f32x4 y = xh * ga + be;
+  const f32x4 y = fma4(z, sc, sh);      // the forward's own expression: identical ReLU gate
   dy = da;
   if (drop) dy *= drop_factor(p, elem, inv_keep);
 #pragma unroll
@@ -166,9 +201,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnParams p) {
   const bool drop = p.keep < 1.f;
   const float inv_keep = drop ? 1.f / p.keep : 1.f;
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sc, sh;
+  bn_affine4(mu, is, ga, be, sc, sh);
   for (long pix = (long)blockIdx.x * PPB + pl; pix < p.pixels; pix += (long)gridDim.x * PPB) {
     f32x4 dy, xh;
-    bn_bwd_elem(p, pix, q, mu, is, ga, be, drop, inv_keep, dy, xh);
+    bn_bwd_elem(p, pix, q, mu, is, sc, sh, drop, inv_keep, dy, xh);
     s1 += dy;
     s2 += dy * xh;
   }
@@ -194,9 +231,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnParams p) {
   const float inv_keep = drop ? 1.f / p.keep : 1.f;
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
   float amax = 0.f;
+  f32x4 sc, sh;
+  bn_affine4(mu, is, ga, be, sc, sh);
   for (long pix = (long)blockIdx.x * PPB + pl; pix < p.pixels; pix += (long)gridDim.x * PPB) {
     f32x4 dy, xh;
-    bn_bwd_elem(p, pix, q, mu, is, ga, be, drop, inv_keep, dy, xh);
+    bn_bwd_elem(p, pix, q, mu, is, sc, sh, drop, inv_keep, dy, xh);
     const f32x4 dz = gs * (dy - mdy - xh * mdyx);
     s1 += dz;
     amax = fmaxf(amax, fmaxf(fmaxf(fabsf(dz[0]), fabsf(dz[1])), fmaxf(fabsf(dz[2]), fabsf(dz[3]))));
@@ -486,7 +525,8 @@ __device__ __forceinline__ float round_half_even(float x) { return rintf(x); }  
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ a, const float* __restrict__ kh,
                                                       const float* __restrict__ bh, const uint8_t* __restrict__ y,
                                                       float* __restrict__ p, float* __restrict__ partial, long pixels,
-                                                      int C) {
+                                                      int C, const float* __restrict__ in_sc,
+                                                      const float* __restrict__ in_sh) {
   __shared__ float sm[256][DC_HEAD_SUMS];
   const int C4 = C >> 2, PPB = 256 / C4;
   const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
@@ -494,6 +534,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 #pragma unroll
   for (int e = 0; e < 4; ++e) { k0[e] = kh[(4 * q + e) * 2]; k1[e] = kh[(4 * q + e) * 2 + 1]; }
   const float b0 = bh[0], b1 = bh[1];
+  // in_sc != NULL: `a` holds the PRE-BatchNorm tensor z and the activation relu(fmaf(z, sc, sh)) is formed here
+  const bool bnin = in_sc != nullptr;
+  const f32x4 isc = bnin ? ld4(in_sc + 4 * q) : f32x4{1.f, 1.f, 1.f, 1.f};
+  const f32x4 ish = bnin ? ld4(in_sh + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
   float acc[DC_HEAD_SUMS];
 #pragma unroll
   for (int k = 0; k < DC_HEAD_SUMS; ++k) acc[k] = 0.f;
@@ -502,6 +546,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     const long pix = (it * gridDim.x + blockIdx.x) * PPB + pl;
     const bool ok = pix < pixels;
     f32x4 v = ok ? ld4(a + pix * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bnin) {
+      v = fma4(v, isc, ish);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ok ? fmaxf(v[e], 0.f) : 0.f;
+    }
     float z0 = v[0] * k0[0] + v[1] * k0[1] + v[2] * k0[2] + v[3] * k0[3];
     float z1 = v[0] * k1[0] + v[1] * k1[1] + v[2] * k1[2] + v[3] * k1[3];
     for (int s = 1; s < C4; s <<= 1) { z0 += __shfl_xor(z0, s); z1 += __shfl_xor(z1, s); }
@@ -553,7 +602,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ a, const float* __restrict__ p,
                                                       const uint8_t* __restrict__ y, const float* __restrict__ kh,
                                                       float* __restrict__ da, float* __restrict__ partial, long pixels,
-                                                      int C, int loss_kind, const double* __restrict__ sums) {
+                                                      int C, int loss_kind, const double* __restrict__ sums,
+                                                      const float* __restrict__ in_sc, const float* __restrict__ in_sh) {
   __shared__ f32x4 sm[256];
   __shared__ float sms[256];
   const int C4 = C >> 2, PPB = 256 / C4;
@@ -562,6 +612,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 #pragma unroll
   for (int e = 0; e < 4; ++e) kd[e] = kh[(4 * q + e) * 2 + 1] - kh[(4 * q + e) * 2];
   const float invM = 1.f / (float)pixels;
+  const bool bnin = in_sc != nullptr;
+  const f32x4 isc = bnin ? ld4(in_sc + 4 * q) : f32x4{1.f, 1.f, 1.f, 1.f};
+  const f32x4 ish = bnin ? ld4(in_sh + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
   float I = 0.f, D = 1.f;
   if (loss_kind == 2) { I = (float)sums[5]; D = (float)(sums[4] + sums[8] + 1e-7); }
   if (loss_kind == 3) { I = (float)sums[5]; D = (float)(sums[7] + sums[6] + 1e-7); }
@@ -581,7 +634,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       else dp = -2.f * (yt * D - 2.f * pr * I) * invD2;
       s = dp * pr * (1.f - pr);
     }
-    const f32x4 v = ld4(a + pix * C + 4 * q);
+    f32x4 v = ld4(a + pix * C + 4 * q);
+    if (bnin) {
+      v = fma4(v, isc, ish);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
     st4(da + pix * C + 4 * q, kd * s);
     sa += v * s;
     if (q == 0) ss += s;
@@ -626,26 +684,52 @@ static int head_blocks(long pixels) {
 }
 extern "C" int dc_head_blocks(long pixels) { return head_blocks(pixels); }
 
+static int head_fwd_impl(const float* a, const float* in_sc, const float* in_sh, const float* kh, const float* bh,
+                         const uint8_t* y, float* p, float* partial, long pixels, int C, dc_stream_t stream);
 extern "C" int dc_head_fwd(const float* a, const float* kh, const float* bh, const uint8_t* y, float* p, float* partial,
                            long pixels, int C, dc_stream_t stream) {
+  return head_fwd_impl(a, nullptr, nullptr, kh, bh, y, p, partial, pixels, C, stream);
+}
+extern "C" int dc_head_fwd_bnin(const float* z, const float* in_scale, const float* in_shift, const float* kh,
+                                const float* bh, const uint8_t* y, float* p, float* partial, long pixels, int C,
+                                dc_stream_t stream) {
+  DC_REQUIRE(in_scale && in_shift, DC_EINVAL, "dc_head_fwd_bnin: null scale/shift");
+  return head_fwd_impl(z, in_scale, in_shift, kh, bh, y, p, partial, pixels, C, stream);
+}
+static int head_fwd_impl(const float* a, const float* in_sc, const float* in_sh, const float* kh, const float* bh,
+                         const uint8_t* y, float* p, float* partial, long pixels, int C, dc_stream_t stream) {
   DC_REQUIRE(a && kh && bh && p && pixels > 0, DC_EINVAL, "dc_head_fwd: bad arguments");
   DC_REQUIRE(!y || partial, DC_EINVAL, "dc_head_fwd: y given without a partial buffer");
   int rc = chan_check("dc_head_fwd", C);
   if (rc) return rc;
   DC_REQUIRE(C <= 256, DC_EUNSUP, "dc_head_fwd: C=%d > 256 (the C/4 lanes of a pixel must fit one wave)", C);
   hipLaunchKernelGGL(head_fwd_kernel, dim3(head_blocks(pixels)), dim3(256), 0, (hipStream_t)stream, a, kh, bh, y, p,
-                     y ? partial : nullptr, pixels, C);
+                     y ? partial : nullptr, pixels, C, in_sc, in_sh);
   DC_CHECK_LAUNCH("dc_head_fwd");
   return DC_OK;
 }
+static int head_bwd_impl(const float* a, const float* in_sc, const float* in_sh, const float* p, const uint8_t* y,
+                         const float* kh, float* da, float* partial, int loss_kind, const double* sums, long pixels,
+                         int C, dc_stream_t stream);
 extern "C" int dc_head_bwd(const float* a, const float* p, const uint8_t* y, const float* kh, float* da, float* partial,
                            int loss_kind, const double* sums, long pixels, int C, dc_stream_t stream) {
+  return head_bwd_impl(a, nullptr, nullptr, p, y, kh, da, partial, loss_kind, sums, pixels, C, stream);
+}
+extern "C" int dc_head_bwd_bnin(const float* z, const float* in_scale, const float* in_shift, const float* p,
+                                const uint8_t* y, const float* kh, float* da, float* partial, int loss_kind,
+                                const double* sums, long pixels, int C, dc_stream_t stream) {
+  DC_REQUIRE(in_scale && in_shift, DC_EINVAL, "dc_head_bwd_bnin: null scale/shift");
+  return head_bwd_impl(z, in_scale, in_shift, p, y, kh, da, partial, loss_kind, sums, pixels, C, stream);
+}
+static int head_bwd_impl(const float* a, const float* in_sc, const float* in_sh, const float* p, const uint8_t* y,
+                         const float* kh, float* da, float* partial, int loss_kind, const double* sums, long pixels,
+                         int C, dc_stream_t stream) {
   DC_REQUIRE(a && p && y && kh && da && partial && pixels > 0, DC_EINVAL, "dc_head_bwd: bad arguments");
   DC_REQUIRE(loss_kind >= 0 && loss_kind <= 3 && (loss_kind < 2 || sums), DC_EINVAL, "dc_head_bwd: bad loss_kind / sums");
   int rc = chan_check("dc_head_bwd", C);
   if (rc) return rc;
   hipLaunchKernelGGL(head_bwd_kernel, dim3(head_blocks(pixels)), dim3(256), 0, (hipStream_t)stream, a, p, y, kh, da,
-                     partial, pixels, C, loss_kind, sums);
+                     partial, pixels, C, loss_kind, sums, in_sc, in_sh);
   DC_CHECK_LAUNCH("dc_head_bwd");
   return DC_OK;
 }

@@ -18,5 +18,9 @@ struct IgemmParams {
   int biasMod;    // bias index = n % biasMod
   long outLd;     // pixel stride of the output tensor in floats
   const float* inScale;  // f16x3 only: device scalar (power of two) applied to the input before the fp16 split
+  // f16x3 only: per-input-channel BatchNorm affine of a NON-materialised activation.  `in` then holds the producer's
+  // pre-BN tensor z and the operand relu(fmaf(z, inSc[c], inSh[c])) is formed while it is staged (padding stays 0).
+  const float* inSc;
+  const float* inSh;
 };
 

@@ -94,6 +94,15 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
   const int Cin4 = p.Cin >> 2, Cin8 = (p.Cin + 7) >> 3;
   const float in_scale = p.inScale ? *p.inScale : 1.f;
+  // BatchNorm + ReLU on load (non-materialised input activation): the per-channel (scale, shift) pairs sit behind the
+  // operand images in LDS; the staging pass reads its 4 channels' pairs once per chunk.
+  const bool bnin = p.inSc != nullptr;
+  float* lds_sc = reinterpret_cast<float*>(smem + Cfg::LDS_BYTES);
+  const int Cinp = (p.Cin + 3) & ~3;
+  if (bnin) {
+    for (int i = tid; i < p.Cin; i += 256) { lds_sc[i] = p.inSc[i]; lds_sc[Cinp + i] = p.inSh[i]; }
+    __syncthreads();
+  }
 
   // Staging addresses: one buffer descriptor per operand (this image's activations / the packed weight slabs) and
   // ONE 32-bit byte offset per load, computed once.  Pixels outside the image, columns beyond Ncols and padding
@@ -165,11 +174,25 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
 
   load_chunk(0);
   for (int c0 = 0; c0 < p.Cin; c0 += CK) {
+    f32x4 csc = {1.f, 1.f, 1.f, 1.f}, csh = {0.f, 0.f, 0.f, 0.f};
+    const bool ch_ok = c0 + 4 * a_g < p.Cin;
+    if (bnin && ch_ok) {
+      csc = *reinterpret_cast<const f32x4*>(lds_sc + c0 + 4 * a_g);
+      csh = *reinterpret_cast<const f32x4*>(lds_sc + Cinp + c0 + 4 * a_g);
+    }
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const int pix = a_pix0 + it * A_STEP;
       if (pix < NPIXH) {
         u32x2 hi, lo;
+        if (bnin) {
+          const bool live = ch_ok && !(a_voff[it] >> 31);     // zero padding stays zero
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float y = fmaxf(__builtin_fmaf(ra[it][e], csc[e], csh[e]), 0.f);
+            ra[it][e] = live ? y : 0.f;
+          }
+        }
         split_f16(ra[it], in_scale, hi, lo);
         char* base = smem + ((a_g >> 1) * PS + pix) * 16 + (a_g & 1) * 8;
         *reinterpret_cast<u32x2*>(base) = hi;
@@ -305,14 +328,16 @@ static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 8 * 1024);
     DC_REQUIRE(e == hipSuccess, DC_EHIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
     attr_set = true;
   }
   p.tilesX = dc_cdiv(p.Wout, TW);
   p.tilesY = dc_cdiv(p.Hout, Cfg::TH);
   dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY * dc_cdiv(p.Ncols, Cfg::BN)));
-  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, p);
+  const int lds = Cfg::LDS_BYTES + (p.inSc ? 8 * ((p.Cin + 3) & ~3) : 0);
+  DC_REQUIRE(lds <= Cfg::LDS_BYTES + 8 * 1024, DC_EUNSUP, "%s: Cin=%d too large for the BN-on-load table", name, p.Cin);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   DC_CHECK_LAUNCH(name);
   return DC_OK;
 }
@@ -403,6 +428,40 @@ extern "C" int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const floa
   p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = Cout;
   p.relu = relu; p.scatterCo = 0; p.biasMod = Cout; p.outLd = z_ld;
   return conv3x3_h_launch(p, (hipStream_t)stream);
+}
+
+extern "C" int dc_conv3x3_fwd_bnin_f16x3(const float* z_in, const float* in_sc, const float* in_sh, const void* wp16,
+                                         const float* bias, float* z, long z_ld, float* stats, const float* scale,
+                                         const float* shift, int relu, int N, int H, int W, int Cin, int Cout,
+                                         dc_stream_t stream) {
+  int rc = check_h("dc_conv3x3_fwd_bnin_f16x3", z_in, wp16, z, N, H, W, Cin, Cout);
+  if (rc) return rc;
+  DC_REQUIRE(in_sc && in_sh, DC_EINVAL, "dc_conv3x3_fwd_bnin_f16x3: null input scale/shift");
+  DC_REQUIRE((scale == nullptr) == (shift == nullptr), DC_EINVAL, "dc_conv3x3_fwd_bnin_f16x3: scale and shift go together");
+  DC_REQUIRE(z_ld >= Cout, DC_EINVAL, "dc_conv3x3_fwd_bnin_f16x3: z_ld < Cout");
+  IgemmParams p{};
+  p.in = z_in; p.wp = reinterpret_cast<const float*>(wp16); p.bias = bias; p.out = z; p.stats = stats;
+  p.scale = scale; p.shift = shift; p.inSc = in_sc; p.inSh = in_sh;
+  p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = Cout;
+  p.relu = relu; p.scatterCo = 0; p.biasMod = Cout; p.outLd = z_ld;
+  return conv3x3_h_launch(p, (hipStream_t)stream);
+}
+
+extern "C" int dc_convT2x2_fwd_bnin_f16x3(const float* z_in, const float* in_sc, const float* in_sh, const void* wp16,
+                                          const float* bias, float* z, long z_ld, float* stats, const float* scale,
+                                          const float* shift, int relu, int N, int H, int W, int Cin, int Cout,
+                                          dc_stream_t stream) {
+  int rc = check_h("dc_convT2x2_fwd_bnin_f16x3", z_in, wp16, z, N, H, W, Cin, Cout);
+  if (rc) return rc;
+  DC_REQUIRE(in_sc && in_sh, DC_EINVAL, "dc_convT2x2_fwd_bnin_f16x3: null input scale/shift");
+  DC_REQUIRE((scale == nullptr) == (shift == nullptr), DC_EINVAL, "dc_convT2x2_fwd_bnin_f16x3: scale and shift go together");
+  DC_REQUIRE(z_ld >= Cout, DC_EINVAL, "dc_convT2x2_fwd_bnin_f16x3: z_ld < Cout");
+  IgemmParams p{};
+  p.in = z_in; p.wp = reinterpret_cast<const float*>(wp16); p.bias = bias; p.out = z; p.stats = stats;
+  p.scale = scale; p.shift = shift; p.inSc = in_sc; p.inSh = in_sh;
+  p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = 4 * Cout;
+  p.relu = relu; p.scatterCo = Cout; p.biasMod = Cout; p.outLd = z_ld;
+  return convT_fwd_h_launch(p, (hipStream_t)stream);
 }
 
 extern "C" int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale, int N, int H,

@@ -34,6 +34,11 @@ struct WgradHParams {
   WgradParams g;
   const float* aScale;  // nullable device scalars (powers of two)
   const float* bScale;
+  // BatchNorm + ReLU on load for the operand that is a NON-materialised activation (conv3x3: A = x; convT2x2: B = x):
+  // that operand pointer then holds the producer's pre-BN tensor z and relu(fmaf(z, sc[c], sh[c])) is formed by the
+  // producer waves while they split it (zero padding stays zero).  Nullable, per channel of that operand.
+  const float* aSc; const float* aSh;
+  const float* bSc; const float* bSh;
 };
 
 // WM x WNW waves tile the CTA's (m, n) block, each wave covering 32 m x (32*NBW) n; the remaining
@@ -117,9 +122,21 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
     const int a_rowb = p.Wa * p.Cm * 4, b_rowb = p.Wb * p.Cn * 4;
     const int a_lbase = (a_c4 >> 3) * A_PLANE + (a_c4 & 7) * 8;
     const int b_lbase = 2 * A_IMG + (b_c4 >> 3) * B_PLANE + (b_c4 & 7) * 8;
+    const bool a_bn = hp.aSc != nullptr, b_bn = hp.bSc != nullptr;
+    f32x4 a_sc = {1.f, 1.f, 1.f, 1.f}, a_sh = {0.f, 0.f, 0.f, 0.f}, b_sc = a_sc, b_sh = a_sh;
+    if (a_bn && a_ch_ok) {
+      a_sc = *reinterpret_cast<const f32x4*>(hp.aSc + m0 + 4 * a_c4);
+      a_sh = *reinterpret_cast<const f32x4*>(hp.aSh + m0 + 4 * a_c4);
+    }
+    if (b_bn && b_ch_ok) {
+      b_sc = *reinterpret_cast<const f32x4*>(hp.bSc + n0 + 4 * b_c4);
+      b_sh = *reinterpret_cast<const f32x4*>(hp.bSh + n0 + 4 * b_c4);
+    }
 
     // request tile `tile`'s raw rows (zeros outside the image: rows via the descriptor bounds, columns by compare)
-    auto request = [&](int tile, f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
+    // ma / mb: per-load 'inside the image' bits, needed only when BN + ReLU is applied on load (0 must stay 0)
+    auto request = [&](int tile, f32x4 (&ra)[NA], f32x4 (&rb)[NB], unsigned& ma, unsigned& mb) {
+      ma = 0u; mb = 0u;
       int t = tile;
       const int tx = t % p.tilesX; t /= p.tilesX;
       const int ty = t % p.tilesY;
@@ -138,6 +155,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
         const bool ok = a_ch_ok && pix < APIX && (unsigned)(ax0 + cc) < (unsigned)p.Wa;
         const unsigned off = ok ? (unsigned)(abase + __mul24(r, a_rowb) + __mul24(cc, p.Cm * 4)) : 0x80000000u;
         ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
+        if (a_bn && ok && (unsigned)(ay0 + r) < (unsigned)p.Ha) ma |= 1u << k;
       }
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
@@ -146,15 +164,21 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
         const bool ok = b_ch_ok && pix < BPIX && (px0 + cc) < p.Wb;
         const unsigned off = ok ? (unsigned)(bbase + __mul24(r, b_rowb) + __mul24(cc, p.Cn * 4)) : 0x80000000u;
         rb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
+        if (b_bn && ok && (py0 + r) < p.Hb) mb |= 1u << k;
       }
     };
     // split the requested rows into fp16 hi/lo and write them into image set `set`
-    auto stage = [&](const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], char* set) {
+    auto bn_relu = [&](f32x4 v, const f32x4& sc, const f32x4& sh, bool live) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = live ? fmaxf(__builtin_fmaf(v[e], sc[e], sh[e]), 0.f) : 0.f;
+      return v;
+    };
+    auto stage = [&](const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], unsigned ma, unsigned mb, char* set) {
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         const int pix = st / AC4 + j * (256 / AC4);
         u32x2 hi, lo;
-        split4_f16<A_SCALED>(ra[j], a_scale, hi, lo);
+        split4_f16<A_SCALED>(a_bn ? bn_relu(ra[j], a_sc, a_sh, (ma >> j) & 1u) : ra[j], a_scale, hi, lo);
         if (pix < APIX) {
           *reinterpret_cast<u32x2*>(set + a_lbase + pix * 64) = hi;
           *reinterpret_cast<u32x2*>(set + A_IMG + a_lbase + pix * 64) = lo;
@@ -164,7 +188,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
       for (int k = 0; k < NB; ++k) {
         const int pix = st / BC4 + k * (256 / BC4);
         u32x2 hi, lo;
-        split4_f16<!A_SCALED>(rb[k], b_scale, hi, lo);
+        split4_f16<!A_SCALED>(b_bn ? bn_relu(rb[k], b_sc, b_sh, (mb >> k) & 1u) : rb[k], b_scale, hi, lo);
         if (pix < BPIX) {
           *reinterpret_cast<u32x2*>(set + b_lbase + pix * 64) = hi;
           *reinterpret_cast<u32x2*>(set + B_IMG + b_lbase + pix * 64) = lo;
@@ -175,17 +199,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
     // Two register sets: while tile i+1 is split into LDS, tile i+2's rows are already in flight (a full tile of
     // MFMA time plus the split covers the HBM latency even when a bandwidth-bound kernel shares the chip).
     f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
-    request(tile_beg, ra0, rb0);
-    if (nt > 1) request(tile_beg + 1, ra1, rb1);
-    stage(ra0, rb0, smem);
+    unsigned ma0, mb0, ma1 = 0u, mb1 = 0u;
+    request(tile_beg, ra0, rb0, ma0, mb0);
+    if (nt > 1) request(tile_beg + 1, ra1, rb1, ma1, mb1);
+    stage(ra0, rb0, ma0, mb0, smem);
     __syncthreads();
     for (int i = 0; i < nt; i += 2) {
-      if (i + 2 < nt) request(tile_beg + i + 2, ra0, rb0);
-      if (i + 1 < nt) stage(ra1, rb1, smem + SET);
+      if (i + 2 < nt) request(tile_beg + i + 2, ra0, rb0, ma0, mb0);
+      if (i + 1 < nt) stage(ra1, rb1, ma1, mb1, smem + SET);
       __syncthreads();
       if (i + 1 < nt) {
-        if (i + 3 < nt) request(tile_beg + i + 3, ra1, rb1);
-        if (i + 2 < nt) stage(ra0, rb0, smem);
+        if (i + 3 < nt) request(tile_beg + i + 3, ra1, rb1, ma1, mb1);
+        if (i + 2 < nt) stage(ra0, rb0, ma0, mb0, smem);
         __syncthreads();
       }
     }
@@ -306,7 +331,8 @@ static long wgrad_h_ws(int N, int Hb, int Wb, int Cm, int Cn) {
 
 template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW, bool A_SCALED>
 static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, const float* aScale, const float* bScale,
-                          int N, int Ha, int Wa, int Hb, int Wb, int Cm, int Cn, hipStream_t st, const char* name) {
+                          const float* xSc, const float* xSh, int N, int Ha, int Wa, int Hb, int Wb, int Cm, int Cn,
+                          hipStream_t st, const char* name) {
   using Cfg = WgradHCfg<KH, KW, S, PAD, TW, RW, WM, WNW, NBW>;
   auto kern = wgrad_f16x3_kernel<KH, KW, S, PAD, TW, RW, WM, WNW, NBW, A_SCALED>;
   static bool attr_set = false;
@@ -323,6 +349,9 @@ static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, 
   p.N = N; p.Ha = Ha; p.Wa = Wa; p.Cm = Cm; p.Hb = Hb; p.Wb = Wb; p.Cn = Cn;
   p.tilesX = pl.tilesX; p.tilesY = pl.tilesY; p.tilesTotal = pl.tilesTotal; p.tilesPerSplit = pl.tilesPerSplit;
   hp.aScale = aScale; hp.bScale = bScale;
+  // the activation operand is the UNscaled one: A for conv3x3 (A_SCALED = false), B for convT2x2
+  hp.aSc = A_SCALED ? nullptr : xSc; hp.aSh = A_SCALED ? nullptr : xSh;
+  hp.bSc = A_SCALED ? xSc : nullptr; hp.bSh = A_SCALED ? xSh : nullptr;
   dim3 grid((unsigned)(pl.splits * dc_cdiv(Cm, Cfg::CM) * dc_cdiv(Cn, Cfg::CN)));
   hipLaunchKernelGGL(kern, grid, dim3(512), Cfg::LDS_BYTES, st, hp);
   DC_CHECK_LAUNCH(name);
@@ -365,15 +394,15 @@ static int check_h(const char* fn, const void* a, const void* b, const void* c, 
   return DC_OK;
 }
 
-static int conv_h_impl(const float* x, const float* dz, float* dw, float* ws, const float* dzScale, int N, int H, int W,
-                       int Cin, int Cout, hipStream_t st) {
+static int conv_h_impl(const float* x, const float* xSc, const float* xSh, const float* dz, float* dw, float* ws,
+                       const float* dzScale, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
   const float* none = nullptr;
-  CONV_H_DISPATCH(wgrad_h_launch, , false>(x, dz, dw, ws, none, dzScale, N, H, W, H, W, Cin, Cout, st, "conv3x3_wgrad_f16x3"))
+  CONV_H_DISPATCH(wgrad_h_launch, , false>(x, dz, dw, ws, none, dzScale, xSc, xSh, N, H, W, H, W, Cin, Cout, st, "conv3x3_wgrad_f16x3"))
 }
-static int convT_h_impl(const float* x, const float* dz, float* dw, float* ws, const float* dzScale, int N, int H, int W,
-                        int Cin, int Cout, hipStream_t st) {
+static int convT_h_impl(const float* x, const float* xSc, const float* xSh, const float* dz, float* dw, float* ws,
+                        const float* dzScale, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
   const float* none = nullptr;
-  CONVT_H_DISPATCH(wgrad_h_launch, , true>(dz, x, dw, ws, dzScale, none, N, 2 * H, 2 * W, H, W, Cout, Cin, st, "convT2x2_wgrad_f16x3"))
+  CONVT_H_DISPATCH(wgrad_h_launch, , true>(dz, x, dw, ws, dzScale, none, xSc, xSh, N, 2 * H, 2 * W, H, W, Cout, Cin, st, "convT2x2_wgrad_f16x3"))
 }
 
 // same workspace (dc_*_wgrad_ws_floats) as the fp32 entry points; dz_scale = device scalar from
@@ -386,11 +415,32 @@ extern "C" int dc_conv3x3_wgrad_f16x3(const float* x, const float* dz, float* dw
   }
   int rc = check_h("dc_conv3x3_wgrad_f16x3", x, dz, dw, ws, N, H, W, Cin, Cout);
   if (rc) return rc;
-  return conv_h_impl(x, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
+  return conv_h_impl(x, nullptr, nullptr, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
 }
 extern "C" int dc_convT2x2_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,
                                        int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
   int rc = check_h("dc_convT2x2_wgrad_f16x3", x, dz, dw, ws, N, H, W, Cin, Cout);
   if (rc) return rc;
-  return convT_h_impl(x, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
+  return convT_h_impl(x, nullptr, nullptr, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
+}
+
+// BN + ReLU on load: z_in is the producer's pre-BN tensor, (in_scale_c, in_shift_c) its per-channel training-mode affine
+// (dc_bn_stats_finalize_affine); the layer input relu(fmaf(z, sc, sh)) is never materialised.
+extern "C" int dc_conv3x3_wgrad_bnin_f16x3(const float* z_in, const float* in_sc, const float* in_sh, const float* dz,
+                                           float* dw, float* ws, const float* dz_scale, int N, int H, int W, int Cin,
+                                           int Cout, dc_stream_t stream) {
+  int rc = check_h("dc_conv3x3_wgrad_bnin_f16x3", z_in, dz, dw, ws, N, H, W, Cin, Cout);
+  if (rc) return rc;
+  DC_REQUIRE(in_sc && in_sh && dc_aligned16(in_sc) && dc_aligned16(in_sh), DC_EINVAL,
+             "dc_conv3x3_wgrad_bnin_f16x3: scale/shift must be non-null and 16-byte aligned");
+  return conv_h_impl(z_in, in_sc, in_sh, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
+}
+extern "C" int dc_convT2x2_wgrad_bnin_f16x3(const float* z_in, const float* in_sc, const float* in_sh, const float* dz,
+                                            float* dw, float* ws, const float* dz_scale, int N, int H, int W, int Cin,
+                                            int Cout, dc_stream_t stream) {
+  int rc = check_h("dc_convT2x2_wgrad_bnin_f16x3", z_in, dz, dw, ws, N, H, W, Cin, Cout);
+  if (rc) return rc;
+  DC_REQUIRE(in_sc && in_sh && dc_aligned16(in_sc) && dc_aligned16(in_sh), DC_EINVAL,
+             "dc_convT2x2_wgrad_bnin_f16x3: scale/shift must be non-null and 16-byte aligned");
+  return convT_h_impl(z_in, in_sc, in_sh, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
 }

@@ -77,6 +77,9 @@ class UNetEngine(object):
         self.streams = 1 if os.environ.get('DC_STREAMS', '2') == '1' else 2     # 2: weight gradients on a side stream
         self.wgrad_after_dgrad = os.environ.get('DC_WGRAD_AFTER_DGRAD', '0') == '1'
         self.dz_bufs = int(os.environ.get('DC_DZ_BUFS', '3'))
+        # BN + ReLU on load: activations that only feed a conv / conv-transpose / the head (no dropout, pool or
+        # skip) are never written; their consumers take (z, scale, shift) instead.  f16x3 kernels only.
+        self.bnin = self.mfma == 'f16x3' and os.environ.get('DC_BNIN', '1') == '1'
         self.loss_kind = 0      # 0 binary_crossentropy, 1 weighted_binary_crossentropy, 2 dice_loss, 3 dicesq_loss
         H, W = window_shape
         if H % 16 or W % 16:
@@ -94,6 +97,12 @@ class UNetEngine(object):
         # dropout after the up layer of each level (unet_2d_summary.py:198,204,210,216)
         self.up_drop = {3: 2 * self.drp, 2: 2 * self.drp, 1: 2 * self.drp, 0: self.drp}
         self.by_name = {l.name: l for l in self.layers}
+        nm = []
+        if self.bnin:
+            nm += ['e%da' % i for i in range(4)] + ['ba'] + ['d%da' % i for i in range(4)] + ['d0b']
+            if not self.upsampling:
+                nm += ['bb', 'd3b', 'd2b', 'd1b']          # feed a Conv2DTranspose
+        self.nm = frozenset(n for n in nm if self.by_name[n].drop <= 0.0)
         # ---- flat parameter layout -----------------------------------------------------------------
         off = 0
         soff = 0
@@ -115,13 +124,13 @@ class UNetEngine(object):
         self.vflat = torch.zeros(npad, dtype=torch.float32, device=dev)
         self.sflat = torch.zeros(soff, dtype=torch.float32, device=dev)
         # per-layer batch statistics / folded affine (scale, shift), each [cout]
-        self.bstat = torch.zeros(4 * soff // 2 + 8, dtype=torch.float32, device=dev)
+        self.bstat = torch.zeros(6 * soff // 2 + 8, dtype=torch.float32, device=dev)
         self._stat_off = {}
         o = 0
         for l in self.layers:
             if l.kind != 'head':
-                self._stat_off[l.name] = o   # mean, invstd, scale, shift : 4 * cout
-                o += 4 * l.cout
+                self._stat_off[l.name] = o   # mean, invstd, folded scale, shift, training scale, shift : 6 * cout
+                o += 6 * l.cout
         # packed weights
         self.wp_fwd, self.wp_dgrad = {}, {}
         for l in self.layers:
@@ -229,7 +238,7 @@ class UNetEngine(object):
         return _ptr(self.sflat, l.soff[key])
 
     def stat_ptr(self, l, which):
-        """which: 0 mean, 1 invstd, 2 scale, 3 shift"""
+        """which: 0 mean, 1 invstd, 2 scale, 3 shift (inference fold), 4 scale, 5 shift (training batch statistics)"""
         return _ptr(self.bstat, self._stat_off[l.name] + which * l.cout)
 
     def _stream(self):
@@ -273,21 +282,51 @@ class UNetEngine(object):
                          BN_EPS, self.stat_ptr(l, 2), self.stat_ptr(l, 3), l.cout, st)
         self._fold_dirty = False
 
-    def _conv_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st):
-        if self.mfma == 'f16x3':
+    def _conv_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None):
+        """bnin = (scale_ptr, shift_ptr): x is the producer's pre-BN tensor, BN + ReLU are applied on load."""
+        if bnin is not None:
+            self.L.dc_conv3x3_fwd_bnin_f16x3(x, bnin[0], bnin[1], _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh,
+                                             relu, N, h, w, l.cin, l.cout, st)
+        elif self.mfma == 'f16x3':
             self.L.dc_conv3x3_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu, None,
                                         N, h, w, l.cin, l.cout, st)
         else:
             self.L.dc_conv3x3_fwd(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu,
                                   N, h, w, l.cin, l.cout, st)
 
-    def _convT_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st):
-        if self.mfma == 'f16x3':
+    def _convT_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None):
+        if bnin is not None:
+            self.L.dc_convT2x2_fwd_bnin_f16x3(x, bnin[0], bnin[1], _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc,
+                                              sh, relu, N, h, w, l.cin, l.cout, st)
+        elif self.mfma == 'f16x3':
             self.L.dc_convT2x2_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu, None,
                                          N, h, w, l.cin, l.cout, st)
         else:
             self.L.dc_convT2x2_fwd(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu,
                                    N, h, w, l.cin, l.cout, st)
+
+    def _bnin_src(self, prod, T):
+        """(pre-BN tensor ptr, (scale_ptr, shift_ptr)) if the producer's activation is not materialised, else None."""
+        if prod is None or prod.name not in self.nm:
+            return None
+        return _ptr(T['z_' + prod.name]), (self.stat_ptr(prod, 4), self.stat_ptr(prod, 5))
+
+    def activation(self, name, N):
+        """Post-BN/ReLU/dropout activation of layer `name` from the last forward_train as a torch tensor (debugging /
+        tests): the stored tensor, or -- for a non-materialised layer -- rebuilt from z with torch ops."""
+        l = self.by_name[name]
+        A = self._acts(N)
+        if name in self.nm:
+            z = self._train_bufs(N)['z_' + name]
+            o = self._stat_off[name]
+            sc, sh = self.bstat[o + 4 * l.cout:o + 5 * l.cout], self.bstat[o + 5 * l.cout:o + 6 * l.cout]
+            return torch.relu(torch.addcmul(sh, z, sc))
+        c = l.cout
+        if name.startswith('u'):
+            return A['cat%d' % l.lvl][..., :c]
+        if name.startswith('e') and name.endswith('b'):
+            return A['cat%d' % l.lvl][..., self._cup(l.lvl):]
+        return A[name]
 
     # ---- geometry helpers --------------------------------------------------------------------------------
     def _hw(self, lvl):
@@ -328,24 +367,25 @@ class UNetEngine(object):
         return A
 
     def _plan(self, A):
-        """(layer, input tensor, output tensor, output channel offset, output ld, h, w) in execution order."""
+        """('block', layer, input tensor, output tensor, output channel offset, output ld, h, w, producer layer of the
+        input or None) / ('pool', ...) / ('up', ...) in execution order."""
         plan = []
         nfb = self.nfb
-        prev = None
+        prev, prev_l = None, None
         for lvl in range(5):
             h, w = self._hw(lvl)
             c = nfb << lvl
             tag = 'b' if lvl == 4 else 'e%d' % lvl
             la, lb = self.by_name[tag + 'a'], self.by_name[tag + 'b']
-            plan.append(('block', la, prev, A[tag + 'a'], 0, c, h, w))
+            plan.append(('block', la, prev, A[tag + 'a'], 0, c, h, w, None))
             if lvl < 4:
                 cup = self._cup(lvl)
-                plan.append(('block', lb, A[tag + 'a'], A['cat%d' % lvl], cup, cup + c, h, w))
+                plan.append(('block', lb, A[tag + 'a'], A['cat%d' % lvl], cup, cup + c, h, w, la))
                 plan.append(('pool', lvl, A['cat%d' % lvl], cup, cup + c, h, w))
                 prev = A['pool%d' % lvl]
             else:
-                plan.append(('block', lb, A[tag + 'a'], A['bb'], 0, c, h, w))
-                prev = A['bb']
+                plan.append(('block', lb, A[tag + 'a'], A['bb'], 0, c, h, w, la))
+                prev, prev_l = A['bb'], lb
         for lvl in (3, 2, 1, 0):
             h, w = self._hw(lvl)
             c = nfb << lvl
@@ -353,10 +393,10 @@ class UNetEngine(object):
             if self.upsampling:
                 plan.append(('up', lvl, prev, A['cat%d' % lvl], 3 * c, h, w))    # h,w are OUTPUT dims
             else:
-                plan.append(('block', self.by_name['u%d' % lvl], prev, A['cat%d' % lvl], 0, 2 * c, h, w))   # convT: OUTPUT dims
-            plan.append(('block', la, A['cat%d' % lvl], A['d%da' % lvl], 0, c, h, w))
-            plan.append(('block', lb, A['d%da' % lvl], A['d%db' % lvl], 0, c, h, w))
-            prev = A['d%db' % lvl]
+                plan.append(('block', self.by_name['u%d' % lvl], prev, A['cat%d' % lvl], 0, 2 * c, h, w, prev_l))   # convT: OUTPUT dims
+            plan.append(('block', la, A['cat%d' % lvl], A['d%da' % lvl], 0, c, h, w, None))
+            plan.append(('block', lb, A['d%da' % lvl], A['d%db' % lvl], 0, c, h, w, la))
+            prev, prev_l = A['d%db' % lvl], lb
         return plan
 
     # ---- inference ---------------------------------------------------------------------------------------
@@ -377,7 +417,7 @@ class UNetEngine(object):
                 _, lvl, src, dst, ld, h, w = step
                 L.dc_upsample2x_drop_fwd(_ptr(src), _ptr(dst), ld, None, 1.0, 0, N, h // 2, w // 2, self._cup(lvl), st)
                 continue
-            _, l, src, dst, coff, ld, h, w = step
+            _, l, src, dst, coff, ld, h, w, _prod = step
             sc, sh = self.stat_ptr(l, 2), self.stat_ptr(l, 3)
             if l.kind == 'conv' and l.cin == 1:
                 L.dc_conv3x3_c1_fwd(_ptr(x_dev), self.pview(self.pflat, l, 'k'), None, _ptr(dst, coff), ld, None,
@@ -478,24 +518,34 @@ class UNetEngine(object):
                 mptr, keep, seed = self._up_drop_args(lvl, masks, step_seed)
                 L.dc_upsample2x_drop_fwd(_ptr(src), _ptr(dst), ld, mptr, keep, seed, N, h // 2, w // 2, self._cup(lvl), st)
                 continue
-            _, l, src, dst, coff, ld, h, w = step
+            _, l, src, dst, coff, ld, h, w, prod = step
             z = T['z_' + l.name]
             bias = self.pview(self.pflat, l, 'b')
             stats = _ptr(T['stats_ws'])
             groups = 1
+            bsrc = self._bnin_src(prod, T)
+            xin, bn = (bsrc[0], bsrc[1]) if bsrc is not None else (_ptr(src) if src is not None else None, None)
             if l.kind == 'conv' and l.cin == 1:
                 tiles = L.dc_conv3x3_c1_tiles(N, h, w, l.cout)
                 L.dc_conv3x3_c1_fwd(_ptr(x_dev), self.pview(self.pflat, l, 'k'), bias, _ptr(z), l.cout, stats,
                                     None, None, 0, N, h, w, l.cout, st)
             elif l.kind == 'conv':
                 tiles = L.dc_conv3x3_tiles(N, h, w, l.cout)
-                self._conv_fwd(_ptr(src), l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h, w, st)
+                self._conv_fwd(xin, l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h, w, st, bnin=bn)
             else:
                 tiles = L.dc_convT2x2_tiles(N, h // 2, w // 2, l.cout)
                 groups = 4
-                self._convT_fwd(_ptr(src), l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h // 2, w // 2, st)
+                self._convT_fwd(xin, l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h // 2, w // 2, st, bnin=bn)
             pixels = N * h * w
             mom = l.mom if update_moving else -1.0
+            if l.name in self.nm:
+                # activation not materialised: emit the per-channel affine its consumers apply on load
+                L.dc_bn_stats_finalize_affine(stats, tiles, groups, l.cout, float(pixels), BN_EPS, mom,
+                                              self.stat_ptr(l, 0), self.stat_ptr(l, 1), self.sview(l, 'mmean'),
+                                              self.sview(l, 'mvar'), self.pview(self.pflat, l, 'gamma'),
+                                              self.pview(self.pflat, l, 'beta'), self.stat_ptr(l, 4),
+                                              self.stat_ptr(l, 5), st)
+                continue
             L.dc_bn_stats_finalize(stats, tiles, groups, l.cout, float(pixels), BN_EPS, mom,
                                    self.stat_ptr(l, 0), self.stat_ptr(l, 1), self.sview(l, 'mmean'),
                                    self.sview(l, 'mvar'), st)
@@ -508,8 +558,14 @@ class UNetEngine(object):
         lo = self.by_name['out']
         pixels = N * self.H * self.W
         hb = L.dc_head_blocks(pixels)
-        L.dc_head_fwd(_ptr(A['d0b']), self.pview(self.pflat, lo, 'k'), self.pview(self.pflat, lo, 'b'),
-                      y_dev.data_ptr(), _ptr(A['p']), _ptr(T['part_ws']), pixels, self.nfb, st)
+        hsrc = self._bnin_src(self.by_name['d0b'], T)
+        if hsrc is not None:
+            L.dc_head_fwd_bnin(hsrc[0], hsrc[1][0], hsrc[1][1], self.pview(self.pflat, lo, 'k'),
+                               self.pview(self.pflat, lo, 'b'), y_dev.data_ptr(), _ptr(A['p']), _ptr(T['part_ws']),
+                               pixels, self.nfb, st)
+        else:
+            L.dc_head_fwd(_ptr(A['d0b']), self.pview(self.pflat, lo, 'k'), self.pview(self.pflat, lo, 'b'),
+                          y_dev.data_ptr(), _ptr(A['p']), _ptr(T['part_ws']), pixels, self.nfb, st)
         L.dc_reduce_partials_f64(_ptr(T['part_ws']), hb, 12, T['sums'].data_ptr(), st)
         return A['p']
 
@@ -522,8 +578,14 @@ class UNetEngine(object):
         pixels0 = N * self.H * self.W
         lo = self.by_name['out']
         hb = L.dc_head_blocks(pixels0)
-        L.dc_head_bwd(_ptr(A['d0b']), _ptr(A['p']), y_dev.data_ptr(), self.pview(self.pflat, lo, 'k'),
-                      _ptr(T['gA']), _ptr(T['part_ws']), self.loss_kind, T['sums'].data_ptr(), pixels0, nfb, st)
+        hsrc = self._bnin_src(self.by_name['d0b'], T)
+        if hsrc is not None:
+            L.dc_head_bwd_bnin(hsrc[0], hsrc[1][0], hsrc[1][1], _ptr(A['p']), y_dev.data_ptr(),
+                               self.pview(self.pflat, lo, 'k'), _ptr(T['gA']), _ptr(T['part_ws']), self.loss_kind,
+                               T['sums'].data_ptr(), pixels0, nfb, st)
+        else:
+            L.dc_head_bwd(_ptr(A['d0b']), _ptr(A['p']), y_dev.data_ptr(), self.pview(self.pflat, lo, 'k'),
+                          _ptr(T['gA']), _ptr(T['part_ws']), self.loss_kind, T['sums'].data_ptr(), pixels0, nfb, st)
         L.dc_head_grad_finalize(_ptr(T['part_ws']), hb, nfb, self.pview(self.gflat, lo, 'k'),
                                 self.pview(self.gflat, lo, 'b'), st)
 
@@ -556,8 +618,10 @@ class UNetEngine(object):
             else:
                 L.dc_convT2x2_dgrad(dz, wpd, dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
 
-        def block_bwd(l, x_in, da_ptr, da_ld, dx_ptr):
-            """da (strided) -> grads of l; dx written to dx_ptr (dense [.., cin]) unless None."""
+        def block_bwd(l, x_in, da_ptr, da_ld, dx_ptr, prod=None):
+            """da (strided) -> grads of l; dx written to dx_ptr (dense [.., cin]) unless None.  prod: the layer that
+            produced x_in (its activation may be non-materialised: BN + ReLU on load)."""
+            bsrc = self._bnin_src(prod, T)
             h, w = self._hw(l.lvl)
             pixels = N * h * w
             z = T['z_' + l.name]
@@ -596,7 +660,12 @@ class UNetEngine(object):
             if two:
                 side.wait_event(ready)
             dk, ws = self.pview(self.gflat, l, 'k'), _ptr(T['wgrad_ws'])
-            if l.kind == 'conv':
+            if bsrc is not None and l.kind == 'conv':
+                L.dc_conv3x3_wgrad_bnin_f16x3(bsrc[0], bsrc[1][0], bsrc[1][1], dz, dk, ws, scale, N, h, w, l.cin, l.cout, sw)
+            elif bsrc is not None:
+                L.dc_convT2x2_wgrad_bnin_f16x3(bsrc[0], bsrc[1][0], bsrc[1][1], dz, dk, ws, scale, N, h // 2, w // 2,
+                                               l.cin, l.cout, sw)
+            elif l.kind == 'conv':
                 if f16:
                     L.dc_conv3x3_wgrad_f16x3(x_in, dz, dk, ws, scale, N, h, w, l.cin, l.cout, sw)
                 else:
@@ -615,16 +684,18 @@ class UNetEngine(object):
         for lvl in (0, 1, 2, 3):
             c = nfb << lvl
             cat, dcat = A['cat%d' % lvl], T['dcat%d' % lvl]
-            block_bwd(self.by_name['d%db' % lvl], _ptr(A['d%da' % lvl]), _ptr(g), c, _ptr(other))
+            block_bwd(self.by_name['d%db' % lvl], _ptr(A['d%da' % lvl]), _ptr(g), c, _ptr(other),
+                      prod=self.by_name['d%da' % lvl])
             g, other = other, g
             block_bwd(self.by_name['d%da' % lvl], _ptr(cat), _ptr(g), c, _ptr(dcat))
             x_up = A['bb'] if lvl == 3 else A['d%db' % (lvl + 1)]
+            l_up = self.by_name['bb' if lvl == 3 else 'd%db' % (lvl + 1)]
             if self.upsampling:
                 h, w = self._hw(lvl)
                 mptr, keep, seed = self._up_drop_args(lvl, masks, step_seed)
                 L.dc_upsample2x_drop_bwd(_ptr(dcat), 3 * c, mptr, keep, seed, _ptr(g), N, h // 2, w // 2, 2 * c, st)
             else:
-                block_bwd(self.by_name['u%d' % lvl], _ptr(x_up), _ptr(dcat), 2 * c, _ptr(g))
+                block_bwd(self.by_name['u%d' % lvl], _ptr(x_up), _ptr(dcat), 2 * c, _ptr(g), prod=l_up)
         for lvl in (4, 3, 2, 1, 0):
             c = nfb << lvl
             h, w = self._hw(lvl)
@@ -635,7 +706,7 @@ class UNetEngine(object):
                 L.dc_maxpool2x2_bwd(_ptr(g), A['idx%d' % lvl].data_ptr(), _ptr(T['dcat%d' % lvl], cup), cup + c,
                                     _ptr(other), N, h, w, c, st)
                 g, other = other, g
-            block_bwd(self.by_name[tag + 'b'], _ptr(A[tag + 'a']), _ptr(g), c, _ptr(other))
+            block_bwd(self.by_name[tag + 'b'], _ptr(A[tag + 'a']), _ptr(g), c, _ptr(other), prod=self.by_name[tag + 'a'])
             g, other = other, g
             if lvl == 0:
                 block_bwd(self.by_name['e0a'], _ptr(x_dev), _ptr(g), c, None)

@@ -94,6 +94,36 @@ int dc_conv3x3_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws
 int dc_convT2x2_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,
                             int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 
+/* ---- BatchNorm + ReLU applied ON LOAD ("bnin"): the layer input is a NON-materialised activation -------------
+ * Conv2D -> BatchNormalization -> Activation('relu') (unet_2d_summary.py:164-167) feeding the next Conv2D /
+ * Conv2DTranspose / head with no Dropout or pooling in between never needs its activation in HBM: the consumer
+ * takes the producer's pre-BN tensor z_in plus the per-channel training-mode affine
+ *     in_scale[c] = gamma*invstd,  in_shift[c] = beta - mean*in_scale[c]      (dc_bn_stats_finalize_affine)
+ * and forms relu(fmaf(z, in_scale, in_shift)) while staging the operand; zero padding stays zero.  Saves one HBM
+ * write + one read of the activation per such layer (dc_bn_relu_drop_fwd is skipped).  Other arguments exactly as
+ * in the entry point without _bnin. */
+int dc_bn_stats_finalize_affine(const float* partial, int parts, int groups, int C, double count, float eps,
+                                float momentum, float* mean, float* invstd, float* moving_mean, float* moving_var,
+                                const float* gamma, const float* beta, float* scale, float* shift, dc_stream_t stream);
+int dc_conv3x3_fwd_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const void* wp16,
+                              const float* bias, float* z, long z_ld, float* stats, const float* scale,
+                              const float* shift, int relu, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+int dc_convT2x2_fwd_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const void* wp16,
+                               const float* bias, float* z, long z_ld, float* stats, const float* scale,
+                               const float* shift, int relu, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+int dc_conv3x3_wgrad_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const float* dz,
+                                float* dw, float* ws, const float* dz_scale, int N, int H, int W, int Cin, int Cout,
+                                dc_stream_t stream);
+int dc_convT2x2_wgrad_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const float* dz,
+                                 float* dw, float* ws, const float* dz_scale, int N, int H, int W, int Cin, int Cout,
+                                 dc_stream_t stream);
+int dc_head_fwd_bnin(const float* z_in, const float* in_scale, const float* in_shift, const float* kh, const float* bh,
+                     const uint8_t* y, float* p, float* partial, long pixels, int C, dc_stream_t stream);
+int dc_head_bwd_bnin(const float* z_in, const float* in_scale, const float* in_shift, const float* p, const uint8_t* y,
+                     const float* kh, float* da, float* partial, int loss_kind, const double* sums, long pixels, int C,
+                     dc_stream_t stream);
+
+
 /* ---- Conv2DTranspose(nf, 2, strides=2)  unet_2d_summary.py:156-157 -----------
  * x: [N,H,W,Cin] -> z: [N,2H,2W,Cout].  wp = dc_pack_weights(convT fwd form).
  * stats: float[dc_convT2x2_tiles()][4*Cout][2] (finalize with groups = 4). */

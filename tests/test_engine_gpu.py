@@ -45,18 +45,11 @@ def test_forward_inference_matches_oracle(N, H, W, nfb, mfma):
 def count_relu_flips(eng, N, cache, masks):
     """Elements whose ReLU gate differs between the fp32 path and the float64 oracle (pre-activation within
     fp32 rounding of 0).  Each flip moves one dz element by O(|da|): a legitimate discontinuity, not an error."""
-    A = eng._acts(N)
     flips = 0
     for l in eng.layers:
         if l.kind == 'head':
             continue
-        c = l.cout
-        if l.name.startswith('u'):
-            a = A['cat%d' % l.lvl][..., :c]
-        elif l.name.startswith('e') and l.name.endswith('b'):
-            a = A['cat%d' % l.lvl][..., c:]
-        else:
-            a = A[l.name]
+        a = eng.activation(l.name, N)      # stored, or rebuilt from z for the BN-on-load layers
         gate = a.cpu().numpy() > 0
         ref = cache[l.name][2]
         live = masks[l.name].astype(bool) if l.name in masks else np.ones_like(ref)

@@ -149,6 +149,110 @@ def test_conv3x3_f16x3_fwd_dgrad(dclib, N, H, W, Ci, Co):
     assert rel_err(dx.cpu().numpy(), dx_ref) > 1e-3
 
 
+@pytest.mark.parametrize('N,H,W,Ci,Co', [(2, 32, 32, 32, 64), (1, 64, 64, 64, 32), (2, 16, 16, 128, 128),
+                                         (1, 20, 36, 8, 24), (3, 40, 40, 32, 32), (1, 6, 6, 16, 64)])
+def test_bn_relu_on_load_conv_convT_wgrad_head(dclib, N, H, W, Ci, Co):
+    """"bnin" entry points: the consumer takes the producer's pre-BN tensor z plus the per-channel training affine
+    and forms relu(fmaf(z, sc, sh)) while staging -- results must equal the materialised path (and the oracle),
+    zero padding must stay zero (a shift > 0 would otherwise leak relu(sh) into the border)."""
+    L = dclib
+    rs = np.random.RandomState(N * 77 + H + Ci)
+    zin = rs.standard_normal((N, H, W, Ci)).astype(np.float32) * 2 + 0.5
+    gamma = (rs.random_sample(Ci) + 0.5).astype(np.float32)
+    beta = (rs.standard_normal(Ci) * 0.5 + 0.3).astype(np.float32)           # mostly positive shifts
+    # statistics through the library: partial sums -> finalize_affine (mean, invstd, scale, shift)
+    part = np.stack([zin.reshape(-1, Ci).astype(np.float64).sum(0), (zin.reshape(-1, Ci).astype(np.float64) ** 2).sum(0)], -1)
+    mean, invstd, sc, sh = (torch.empty(Ci, device='cuda') for _ in range(4))
+    L.dc_bn_stats_finalize_affine(dev(part.astype(np.float32)).data_ptr(), 1, 1, Ci, float(N * H * W), 1e-3, -1.0,
+                                  mean.data_ptr(), invstd.data_ptr(), None, None, dev(gamma).data_ptr(),
+                                  dev(beta).data_ptr(), sc.data_ptr(), sh.data_ptr(), None)
+    # the materialised activation from the library's own BN kernel (same affine, same bits)
+    a = torch.empty(N, H, W, Ci, device='cuda')
+    L.dc_bn_relu_drop_fwd(dev(zin).data_ptr(), mean.data_ptr(), invstd.data_ptr(), dev(gamma).data_ptr(),
+                          dev(beta).data_ptr(), None, 1.0, 0, a.data_ptr(), Ci, N * H * W, Ci, None)
+    torch.cuda.synchronize()
+    a_np = a.cpu().numpy()
+    mu64 = zin.reshape(-1, Ci).astype(np.float64).mean(0)
+    var64 = zin.reshape(-1, Ci).astype(np.float64).var(0)
+    a_ref = np.maximum((zin.astype(np.float64) - mu64) / np.sqrt(var64 + 1e-3) * gamma + beta, 0)
+    assert np.abs(a_np - a_ref).max() < 1e-5 * max(1.0, np.abs(a_ref).max())
+    assert (a_np > 0).mean() > 0.3
+
+    # conv3x3 forward
+    K = (rs.standard_normal((3, 3, Ci, Co)) * np.sqrt(2.0 / (9 * Ci))).astype(np.float32)
+    Kd = dev(K)
+    wp = torch.empty(L.dc_pack_weights_f16x3_floats(9, Ci, Co), device='cuda')
+    L.dc_pack_weights_f16x3(Kd.data_ptr(), wp.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
+    z1 = torch.full((N, H, W, Co), float('nan'), device='cuda'); z2 = torch.full_like(z1, float('nan'))
+    L.dc_conv3x3_fwd_f16x3(a.data_ptr(), wp.data_ptr(), None, z1.data_ptr(), Co, None, None, None, 0, None,
+                           N, H, W, Ci, Co, None)
+    L.dc_conv3x3_fwd_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), wp.data_ptr(), None, z2.data_ptr(),
+                                Co, None, None, None, 0, N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z2)                       # same operand bits -> same result bits
+    z_ref = on.conv3x3_fwd(a_ref, K.astype(np.float64), np.zeros(Co))
+    assert rel_err(z2.cpu().numpy(), z_ref) < 2e-5
+
+    # conv3x3 weight gradient
+    dz = (rs.standard_normal((N, H, W, Co)) * 3e-7).astype(np.float32)
+    scl = torch.empty(1, device='cuda')
+    L.dc_pow2_scale_from_absmax(dev(np.array([np.abs(dz).max()], np.float32)).data_ptr(), 1, 1024.0, scl.data_ptr(), None)
+    ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, H, W, Ci, Co), device='cuda')
+    dw1 = torch.full((3, 3, Ci, Co), float('nan'), device='cuda'); dw2 = torch.full_like(dw1, float('nan'))
+    dzd = dev(dz)
+    L.dc_conv3x3_wgrad_f16x3(a.data_ptr(), dzd.data_ptr(), dw1.data_ptr(), ws.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
+    L.dc_conv3x3_wgrad_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), dzd.data_ptr(), dw2.data_ptr(),
+                                  ws.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert torch.equal(dw1, dw2)
+    _, dK_ref, _ = on.conv3x3_bwd(a_ref, K.astype(np.float64), dz.astype(np.float64))
+    assert rel_err(dw2.cpu().numpy(), dK_ref) < 2e-5
+
+    # conv-transpose forward + weight gradient (x is the B operand there)
+    KT = (rs.standard_normal((2, 2, Co, Ci)) * np.sqrt(2.0 / (4 * Ci))).astype(np.float32)     # Keras (kh,kw,out,in)
+    KTd = dev(KT)
+    wpt = torch.empty(L.dc_pack_weights_f16x3_floats(1, Ci, 4 * Co), device='cuda')
+    L.dc_pack_weights_f16x3(KTd.data_ptr(), wpt.data_ptr(), 1, Ci, 4 * Co, 0, 1, Ci, 0, None)
+    t1 = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device='cuda'); t2 = torch.full_like(t1, float('nan'))
+    L.dc_convT2x2_fwd_f16x3(a.data_ptr(), wpt.data_ptr(), None, t1.data_ptr(), Co, None, None, None, 0, None,
+                            N, H, W, Ci, Co, None)
+    L.dc_convT2x2_fwd_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), wpt.data_ptr(), None, t2.data_ptr(),
+                                 Co, None, None, None, 0, N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert torch.equal(t1, t2)
+    assert rel_err(t2.cpu().numpy(), on.convT2x2_fwd(a_ref, KT.astype(np.float64), np.zeros(Co))) < 2e-5
+    dzt = (rs.standard_normal((N, 2 * H, 2 * W, Co)) * 3e-7).astype(np.float32)
+    wst = torch.empty(L.dc_convT2x2_wgrad_ws_floats(N, H, W, Ci, Co), device='cuda')
+    g1 = torch.full((2, 2, Co, Ci), float('nan'), device='cuda'); g2 = torch.full_like(g1, float('nan'))
+    dztd = dev(dzt)
+    L.dc_convT2x2_wgrad_f16x3(a.data_ptr(), dztd.data_ptr(), g1.data_ptr(), wst.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
+    L.dc_convT2x2_wgrad_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), dztd.data_ptr(), g2.data_ptr(),
+                                   wst.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert torch.equal(g1, g2)
+
+    # head (needs a power-of-two channel count)
+    if Ci & (Ci - 1) == 0:
+        pixels = N * H * W
+        kh = (rs.standard_normal((Ci, 2)) * 0.3).astype(np.float32); bh = rs.standard_normal(2).astype(np.float32)
+        y = (rs.random_sample(pixels) < 0.3).astype(np.uint8)
+        hb = L.dc_head_blocks(pixels)
+        p1, p2 = torch.empty(pixels, device='cuda'), torch.empty(pixels, device='cuda')
+        q1, q2 = torch.zeros(hb * 12, device='cuda'), torch.zeros(hb * 12, device='cuda')
+        L.dc_head_fwd(a.data_ptr(), dev(kh).data_ptr(), dev(bh).data_ptr(), dev(y).data_ptr(), p1.data_ptr(), q1.data_ptr(), pixels, Ci, None)
+        L.dc_head_fwd_bnin(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), dev(kh).data_ptr(), dev(bh).data_ptr(),
+                           dev(y).data_ptr(), p2.data_ptr(), q2.data_ptr(), pixels, Ci, None)
+        torch.cuda.synchronize()
+        assert torch.equal(p1, p2) and torch.equal(q1, q2)
+        d1, d2 = torch.empty(pixels, Ci, device='cuda'), torch.empty(pixels, Ci, device='cuda')
+        r1, r2 = torch.zeros(hb * (Ci + 4), device='cuda'), torch.zeros(hb * (Ci + 4), device='cuda')
+        L.dc_head_bwd(a.data_ptr(), p1.data_ptr(), dev(y).data_ptr(), dev(kh).data_ptr(), d1.data_ptr(), r1.data_ptr(), 0, None, pixels, Ci, None)
+        L.dc_head_bwd_bnin(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), p1.data_ptr(), dev(y).data_ptr(),
+                           dev(kh).data_ptr(), d2.data_ptr(), r2.data_ptr(), 0, None, pixels, Ci, None)
+        torch.cuda.synchronize()
+        assert torch.equal(d1, d2) and torch.equal(r1, r2)
+
+
 def test_conv3x3_identity_kernel_kat(dclib):
     """Analytic known-answer: centre-tap identity kernel reproduces the input exactly; a one-hot shifted
     tap reproduces the zero-padded shift (pins 'same' padding + cross-correlation orientation)."""
@@ -335,7 +439,9 @@ def test_batchnorm_relu_dropout_fwd_bwd(dclib, pixels_shape, C, keep):
 
 
 def test_bn_constant_input_kat(dclib):
-    """KAT: constant input => var = 0 => relu(bn(z)) = relu(beta)."""
+    """KAT: constant input => var = 0 => relu(bn(z)) = relu(beta).  BN is applied in tf.nn.batch_normalization's own
+    form  z*inv + (beta - mean*inv),  inv = gamma*rsqrt(var+eps)  (one fma per element), so the result carries one
+    fp32 rounding of mean*inv (= 3.25*31.6 ~ 103 here: ulp/2 = 3.8e-6)."""
     L = dclib
     C, M = 32, 512
     z = np.full((M, C), 3.25, np.float32)
@@ -347,7 +453,7 @@ def test_bn_constant_input_kat(dclib):
     L.dc_bn_relu_drop_fwd(dev(z).data_ptr(), mean.data_ptr(), invstd.data_ptr(), dev(np.ones(C, np.float32)).data_ptr(),
                           dev(beta).data_ptr(), None, 1.0, 0, out.data_ptr(), C, M, C, None)
     torch.cuda.synchronize()
-    assert np.allclose(out.cpu().numpy(), np.maximum(beta, 0)[None].repeat(M, 0), atol=1e-6)
+    assert np.allclose(out.cpu().numpy(), np.maximum(beta, 0)[None].repeat(M, 0), atol=5e-6)
 
 
 def test_dropout_rng_is_reproducible_and_unbiased(dclib):
