@@ -284,6 +284,53 @@ extern "C" int dc_pow2_scale_from_absmax(const float* partial, int n, float targ
   return DC_OK;
 }
 
+// One launch for what follows bn_bwd_apply: block c < C sums column c of dbias_partial[blocks][C] (fixed order, double
+// accumulation -> bit-reproducible); block C turns absmax_partial[blocks] into the power-of-two scale (nullable).
+__global__ __launch_bounds__(256) void bn_bwd_apply_finalize_kernel(const float* __restrict__ dbias_partial,
+                                                                   const float* __restrict__ absmax_partial, int blocks,
+                                                                   int C, float target, float* __restrict__ dbias,
+                                                                   float* __restrict__ scale) {
+  __shared__ double smd[256];
+  __shared__ float smf[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  if (c < C) {
+    double s = 0.0;
+    for (int i = tid; i < blocks; i += 256) s += (double)dbias_partial[(long)i * C + c];
+    smd[tid] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+      if (tid < k) smd[tid] += smd[tid + k];
+      __syncthreads();
+    }
+    if (tid == 0) dbias[c] = (float)smd[0];
+    return;
+  }
+  float m = 0.f;
+  for (int i = tid; i < blocks; i += 256) m = fmaxf(m, absmax_partial[i]);
+  smf[tid] = m;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (tid < k) smf[tid] = fmaxf(smf[tid], smf[tid + k]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    m = smf[0];
+    float e = (m > 0.f && isfinite(m)) ? floorf(log2f(target / m)) : 0.f;
+    e = fminf(fmaxf(e, -100.f), 100.f);
+    scale[0] = exp2f(e);
+  }
+}
+extern "C" int dc_bn_bwd_apply_finalize(const float* dbias_partial, const float* absmax_partial, int blocks, int C,
+                                        float target, float* dbias, float* scale, dc_stream_t stream) {
+  DC_REQUIRE(dbias_partial && dbias && blocks > 0 && C > 0, DC_EINVAL, "dc_bn_bwd_apply_finalize: bad arguments");
+  DC_REQUIRE((absmax_partial == nullptr) == (scale == nullptr) && (!scale || target > 0.f), DC_EINVAL,
+             "dc_bn_bwd_apply_finalize: absmax_partial, scale and target go together");
+  hipLaunchKernelGGL(bn_bwd_apply_finalize_kernel, dim3(C + (scale ? 1 : 0)), dim3(256), 0, (hipStream_t)stream,
+                     dbias_partial, absmax_partial, blocks, C, target, dbias, scale);
+  DC_CHECK_LAUNCH("dc_bn_bwd_apply_finalize");
+  return DC_OK;
+}
+
 extern "C" int dc_bn_bwd_blocks(long pixels, int C) { return ew_blocks(pixels, C); }
 
 extern "C" int dc_bn_bwd_reduce(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,

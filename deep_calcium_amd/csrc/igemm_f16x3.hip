@@ -403,6 +403,46 @@ extern "C" int dc_pack_weights_f16x3(const float* src, void* dst, int taps, int 
   return DC_OK;
 }
 
+// All layers' re-packs in ONE launch (the weights change every optimizer step: 2 packs x 21 layers were 42 launches
+// of ~4 us each).  jobs (device memory): DC_PACK_JOB_LONGS longs per job =
+//   { src pointer, dst pointer, taps, K, Ncols, s_tap, s_k, s_n, flip, first block of the job }, plus one trailing
+//   sentinel entry whose "first block" field is the grid size.
+#define DC_PACK_JOB_LONGS 10
+__global__ void pack_weights_f16x3_batch_kernel(const long* __restrict__ jobs, int njobs) {
+  int j = 0;
+  while (j + 1 < njobs && jobs[(j + 1) * DC_PACK_JOB_LONGS + 9] <= (long)blockIdx.x) ++j;
+  const long* jb = jobs + (long)j * DC_PACK_JOB_LONGS;
+  const float* src = reinterpret_cast<const float*>(jb[0]);
+  _Float16* dst = reinterpret_cast<_Float16*>(jb[1]);
+  const int taps = (int)jb[2], K = (int)jb[3], Ncols = (int)jb[4], flip = (int)jb[8];
+  const long s_tap = jb[5], s_k = jb[6], s_n = jb[7];
+  const int b0 = (int)jb[9], nb = (int)jb[DC_PACK_JOB_LONGS + 9] - b0;
+  const int K8 = (K + 7) >> 3;
+  const long total = (long)taps * K8 * 8 * Ncols;
+  for (long i = (blockIdx.x - b0) * (long)blockDim.x + threadIdx.x; i < total; i += (long)nb * blockDim.x) {
+    const int e = (int)(i & 7);
+    long r = i >> 3;
+    const int n = (int)(r % Ncols); r /= Ncols;
+    const int k8 = (int)(r % K8);
+    const int tap = (int)(r / K8);
+    const int k = k8 * 8 + e;
+    const int ts = flip ? (taps - 1 - tap) : tap;
+    const float x = (k < K) ? src[ts * s_tap + k * s_k + n * s_n] : 0.f;
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    const long slot = ((long)(tap * K8 + k8) * 2) * Ncols + n;
+    dst[slot * 8 + e] = hi;
+    dst[(slot + Ncols) * 8 + e] = lo;
+  }
+}
+extern "C" int dc_pack_weights_f16x3_batch(const long* jobs_dev, int njobs, int total_blocks, dc_stream_t stream) {
+  DC_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, DC_EINVAL, "dc_pack_weights_f16x3_batch: bad arguments");
+  hipLaunchKernelGGL(pack_weights_f16x3_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev,
+                     njobs);
+  DC_CHECK_LAUNCH("dc_pack_weights_f16x3_batch");
+  return DC_OK;
+}
+
 extern "C" long dc_pack_weights_f16x3_floats(int taps, int K, int Ncols) {
   return (long)taps * ((K + 7) / 8) * 8 * Ncols;   // 2 halfs per element = one float's worth of bytes
 }

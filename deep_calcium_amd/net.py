@@ -256,18 +256,32 @@ class UNetEngine(object):
         if not self._packed_dirty:
             return
         L, st = self.L, self._stream()
+        jobs = []
         for l in self.layers:
             if l.name not in self.wp_fwd:
                 continue
             src = self.pview(self.pflat, l, 'k')
             ci, co = l.cin, l.cout
-            pack = L.dc_pack_weights_f16x3 if self.mfma == 'f16x3' else L.dc_pack_weights
             if l.kind == 'conv':
-                pack(src, _ptr(self.wp_fwd[l.name]), 9, ci, co, ci * co, co, 1, 0, st)
-                pack(src, _ptr(self.wp_dgrad[l.name]), 9, co, ci, ci * co, 1, co, 1, st)
+                jobs.append((src, _ptr(self.wp_fwd[l.name]), 9, ci, co, ci * co, co, 1, 0))
+                jobs.append((src, _ptr(self.wp_dgrad[l.name]), 9, co, ci, ci * co, 1, co, 1))
             else:
-                pack(src, _ptr(self.wp_fwd[l.name]), 1, ci, 4 * co, 0, 1, ci, 0, st)
-                pack(src, _ptr(self.wp_dgrad[l.name]), 4, co, ci, co * ci, ci, 1, 0, st)
+                jobs.append((src, _ptr(self.wp_fwd[l.name]), 1, ci, 4 * co, 0, 1, ci, 0))
+                jobs.append((src, _ptr(self.wp_dgrad[l.name]), 4, co, ci, co * ci, ci, 1, 0))
+        if self.mfma == 'f16x3':
+            if getattr(self, '_pack_jobs', None) is None:      # pointers and shapes are fixed: build the table once
+                rows, b = [], 0
+                for j in jobs:
+                    total = j[2] * ((j[3] + 7) // 8) * 8 * j[4]
+                    rows.append(list(j) + [b])
+                    b += max(1, min((total + 255) // 256, 128))
+                rows.append([0] * 9 + [b])
+                self._pack_jobs = (torch.tensor(rows, dtype=torch.int64, device=self.device), len(jobs), b)
+            tab, n, blocks = self._pack_jobs
+            L.dc_pack_weights_f16x3_batch(tab.data_ptr(), n, blocks, st)
+        else:
+            for j in jobs:
+                L.dc_pack_weights(*(j + (st,)))
         self._packed_dirty = False
 
     def refold(self):
@@ -641,14 +655,13 @@ class UNetEngine(object):
             L.dc_bn_bwd_apply(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed, dgamma, dbeta,
                               dz, _ptr(T['part_ws2']), _ptr(T['absmax']), pixels, l.cout, st)
             f16 = self.mfma == 'f16x3'
-            if f16:
-                # exact power-of-two scale that brings max|dz| to [512, 1024] before the fp16 split
-                L.dc_pow2_scale_from_absmax(_ptr(T['absmax']), blocks, 1024.0, scale, st)
+            # one launch: conv-bias gradient (column sums of the dz partials) + -- f16x3 -- the exact power-of-two scale
+            # that brings max|dz| to [512, 1024] before the fp16 split
+            L.dc_bn_bwd_apply_finalize(_ptr(T['part_ws2']), _ptr(T['absmax']) if f16 else None, blocks, l.cout, 1024.0,
+                                       self.pview(self.gflat, l, 'b'), scale if f16 else None, st)
             if two:
                 ready = torch.cuda.Event()
                 ready.record(main)
-            L.dc_reduce_partials(_ptr(T['part_ws2']), blocks, l.cout, 1.0, self.pview(self.gflat, l, 'b'),
-                                 _ptr(T['red_tmp']), st)
             # ---- main stream first: the data gradient feeds the next block ---------------------------------------
             wpd = _ptr(self.wp_dgrad[l.name]) if dx_ptr is not None else None
             if dx_ptr is not None and self.wgrad_after_dgrad:

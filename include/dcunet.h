@@ -77,6 +77,10 @@ int dc_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* ws,
 long dc_pack_weights_f16x3_floats(int taps, int K, int Ncols);
 int dc_pack_weights_f16x3(const float* src, void* dst, int taps, int K, int Ncols,
                           long s_tap, long s_k, long s_n, int flip, dc_stream_t stream);
+/* every layer's dc_pack_weights_f16x3 in ONE launch.  jobs_dev: device array of (njobs + 1) x 10 longs,
+ *   { src pointer, dst pointer, taps, K, Ncols, s_tap, s_k, s_n, flip, first block of the job };
+ * the trailing sentinel entry only carries the grid size (= total_blocks) in its last field. */
+int dc_pack_weights_f16x3_batch(const long* jobs_dev, int njobs, int total_blocks, dc_stream_t stream);
 int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, float* stats,
                          const float* scale, const float* shift, int relu, const float* in_scale,
                          int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
@@ -166,6 +170,10 @@ int dc_bn_bwd_apply(const float* da, long da_ld, const float* z, const float* me
 /* scale[0] = 2^floor(log2(target / max_i partial[i])) (1 for an all-zero tensor): the exact power-of-two input scale
  * of the f16x3 gradient contractions. */
 int dc_pow2_scale_from_absmax(const float* partial, int n, float target, float* scale, dc_stream_t stream);
+/* what follows dc_bn_bwd_apply, in ONE launch: dbias[c] = sum over blocks of dbias_partial[b][c] (fixed order) and,
+ * when absmax_partial / scale are given, scale[0] as dc_pow2_scale_from_absmax(absmax_partial, blocks, target). */
+int dc_bn_bwd_apply_finalize(const float* dbias_partial, const float* absmax_partial, int blocks, int C, float target,
+                             float* dbias, float* scale, dc_stream_t stream);
 
 /* ---- MaxPooling2D(2, strides=2)  :176 ----------------------------------------
  * in strided [N,H,W,C] (in_ld), out dense [N,H/2,W/2,C], idx (nullable) uint8 in {0..3}: FIRST max in
