@@ -445,6 +445,61 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   }
 }
 
+// maxpool backward + the BatchNorm-backward partial sums of the layer whose output was pooled: the routed gradient
+// (+ skip gradient) is da of that layer, so (sum dy, sum dy*xhat) are accumulated while it is written and
+// dc_bn_bwd_reduce's re-read of da is saved.  The channel quad of a thread is loop-invariant (grid stride is a
+// multiple of C/4), partials land as dc_bn_bwd_finalize expects: bn.partial[block][C][2].
+__global__ __launch_bounds__(256) void maxpool_bwd_bnred_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                               const float* __restrict__ skip, long skip_ld,
+                                                               float* __restrict__ dx, int N, int H, int W, BnParams p) {
+  __shared__ f32x4 sm1[256], sm2[256];
+  const int C = p.C, C4 = C >> 2, h2 = H >> 1, w2 = W >> 1, PPB = 256 / C4;
+  const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
+  const f32x4 mu = ld4(p.mean + 4 * q), is = ld4(p.invstd + 4 * q), ga = ld4(p.gamma + 4 * q), be = ld4(p.beta + 4 * q);
+  f32x4 sc, sh;
+  bn_affine4(mu, is, ga, be, sc, sh);
+  const bool drop = p.keep < 1.f;
+  const float inv_keep = drop ? 1.f / p.keep : 1.f;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  const long total = (long)N * h2 * w2 * C4;
+  for (long i = blockIdx.x * 256L + tid; i < total; i += gridDim.x * 256L) {
+    long r = i / C4;
+    const int x = (int)(r % w2); r /= w2;
+    const int y = (int)(r % h2);
+    const long n = r / h2;
+    const f32x4 g = ld4(dy + i * 4);
+    const uchar4 k = *reinterpret_cast<const uchar4*>(idx + i * 4);
+    const uint8_t* kk = reinterpret_cast<const uint8_t*>(&k);
+    const long pix00 = (n * H + 2 * y) * W + 2 * x;
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+      const long pix = pix00 + (pos >> 1) * (long)W + (pos & 1);
+      f32x4 v = skip ? ld4(skip + pix * skip_ld + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += (kk[e] == pos) ? g[e] : 0.f;
+      st4(dx + pix * C + 4 * q, v);
+      const long elem = pix * C + 4 * q;
+      const f32x4 z = ld4(p.z + elem);
+      const f32x4 xh = (z - mu) * is;
+      const f32x4 yv = fma4(z, sc, sh);
+      f32x4 d = v;
+      if (drop) d *= drop_factor(p, elem, inv_keep);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = (yv[e] > 0.f) ? d[e] : 0.f;
+      s1 += d;
+      s2 += d * xh;
+    }
+  }
+  sm1[tid] = s1; sm2[tid] = s2;
+  __syncthreads();
+  if (pl == 0) {
+    for (int k = 1; k < PPB; ++k) { s1 += sm1[k * C4 + q]; s2 += sm2[k * C4 + q]; }
+    float* dst = p.partial + ((long)blockIdx.x * C + 4 * q) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dst[2 * e] = s1[e]; dst[2 * e + 1] = s2[e]; }
+  }
+}
+
 static int pool_check(const char* fn, int N, int H, int W, int C) {
   DC_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, DC_EINVAL, "%s: H and W must be positive and even", fn);
   DC_REQUIRE(C >= 4 && C % 4 == 0, DC_EUNSUP, "%s: C=%d must be a multiple of 4", fn, C);
@@ -470,6 +525,30 @@ extern "C" int dc_maxpool2x2_bwd(const float* dy, const uint8_t* idx, const floa
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, idx, skip, skip_ld, dx, N, H, W, C);
   DC_CHECK_LAUNCH("dc_maxpool2x2_bwd");
+  return DC_OK;
+}
+static int pool_bwd_blocks(int N, int H, int W, int C) {
+  const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+  return (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+}
+extern "C" int dc_maxpool2x2_bwd_blocks(int N, int H, int W, int C) { return pool_bwd_blocks(N, H, W, C); }
+extern "C" int dc_maxpool2x2_bwd_bnred(const float* dy, const uint8_t* idx, const float* skip, long skip_ld, float* dx,
+                                       const float* z, const float* mean, const float* invstd, const float* gamma,
+                                       const float* beta, const uint8_t* mask, float keep, uint64_t seed,
+                                       float* bn_partial, int N, int H, int W, int C, dc_stream_t stream) {
+  DC_REQUIRE(dy && idx && dx && z && mean && invstd && gamma && beta && bn_partial && keep > 0.f, DC_EINVAL,
+             "dc_maxpool2x2_bwd_bnred: bad arguments");
+  DC_REQUIRE(!skip || (skip_ld >= C && skip_ld % 4 == 0), DC_EINVAL, "dc_maxpool2x2_bwd_bnred: bad skip_ld");
+  int rc = pool_check("dc_maxpool2x2_bwd_bnred", N, H, W, C);
+  if (rc) return rc;
+  rc = chan_check("dc_maxpool2x2_bwd_bnred", C);
+  if (rc) return rc;
+  BnParams p{};
+  p.z = z; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.mask = mask; p.keep = keep;
+  p.seed = seed; p.partial = bn_partial; p.C = C;
+  hipLaunchKernelGGL(maxpool_bwd_bnred_kernel, dim3(pool_bwd_blocks(N, H, W, C)), dim3(256), 0, (hipStream_t)stream, dy,
+                     idx, skip, skip_ld, dx, N, H, W, p);
+  DC_CHECK_LAUNCH("dc_maxpool2x2_bwd_bnred");
   return DC_OK;
 }
 
@@ -650,7 +729,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                       const uint8_t* __restrict__ y, const float* __restrict__ kh,
                                                       float* __restrict__ da, float* __restrict__ partial, long pixels,
                                                       int C, int loss_kind, const double* __restrict__ sums,
-                                                      const float* __restrict__ in_sc, const float* __restrict__ in_sh) {
+                                                      const float* __restrict__ in_sc, const float* __restrict__ in_sh,
+                                                      const float* __restrict__ bn_mean,
+                                                      const float* __restrict__ bn_invstd, float* __restrict__ bn_partial) {
   __shared__ f32x4 sm[256];
   __shared__ float sms[256];
   const int C4 = C >> 2, PPB = 256 / C4;
@@ -662,6 +743,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   const bool bnin = in_sc != nullptr;
   const f32x4 isc = bnin ? ld4(in_sc + 4 * q) : f32x4{1.f, 1.f, 1.f, 1.f};
   const f32x4 ish = bnin ? ld4(in_sh + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // bn_partial != NULL (needs bnin): also emit this block's (sum dy, sum dy*xhat) of the producing BatchNorm layer,
+  // dy = da * [relu gate] -- the sums dc_bn_bwd_reduce would otherwise re-read da and z for
+  const bool bnred = bn_partial != nullptr;
+  const f32x4 bmu = bnred ? ld4(bn_mean + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 bis = bnred ? ld4(bn_invstd + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 r1 = {0.f, 0.f, 0.f, 0.f}, r2 = {0.f, 0.f, 0.f, 0.f};
   float I = 0.f, D = 1.f;
   if (loss_kind == 2) { I = (float)sums[5]; D = (float)(sums[4] + sums[8] + 1e-7); }
   if (loss_kind == 3) { I = (float)sums[5]; D = (float)(sums[7] + sums[6] + 1e-7); }
@@ -683,7 +770,17 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     }
     f32x4 v = ld4(a + pix * C + 4 * q);
     if (bnin) {
+      const f32x4 zraw = v;
       v = fma4(v, isc, ish);
+      if (bnred) {
+        const f32x4 xh = (zraw - bmu) * bis;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dy = (v[e] > 0.f) ? kd[e] * s : 0.f;
+          r1[e] += dy;
+          r2[e] += dy * xh[e];
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     }
@@ -702,6 +799,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     float s = 0.f;
     for (int k = 0; k < PPB; ++k) s += sms[k * C4];
     partial[(long)blockIdx.x * (C + 4) + C] = s;
+  }
+  if (bnred) {
+    __shared__ f32x4 sm2[256];
+    __syncthreads();
+    sm[tid] = r1; sm2[tid] = r2;
+    __syncthreads();
+    if (pl == 0) {
+      for (int k = 1; k < PPB; ++k) { r1 += sm[k * C4 + q]; r2 += sm2[k * C4 + q]; }
+      float* dst = bn_partial + ((long)blockIdx.x * C + 4 * q) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dst[2 * e] = r1[e]; dst[2 * e + 1] = r2[e]; }
+    }
   }
 }
 
@@ -757,7 +866,8 @@ static int head_fwd_impl(const float* a, const float* in_sc, const float* in_sh,
 }
 static int head_bwd_impl(const float* a, const float* in_sc, const float* in_sh, const float* p, const uint8_t* y,
                          const float* kh, float* da, float* partial, int loss_kind, const double* sums, long pixels,
-                         int C, dc_stream_t stream);
+                         int C, dc_stream_t stream, const float* bn_mean = nullptr, const float* bn_invstd = nullptr,
+                         float* bn_partial = nullptr);
 extern "C" int dc_head_bwd(const float* a, const float* p, const uint8_t* y, const float* kh, float* da, float* partial,
                            int loss_kind, const double* sums, long pixels, int C, dc_stream_t stream) {
   return head_bwd_impl(a, nullptr, nullptr, p, y, kh, da, partial, loss_kind, sums, pixels, C, stream);
@@ -768,15 +878,23 @@ extern "C" int dc_head_bwd_bnin(const float* z, const float* in_scale, const flo
   DC_REQUIRE(in_scale && in_shift, DC_EINVAL, "dc_head_bwd_bnin: null scale/shift");
   return head_bwd_impl(z, in_scale, in_shift, p, y, kh, da, partial, loss_kind, sums, pixels, C, stream);
 }
+extern "C" int dc_head_bwd_bnin_bnred(const float* z, const float* in_scale, const float* in_shift, const float* p,
+                                      const uint8_t* y, const float* kh, float* da, float* partial, int loss_kind,
+                                      const double* sums, const float* bn_mean, const float* bn_invstd,
+                                      float* bn_partial, long pixels, int C, dc_stream_t stream) {
+  DC_REQUIRE(in_scale && in_shift && bn_mean && bn_invstd && bn_partial, DC_EINVAL, "dc_head_bwd_bnin_bnred: null pointer");
+  return head_bwd_impl(z, in_scale, in_shift, p, y, kh, da, partial, loss_kind, sums, pixels, C, stream, bn_mean,
+                       bn_invstd, bn_partial);
+}
 static int head_bwd_impl(const float* a, const float* in_sc, const float* in_sh, const float* p, const uint8_t* y,
                          const float* kh, float* da, float* partial, int loss_kind, const double* sums, long pixels,
-                         int C, dc_stream_t stream) {
+                         int C, dc_stream_t stream, const float* bn_mean, const float* bn_invstd, float* bn_partial) {
   DC_REQUIRE(a && p && y && kh && da && partial && pixels > 0, DC_EINVAL, "dc_head_bwd: bad arguments");
   DC_REQUIRE(loss_kind >= 0 && loss_kind <= 3 && (loss_kind < 2 || sums), DC_EINVAL, "dc_head_bwd: bad loss_kind / sums");
   int rc = chan_check("dc_head_bwd", C);
   if (rc) return rc;
   hipLaunchKernelGGL(head_bwd_kernel, dim3(head_blocks(pixels)), dim3(256), 0, (hipStream_t)stream, a, p, y, kh, da,
-                     partial, pixels, C, loss_kind, sums, in_sc, in_sh);
+                     partial, pixels, C, loss_kind, sums, in_sc, in_sh, bn_mean, bn_invstd, bn_partial);
   DC_CHECK_LAUNCH("dc_head_bwd");
   return DC_OK;
 }

@@ -80,6 +80,8 @@ class UNetEngine(object):
         # BN + ReLU on load: activations that only feed a conv / conv-transpose / the head (no dropout, pool or
         # skip) are never written; their consumers take (z, scale, shift) instead.  f16x3 kernels only.
         self.bnin = self.mfma == 'f16x3' and os.environ.get('DC_BNIN', '1') == '1'
+        # BatchNorm-backward pass-1 sums emitted by the kernel that produces da (head / max-pool backward)
+        self.bnred = os.environ.get('DC_BNRED', '1') == '1'
         self.loss_kind = 0      # 0 binary_crossentropy, 1 weighted_binary_crossentropy, 2 dice_loss, 3 dicesq_loss
         H, W = window_shape
         if H % 16 or W % 16:
@@ -472,7 +474,10 @@ class UNetEngine(object):
             blocks = L.dc_bn_bwd_blocks(N * h * w, l.cout)
             part_floats = max(part_floats, blocks * l.cout * 2)
         hb = L.dc_head_blocks(N * self.H * self.W)
-        part_floats = max(part_floats, hb * (nfb + 4), hb * 12)
+        part_floats = max(part_floats, hb * (nfb + 4), hb * 12, hb * nfb * 2)
+        for lvl in range(4):
+            h, w = self._hw(lvl)
+            part_floats = max(part_floats, L.dc_maxpool2x2_bwd_blocks(N, h, w, nfb << lvl) * (nfb << lvl) * 2)
         T['stats_ws'] = torch.empty(stats_floats, dtype=torch.float32, device=dev)
         T['part_ws'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['part_ws2'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
@@ -593,7 +598,15 @@ class UNetEngine(object):
         lo = self.by_name['out']
         hb = L.dc_head_blocks(pixels0)
         hsrc = self._bnin_src(self.by_name['d0b'], T)
-        if hsrc is not None:
+        fused_d0b = None          # (partial ptr, rows): BN-backward sums of d0b already produced by the head kernel
+        if hsrc is not None and self.bnred:
+            ld0 = self.by_name['d0b']
+            L.dc_head_bwd_bnin_bnred(hsrc[0], hsrc[1][0], hsrc[1][1], _ptr(A['p']), y_dev.data_ptr(),
+                                     self.pview(self.pflat, lo, 'k'), _ptr(T['gA']), _ptr(T['part_ws']), self.loss_kind,
+                                     T['sums'].data_ptr(), self.stat_ptr(ld0, 0), self.stat_ptr(ld0, 1),
+                                     _ptr(T['part_ws2']), pixels0, nfb, st)
+            fused_d0b = (_ptr(T['part_ws2']), hb)
+        elif hsrc is not None:
             L.dc_head_bwd_bnin(hsrc[0], hsrc[1][0], hsrc[1][1], _ptr(A['p']), y_dev.data_ptr(),
                                self.pview(self.pflat, lo, 'k'), _ptr(T['gA']), _ptr(T['part_ws']), self.loss_kind,
                                T['sums'].data_ptr(), pixels0, nfb, st)
@@ -632,7 +645,7 @@ class UNetEngine(object):
             else:
                 L.dc_convT2x2_dgrad(dz, wpd, dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
 
-        def block_bwd(l, x_in, da_ptr, da_ld, dx_ptr, prod=None):
+        def block_bwd(l, x_in, da_ptr, da_ld, dx_ptr, prod=None, fused=None):
             """da (strided) -> grads of l; dx written to dx_ptr (dense [.., cin]) unless None.  prod: the layer that
             produced x_in (its activation may be non-materialised: BN + ReLU on load)."""
             bsrc = self._bnin_src(prod, T)
@@ -647,9 +660,12 @@ class UNetEngine(object):
             k = self._dz_turn
             self._dz_turn = (k + 1) % self.dz_bufs
             dz, scale = _ptr(T['dz'][k]), _ptr(T['dz_scale'], 4 * k)
-            L.dc_bn_bwd_reduce(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed,
-                               _ptr(T['part_ws']), pixels, l.cout, st)
-            L.dc_bn_bwd_finalize(_ptr(T['part_ws']), blocks, l.cout, dgamma, dbeta, st)
+            if fused is not None:      # pass-1 sums came out of the kernel that wrote da
+                L.dc_bn_bwd_finalize(fused[0], fused[1], l.cout, dgamma, dbeta, st)
+            else:
+                L.dc_bn_bwd_reduce(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed,
+                                   _ptr(T['part_ws']), pixels, l.cout, st)
+                L.dc_bn_bwd_finalize(_ptr(T['part_ws']), blocks, l.cout, dgamma, dbeta, st)
             if two and self._dz_free[k] is not None:
                 main.wait_event(self._dz_free[k])       # the wgrad that last read this dz buffer has finished
             L.dc_bn_bwd_apply(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed, dgamma, dbeta,
@@ -698,7 +714,7 @@ class UNetEngine(object):
             c = nfb << lvl
             cat, dcat = A['cat%d' % lvl], T['dcat%d' % lvl]
             block_bwd(self.by_name['d%db' % lvl], _ptr(A['d%da' % lvl]), _ptr(g), c, _ptr(other),
-                      prod=self.by_name['d%da' % lvl])
+                      prod=self.by_name['d%da' % lvl], fused=fused_d0b if lvl == 0 else None)
             g, other = other, g
             block_bwd(self.by_name['d%da' % lvl], _ptr(cat), _ptr(g), c, _ptr(dcat))
             x_up = A['bb'] if lvl == 3 else A['d%db' % (lvl + 1)]
@@ -716,10 +732,24 @@ class UNetEngine(object):
             if lvl < 4:
                 # g = d(pool output); route through the argmax and add the skip gradient (second half of dcat)
                 cup = self._cup(lvl)
-                L.dc_maxpool2x2_bwd(_ptr(g), A['idx%d' % lvl].data_ptr(), _ptr(T['dcat%d' % lvl], cup), cup + c,
-                                    _ptr(other), N, h, w, c, st)
+                lb = self.by_name[tag + 'b']
+                if self.bnred:
+                    mptr, keep, seed = self._drop_args(lb, masks, step_seed)
+                    L.dc_maxpool2x2_bwd_bnred(_ptr(g), A['idx%d' % lvl].data_ptr(), _ptr(T['dcat%d' % lvl], cup), cup + c,
+                                              _ptr(other), _ptr(T['z_' + lb.name]), self.stat_ptr(lb, 0),
+                                              self.stat_ptr(lb, 1), self.pview(self.pflat, lb, 'gamma'),
+                                              self.pview(self.pflat, lb, 'beta'), mptr, keep, seed,
+                                              _ptr(T['part_ws2']), N, h, w, c, st)
+                    fused_pool = (_ptr(T['part_ws2']), L.dc_maxpool2x2_bwd_blocks(N, h, w, c))
+                else:
+                    L.dc_maxpool2x2_bwd(_ptr(g), A['idx%d' % lvl].data_ptr(), _ptr(T['dcat%d' % lvl], cup), cup + c,
+                                        _ptr(other), N, h, w, c, st)
+                    fused_pool = None
                 g, other = other, g
-            block_bwd(self.by_name[tag + 'b'], _ptr(A[tag + 'a']), _ptr(g), c, _ptr(other), prod=self.by_name[tag + 'a'])
+            else:
+                fused_pool = None
+            block_bwd(self.by_name[tag + 'b'], _ptr(A[tag + 'a']), _ptr(g), c, _ptr(other), prod=self.by_name[tag + 'a'],
+                      fused=fused_pool)
             g, other = other, g
             if lvl == 0:
                 block_bwd(self.by_name['e0a'], _ptr(x_dev), _ptr(g), c, None)

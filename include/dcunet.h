@@ -175,6 +175,22 @@ int dc_pow2_scale_from_absmax(const float* partial, int n, float target, float* 
 int dc_bn_bwd_apply_finalize(const float* dbias_partial, const float* absmax_partial, int blocks, int C, float target,
                              float* dbias, float* scale, dc_stream_t stream);
 
+/* ---- BatchNorm-backward sums fused into the kernel that PRODUCES da ("bnred") -------------------------------
+ * The kernel that writes da of a BatchNorm layer also emits that layer's pass-1 partial sums
+ * bn_partial[blocks][C][2] = (sum dy, sum dy*xhat), dy = da * [relu gate] * dropout, so dc_bn_bwd_reduce (and its
+ * re-read of da and z) is skipped; dc_bn_bwd_finalize(bn_partial, blocks, ...) follows as usual.
+ *   dc_head_bwd_bnin_bnred : blocks = dc_head_blocks(pixels); BN layer = the head's (non-materialised) input layer
+ *   dc_maxpool2x2_bwd_bnred: blocks = dc_maxpool2x2_bwd_blocks(); BN layer = the pooled layer (z dense [N,H,W,C]) */
+int dc_head_bwd_bnin_bnred(const float* z_in, const float* in_scale, const float* in_shift, const float* p,
+                           const uint8_t* y, const float* kh, float* da, float* partial, int loss_kind,
+                           const double* sums, const float* bn_mean, const float* bn_invstd, float* bn_partial,
+                           long pixels, int C, dc_stream_t stream);
+int dc_maxpool2x2_bwd_blocks(int N, int H, int W, int C);
+int dc_maxpool2x2_bwd_bnred(const float* dy, const uint8_t* idx, const float* skip, long skip_ld, float* dx,
+                            const float* z, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, const uint8_t* mask, float keep, uint64_t seed, float* bn_partial,
+                            int N, int H, int W, int C, dc_stream_t stream);
+
 /* ---- MaxPooling2D(2, strides=2)  :176 ----------------------------------------
  * in strided [N,H,W,C] (in_ld), out dense [N,H/2,W/2,C], idx (nullable) uint8 in {0..3}: FIRST max in
  * row-major window order (bit-exact contract). */

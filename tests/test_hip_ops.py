@@ -566,6 +566,78 @@ def test_head_fwd_bwd_metrics(dclib, C, pixels):
         assert np.abs(da.cpu().numpy() - ref).max() < 2e-5 * max(np.abs(ref).max(), 1e-12), name
 
 
+@pytest.mark.parametrize('N,H,W,C,keep', [(2, 16, 16, 32, 1.0), (1, 32, 48, 64, 0.75), (3, 8, 8, 8, 0.5)])
+def test_bnred_sums_from_pool_and_head_backward(dclib, N, H, W, C, keep):
+    """"bnred" entry points: the kernel that writes da also emits the BatchNorm-backward pass-1 sums; after
+    dc_bn_bwd_finalize they must equal what dc_bn_bwd_reduce computes from the da the same kernel wrote."""
+    L = dclib
+    rs = np.random.RandomState(N + H + C)
+    z = rs.standard_normal((N, H, W, C)).astype(np.float32)
+    gamma = (rs.random_sample(C) + 0.5).astype(np.float32); beta = (rs.standard_normal(C) * 0.3).astype(np.float32)
+    mean = z.reshape(-1, C).mean(0).astype(np.float32)
+    invstd = (1 / np.sqrt(z.reshape(-1, C).var(0) + 1e-3)).astype(np.float32)
+    mask = (rs.random_sample(z.shape) < keep).astype(np.uint8) if keep < 1 else None
+    zd, md, isd, gd, bd = dev(z), dev(mean), dev(invstd), dev(gamma), dev(beta)
+    mk = dev(mask).data_ptr() if mask is not None else None
+
+    def finalize(partial, P):
+        dg, db = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+        L.dc_bn_bwd_finalize(partial.data_ptr(), P, C, dg.data_ptr(), db.data_ptr(), None)
+        torch.cuda.synchronize()
+        return dg.cpu().numpy().astype(np.float64), db.cpu().numpy().astype(np.float64)
+
+    # ---- max-pool backward
+    dy = rs.standard_normal((N, H // 2, W // 2, C)).astype(np.float32)
+    idx = rs.randint(0, 4, dy.shape).astype(np.uint8)
+    skip = rs.standard_normal((N, H, W, C + 8)).astype(np.float32)
+    dyd, idd, skd = dev(dy), dev(idx), dev(skip)
+    dx1, dx2 = torch.empty(N, H, W, C, device='cuda'), torch.empty(N, H, W, C, device='cuda')
+    L.dc_maxpool2x2_bwd(dyd.data_ptr(), idd.data_ptr(), skd.data_ptr() + 32, C + 8, dx1.data_ptr(), N, H, W, C, None)
+    P = L.dc_maxpool2x2_bwd_blocks(N, H, W, C)
+    part = torch.full((P * C * 2,), float('nan'), device='cuda')
+    L.dc_maxpool2x2_bwd_bnred(dyd.data_ptr(), idd.data_ptr(), skd.data_ptr() + 32, C + 8, dx2.data_ptr(), zd.data_ptr(),
+                              md.data_ptr(), isd.data_ptr(), gd.data_ptr(), bd.data_ptr(), mk, keep, 0,
+                              part.data_ptr(), N, H, W, C, None)
+    torch.cuda.synchronize()
+    assert torch.equal(dx1, dx2)
+    Pr = L.dc_bn_bwd_blocks(N * H * W, C)
+    part_r = torch.empty(Pr * C * 2, device='cuda')
+    L.dc_bn_bwd_reduce(dx1.data_ptr(), C, zd.data_ptr(), md.data_ptr(), isd.data_ptr(), gd.data_ptr(), bd.data_ptr(), mk,
+                       keep, 0, part_r.data_ptr(), N * H * W, C, None)
+    (dg, db), (dg_r, db_r) = finalize(part, P), finalize(part_r, Pr)
+    tol = 1e-5 * max(1.0, np.abs(dg_r).max(), np.abs(db_r).max())
+    assert np.abs(dg - dg_r).max() < tol and np.abs(db - db_r).max() < tol
+
+    # ---- head backward (BN + ReLU on load, no dropout on the head's input layer)
+    if keep == 1.0:
+        pixels = N * H * W
+        sc, sh = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+        part0 = np.stack([z.reshape(-1, C).astype(np.float64).sum(0), (z.reshape(-1, C).astype(np.float64) ** 2).sum(0)], -1)
+        L.dc_bn_stats_finalize_affine(dev(part0.astype(np.float32)).data_ptr(), 1, 1, C, float(pixels), 1e-3, -1.0,
+                                      md.data_ptr(), isd.data_ptr(), None, None, gd.data_ptr(), bd.data_ptr(),
+                                      sc.data_ptr(), sh.data_ptr(), None)
+        kh = (rs.standard_normal((C, 2)) * 0.3).astype(np.float32)
+        y = (rs.random_sample(pixels) < 0.3).astype(np.uint8)
+        p = rs.random_sample(pixels).astype(np.float32)
+        hb = L.dc_head_blocks(pixels)
+        da1, da2 = torch.empty(pixels, C, device='cuda'), torch.empty(pixels, C, device='cuda')
+        r1, r2 = torch.zeros(hb * (C + 4), device='cuda'), torch.zeros(hb * (C + 4), device='cuda')
+        partb = torch.full((hb * C * 2,), float('nan'), device='cuda')
+        khd, yd, pd = dev(kh), dev(y), dev(p)
+        L.dc_head_bwd_bnin(zd.data_ptr(), sc.data_ptr(), sh.data_ptr(), pd.data_ptr(), yd.data_ptr(), khd.data_ptr(),
+                           da1.data_ptr(), r1.data_ptr(), 0, None, pixels, C, None)
+        L.dc_head_bwd_bnin_bnred(zd.data_ptr(), sc.data_ptr(), sh.data_ptr(), pd.data_ptr(), yd.data_ptr(), khd.data_ptr(),
+                                 da2.data_ptr(), r2.data_ptr(), 0, None, md.data_ptr(), isd.data_ptr(), partb.data_ptr(),
+                                 pixels, C, None)
+        torch.cuda.synchronize()
+        assert torch.equal(da1, da2) and torch.equal(r1, r2)
+        L.dc_bn_bwd_reduce(da1.data_ptr(), C, zd.data_ptr(), md.data_ptr(), isd.data_ptr(), gd.data_ptr(), bd.data_ptr(),
+                           None, 1.0, 0, part_r.data_ptr(), pixels, C, None)
+        (dg, db), (dg_r, db_r) = finalize(partb, hb), finalize(part_r, Pr)
+        tol = 1e-5 * max(1e-6, np.abs(dg_r).max(), np.abs(db_r).max())
+        assert np.abs(dg - dg_r).max() < tol and np.abs(db - db_r).max() < tol
+
+
 def test_adam_keras_form(dclib):
     L = dclib
     rs = np.random.RandomState(0)
