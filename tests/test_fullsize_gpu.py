@@ -1,0 +1,95 @@
+"""Parity at BASELINE.json's FULL size (batch 16 of 512x512, nb_filters_base 32), where the float64 numpy oracle is
+too slow to run whole: size-independent properties + an independent second implementation.
+
+* the split-fp16 path (BN + ReLU on load, fused BN-backward sums, two streams) against the library's own fp32-MFMA
+  path (materialised activations, separate kernels): loss, probabilities and gradients must agree;
+* one image of the batch against the CPU torch oracle (fp64) on the full 512x512 window;
+* batch-independence (image i of a batch-16 forward == the same image alone, bit for bit);
+* bit-reproducibility of the whole train step at full size.
+"""
+import numpy as np
+import pytest
+
+from oracle import unet_numpy as on
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+N, H, W, NFB = 16, 512, 512, 32
+
+
+@pytest.fixture(scope='module')
+def setup():
+    from deep_calcium_amd.net import UNetEngine
+    Wt = on.init_weights(NFB, seed=4242, randomize_bn=True)
+    x, y = on.synthetic_batch(N, H, W)
+    engs = {}
+    for mode in ('f16x3', 'f32'):
+        e = UNetEngine((H, W), nb_filters_base=NFB, prop_dropout_base=0.25, mfma=mode)
+        e.set_weights(Wt)
+        engs[mode] = e
+    yield engs, Wt, torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), x, y
+    engs.clear()
+    torch.cuda.empty_cache()
+
+
+def _masks(seed=5):
+    # explicit dropout masks so that both implementations drop the same elements (uint8 on the device)
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    out = {}
+    for name, rate, lvl in (('e1b', 0.25, 1), ('e2b', 0.5, 2), ('e3b', 0.5, 3), ('u3', 0.5, 3), ('u2', 0.5, 2),
+                            ('u1', 0.5, 1), ('u0', 0.25, 0)):
+        c = NFB << lvl
+        out[name] = (torch.rand((N, H >> lvl, W >> lvl, c), device='cuda', generator=g) >= rate).to(torch.uint8)
+    return out
+
+
+def test_fullsize_train_step_two_implementations_agree(setup):
+    engs, Wt, xd, yd, x, y = setup
+    masks = _masks()
+    res = {}
+    for mode, e in engs.items():
+        p = e.forward_train(xd, yd, masks, update_moving=False).clone()
+        loss = e.read_sums()[0] / (N * H * W)
+        e.backward()
+        torch.cuda.synchronize()
+        res[mode] = (p, loss, e.gflat.clone())
+    pa, la, ga = res['f16x3']
+    pb, lb, gb = res['f32']
+    assert (pa - pb).abs().max().item() < 1e-4
+    assert abs(la - lb) < 1e-5
+    ga, gb = ga.double(), gb.double()
+    cos = (ga @ gb / (ga.norm() * gb.norm())).item()
+    rel = ((ga - gb).norm() / gb.norm()).item()
+    # ReLU-gate flips (pre-activations within fp32 rounding of 0) move single dz elements: rel-L2, not max-abs
+    assert cos > 0.9999 and rel < 2e-2, (cos, rel)
+
+
+def test_fullsize_inference_vs_torch_oracle_and_batch_independence(setup):
+    from oracle.unet_torch import UNetTorch
+    engs, Wt, xd, yd, x, y = setup
+    e = engs['f16x3']
+    p16 = e.forward_infer(xd).clone()
+    for i in (0, 7, 15):
+        p1 = e.forward_infer(xd[i:i + 1].contiguous())
+        assert torch.equal(p1[0], p16[i]), i                 # batch-independent bits
+    ref = UNetTorch(Wt, NFB, dtype=torch.float64, requires_grad=False)
+    with torch.no_grad():
+        p_ref = ref.forward(x[3:4], training=False).detach().numpy()
+    got = p16[3].cpu().numpy()
+    assert np.abs(got - p_ref[0]).max() < 1e-4
+    away = np.abs(p_ref[0] - 0.5) >= 1e-4
+    assert np.array_equal((got > 0.5)[away], (p_ref[0] > 0.5)[away])
+    assert (engs['f32'].forward_infer(xd) - p16).abs().max().item() < 1e-4
+
+
+def test_fullsize_train_step_is_bit_reproducible(setup):
+    engs, Wt, xd, yd, x, y = setup
+    e = engs['f16x3']
+    outs = []
+    for _ in range(2):
+        e.forward_train(xd, yd, None, update_moving=False)          # hash-RNG dropout: same seed, same bits
+        e.backward()
+        torch.cuda.synchronize()
+        outs.append((e.gflat.clone(), e.read_sums().copy()))
+    assert torch.equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
