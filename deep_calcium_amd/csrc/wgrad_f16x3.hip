@@ -360,10 +360,11 @@ static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, 
 }
 
 // conv3x3 (A = x unscaled, B = dz scaled).  <KH,KW,S,PAD, TW, RW, WM, WNW, NBW>: CTA block 32*WM x 32*WNW*NBW.
+// Cin, Cout > 32 (one wave per 32x32 block, WK = 1): 16-wide x 4-row tiles -- the halo'd A tile is 6x18 pixels for 64
+// outputs (1.69x) instead of 4x34 (2.13x) with 32x2 tiles: less L2->LDS traffic, +3.5..5 % measured.
 #define CONV_H_DISPATCH(FN, ...)                                                       \
   if (W <= 8) return FN<3, 3, 1, 1, 8, 8, 2, 2, 1 __VA_ARGS__;                         \
-  if (W <= 16) return FN<3, 3, 1, 1, 16, 4, 2, 2, 1 __VA_ARGS__;                       \
-  if (Cin > 32 && Cout > 32) return FN<3, 3, 1, 1, 32, 2, 2, 2, 1 __VA_ARGS__;         \
+  if (W <= 16 || (Cin > 32 && Cout > 32)) return FN<3, 3, 1, 1, 16, 4, 2, 2, 1 __VA_ARGS__; \
   if (Cin > 32) return FN<3, 3, 1, 1, 32, 2, 2, 1, 1 __VA_ARGS__;                      \
   if (Cout > 32) return FN<3, 3, 1, 1, 32, 2, 1, 2, 1 __VA_ARGS__;                     \
   return FN<3, 3, 1, 1, 32, 2, 1, 1, 1 __VA_ARGS__;
