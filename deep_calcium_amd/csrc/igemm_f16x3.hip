@@ -18,6 +18,7 @@
 //   * activations are split while being written to LDS (v_cvt_pk_f16_f32 x2 + 2 sub per pair);
 //   * weights arrive PRE-split from dc_pack_weights_f16x3 ([tap][K/8][hi|lo][col][8]) and are copied verbatim.
 #include "igemm_common.h"
+#include <type_traits>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -139,19 +140,21 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
     const unsigned a_add = (unsigned)c0 * 4u, b_add = (unsigned)(c0 >> 3) * 2u * (unsigned)p.Ncols * 16u;
     const bool partial = c0 + CK > p.Cin;     // wave-uniform; only the ragged last chunk of Cin % 16 != 0
 #pragma unroll
+    // the chunk's byte offset rides in the scalar soffset operand: no per-load VALU add (an out-of-range voffset
+    // stays out of range: the marker is 2 GiB)
     for (int it = 0; it < NA; ++it) {
-      unsigned off = a_voff[it] + a_add;
+      unsigned off = a_voff[it];
       if (partial && c0 + 4 * a_g >= p.Cin) off = OOB;
-      ra[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0));
+      ra[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, (int)a_add, 0));
     }
 #pragma unroll
     for (int it = 0; it < NBV; ++it) {
-      unsigned off = b_voff[it] + b_add;
+      unsigned off = b_voff[it];
       if (partial) {
         const int row = b_row0 + it * B_STEP;
         if ((c0 >> 3) + ((row >> 1) % G8) >= Cin8) off = OOB;
       }
-      rb[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, off, 0, 0);
+      rb[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, off, (int)b_add, 0);
     }
   };
 
@@ -257,47 +260,63 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   const int ld = (int)p.outLd;
   const int sy = scatter ? 4 * p.Wout * ld : p.Wout * ld;   // floats per output-pixel row step
   const int sx = scatter ? 2 * ld : ld;                     // floats per output-pixel column step
+  // Interior items (every pixel and column of the tile exists: all but the ragged border) take a lean epilogue: no
+  // per-element validity selects, and the per-element address term rides in the scalar soffset operand.
+  const bool interior = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (n0 + BN <= p.Ncols);   // wave-uniform
+  auto epilogue = [&](auto interior_tag) {
+    constexpr bool INT = decltype(interior_tag)::value;
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int n = n0 + (wave_n * NB + nb) * 32 + li;
-    const bool n_ok = n < p.Ncols;
-    const float bv = (p.bias && n_ok) ? p.bias[n % p.biasMod] : 0.f;
-    const float sc = (p.scale && n_ok) ? p.scale[n % p.biasMod] : 1.f;
-    const float sh = (p.shift && n_ok) ? p.shift[n % p.biasMod] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
-    int colterm = n;
-    if (scatter) {
-      const int ab = n / p.scatterCo, o = n - ab * p.scatterCo;
-      colterm = ((ab >> 1) * 2 * p.Wout + (ab & 1)) * ld + o;
-    }
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = n0 + (wave_n * NB + nb) * 32 + li;
+      const bool n_ok = INT || n < p.Ncols;
+      const float bv = (p.bias && n_ok) ? p.bias[n % p.biasMod] : 0.f;
+      const float sc = (p.scale && n_ok) ? p.scale[n % p.biasMod] : 1.f;
+      const float sh = (p.shift && n_ok) ? p.shift[n % p.biasMod] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+      int colterm = n;
+      if (scatter) {
+        const int ab = n / p.scatterCo, o = n - ab * p.scatterCo;
+        colterm = ((ab >> 1) * 2 * p.Wout + (ab & 1)) * ld + o;
+      }
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int mblk = wave_m * MB + mb;                       // wave-uniform
-      const int oyb = oy0 + mblk * RPM, oxb = ox0 + 4 * h;
-      const unsigned base = (unsigned)((oyb * sy + oxb * sx + colterm) * 4);
+      for (int mb = 0; mb < MB; ++mb) {
+        const int mblk = wave_m * MB + mb;                       // wave-uniform
+        const int oyb = oy0 + mblk * RPM, oxb = ox0 + 4 * h;
+        const unsigned base = (unsigned)((oyb * sy + oxb * sx + colterm) * 4);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int mr = (r & 3) + 8 * (r >> 2);                 // compile-time; + 4h stays inside one tile row
-        const int rowc = mr / TW, colc = mr % TW;
-        const bool ok = n_ok && (oyb + rowc) < p.Hout && (oxb + colc) < p.Wout;
-        float v = acc[mb][nb][r] * out_scale + bv;
-        s1 += ok ? v : 0.f;
-        s2 += ok ? v * v : 0.f;
-        if (p.scale) v = v * sc + sh;
-        if (p.relu) v = fmaxf(v, 0.f);
-        const unsigned off = ok ? base + (unsigned)((rowc * sy + colc * sx) * 4) : OOB;   // scalar addend
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, off, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+          const int mr = (r & 3) + 8 * (r >> 2);                 // compile-time; + 4h stays inside one tile row
+          const int rowc = mr / TW, colc = mr % TW;
+          float v = __builtin_fmaf(acc[mb][nb][r], out_scale, bv);
+          if constexpr (INT) {
+            s1 += v;
+            s2 = __builtin_fmaf(v, v, s2);
+            if (p.scale) v = v * sc + sh;
+            if (p.relu) v = fmaxf(v, 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, base,
+                                                  (rowc * sy + colc * sx) * 4, 0);      // scalar addend
+          } else {
+            const bool ok = n_ok && (oyb + rowc) < p.Hout && (oxb + colc) < p.Wout;
+            s1 += ok ? v : 0.f;
+            s2 += ok ? v * v : 0.f;
+            if (p.scale) v = v * sc + sh;
+            if (p.relu) v = fmaxf(v, 0.f);
+            const unsigned off = ok ? base + (unsigned)((rowc * sy + colc * sx) * 4) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, off, 0, 0);
+          }
+        }
+      }
+      if (p.stats) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (h == 0) {
+          red[((wave * NB + nb) * 32 + li) * 2 + 0] = s1;
+          red[((wave * NB + nb) * 32 + li) * 2 + 1] = s2;
+        }
       }
     }
-    if (p.stats) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (h == 0) {
-        red[((wave * NB + nb) * 32 + li) * 2 + 0] = s1;
-        red[((wave * NB + nb) * 32 + li) * 2 + 1] = s2;
-      }
-    }
-  }
+  };
+  if (interior) epilogue(std::true_type{}); else epilogue(std::false_type{});
   if (p.stats) {
     __syncthreads();
     if (tid < Cfg::WAVES_N * NB * 32) {
