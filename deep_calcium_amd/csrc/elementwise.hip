@@ -179,18 +179,22 @@ extern "C" int dc_bn_relu_drop_fwd(const float* z, const float* mean, const floa
 }
 
 // dy = da * [y > 0] * dropfactor ; xhat = (z - mean) * invstd
-__device__ __forceinline__ void bn_bwd_elem(const BnParams& p, long pix, int q, const f32x4& mu, const f32x4& is,
-                                            const f32x4& sc, const f32x4& sh, bool drop, float inv_keep, f32x4& dy,
-                                            f32x4& xh) {
-  const long elem = pix * p.C + 4 * q;
-  const f32x4 z = ld4(p.z + elem);
-  const f32x4 da = ld4(p.da + pix * p.da_ld + 4 * q);
+__device__ __forceinline__ void bn_bwd_math(const BnParams& p, long pix, int q, const f32x4& z, const f32x4& da,
+                                            const f32x4& mu, const f32x4& is, const f32x4& sc, const f32x4& sh,
+                                            bool drop, float inv_keep, f32x4& dy, f32x4& xh) {
   xh = (z - mu) * is;
   const f32x4 y = fma4(z, sc, sh);      // the forward's own expression: identical ReLU gate
   dy = da;
-  if (drop) dy *= drop_factor(p, elem, inv_keep);
+  if (drop) dy *= drop_factor(p, pix * p.C + 4 * q, inv_keep);
 #pragma unroll
   for (int e = 0; e < 4; ++e) dy[e] = (y[e] > 0.f) ? dy[e] : 0.f;
+}
+__device__ __forceinline__ void bn_bwd_elem(const BnParams& p, long pix, int q, const f32x4& mu, const f32x4& is,
+                                            const f32x4& sc, const f32x4& sh, bool drop, float inv_keep, f32x4& dy,
+                                            f32x4& xh) {
+  const f32x4 z = ld4(p.z + pix * p.C + 4 * q);
+  const f32x4 da = ld4(p.da + pix * p.da_ld + 4 * q);
+  bn_bwd_math(p, pix, q, z, da, mu, is, sc, sh, drop, inv_keep, dy, xh);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnParams p) {
@@ -203,12 +207,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnParams p) {
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
   f32x4 sc, sh;
   bn_affine4(mu, is, ga, be, sc, sh);
-  for (long pix = (long)blockIdx.x * PPB + pl; pix < p.pixels; pix += (long)gridDim.x * PPB) {
+  auto finish = [&](long pix, const f32x4& z, const f32x4& da) {
     f32x4 dy, xh;
-    bn_bwd_elem(p, pix, q, mu, is, sc, sh, drop, inv_keep, dy, xh);
+    bn_bwd_math(p, pix, q, z, da, mu, is, sc, sh, drop, inv_keep, dy, xh);
     s1 += dy;
     s2 += dy * xh;
+  };
+  const long stride = (long)gridDim.x * PPB;
+  long pix = (long)blockIdx.x * PPB + pl;
+  for (; pix + stride < p.pixels; pix += 2 * stride) {
+    const long pb = pix + stride;
+    const f32x4 z0 = ld4(p.z + pix * p.C + 4 * q), d0 = ld4(p.da + pix * p.da_ld + 4 * q);
+    const f32x4 z1 = ld4(p.z + pb * p.C + 4 * q), d1 = ld4(p.da + pb * p.da_ld + 4 * q);
+    finish(pix, z0, d0);
+    finish(pb, z1, d1);
   }
+  if (pix < p.pixels) finish(pix, ld4(p.z + pix * p.C + 4 * q), ld4(p.da + pix * p.da_ld + 4 * q));
   sm1[tid] = s1; sm2[tid] = s2;
   __syncthreads();
   if (pl == 0) {
@@ -233,14 +247,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnParams p) {
   float amax = 0.f;
   f32x4 sc, sh;
   bn_affine4(mu, is, ga, be, sc, sh);
-  for (long pix = (long)blockIdx.x * PPB + pl; pix < p.pixels; pix += (long)gridDim.x * PPB) {
+  auto finish = [&](long pix, const f32x4& z, const f32x4& da) {
     f32x4 dy, xh;
-    bn_bwd_elem(p, pix, q, mu, is, sc, sh, drop, inv_keep, dy, xh);
+    bn_bwd_math(p, pix, q, z, da, mu, is, sc, sh, drop, inv_keep, dy, xh);
     const f32x4 dz = gs * (dy - mdy - xh * mdyx);
     s1 += dz;
     amax = fmaxf(amax, fmaxf(fmaxf(fabsf(dz[0]), fabsf(dz[1])), fmaxf(fabsf(dz[2]), fabsf(dz[3]))));
     st4(p.out + pix * p.out_ld + 4 * q, dz);
+  };
+  // two pixels per iteration: four 16-byte loads in flight per lane before the first use
+  const long stride = (long)gridDim.x * PPB;
+  long pix = (long)blockIdx.x * PPB + pl;
+  for (; pix + stride < p.pixels; pix += 2 * stride) {
+    const long pb = pix + stride;
+    const f32x4 z0 = ld4(p.z + pix * p.C + 4 * q), d0 = ld4(p.da + pix * p.da_ld + 4 * q);
+    const f32x4 z1 = ld4(p.z + pb * p.C + 4 * q), d1 = ld4(p.da + pb * p.da_ld + 4 * q);
+    finish(pix, z0, d0);
+    finish(pb, z1, d1);
   }
+  if (pix < p.pixels) finish(pix, ld4(p.z + pix * p.C + 4 * q), ld4(p.da + pix * p.da_ld + 4 * q));
   if (p.partial) {
     sm1[tid] = s1;
     __syncthreads();
