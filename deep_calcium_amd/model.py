@@ -269,15 +269,26 @@ class Model(object):
             raise RuntimeError('compile() the model first')
         eng = self.engine
         eng.forward_train(xd, yd, masks)
-        eng.backward()
         world = parallel.world_size()
+        # The loss / metric sums are complete once the forward's head kernel has run: their (all-reduced) copy goes to
+        # pinned host memory right away and the host only waits for THAT copy -- backward and Adam of this step are still
+        # executing when the call returns, so the next step's launches queue up behind them with no idle gap.
         sums = eng._train_bufs(xd.shape[0])['sums']
         if world > 1:
-            parallel.all_reduce_sum(eng.gflat)
+            sums = sums.clone()              # the backward of the dice losses reads the rank-local sums
             parallel.all_reduce_sum(sums)
+        if getattr(self, '_sums_host', None) is None:
+            self._sums_host = torch.empty(sums.shape, dtype=sums.dtype).pin_memory()
+        self._sums_host.copy_(sums, non_blocking=True)
+        copied = torch.cuda.Event()
+        copied.record()
+        eng.backward()
+        if world > 1:
+            parallel.all_reduce_sum(eng.gflat)
         o = self.optimizer
         eng.adam_step(o.lr, o.beta_1, o.beta_2, o.epsilon, grad_scale=1.0 / world)
-        m = metrics_from_sums(sums.cpu().numpy(), float(world * xd.shape[0] * xd.shape[1] * xd.shape[2]), self.loss)
+        copied.synchronize()
+        m = metrics_from_sums(self._sums_host.numpy().copy(), float(world * xd.shape[0] * xd.shape[1] * xd.shape[2]), self.loss)
         return [m[k] for k in self.metrics_names]
 
     def fit_generator(self, generator, steps_per_epoch, epochs=1, verbose=1, callbacks=None, max_queue_size=10,
