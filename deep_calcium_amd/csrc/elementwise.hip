@@ -692,21 +692,30 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   float acc[DC_HEAD_SUMS];
 #pragma unroll
   for (int k = 0; k < DC_HEAD_SUMS; ++k) acc[k] = 0.f;
+  // The C/4 lanes of a pixel share its two logits after the xor-reduce.  Pixels are taken C/4 at a time: lane q keeps
+  // the logits of the q-th one, then EVERY lane runs the softmax / BCE / metric arithmetic (3 exp, 3 log per pixel) for
+  // its own pixel -- C/4 times fewer issues of that transcendental-heavy block than one active lane per pixel.
   const long iters = (pixels + (long)gridDim.x * PPB - 1) / ((long)gridDim.x * PPB);
-  for (long it = 0; it < iters; ++it) {  // uniform trip count: the shuffles below need every lane
-    const long pix = (it * gridDim.x + blockIdx.x) * PPB + pl;
-    const bool ok = pix < pixels;
-    f32x4 v = ok ? ld4(a + pix * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-    if (bnin) {
-      v = fma4(v, isc, ish);
+  for (long it0 = 0; it0 < iters; it0 += C4) {  // uniform trip counts: the shuffles below need every lane
+    float kz0 = 0.f, kz1 = 0.f;
+    long kpix = pixels;                           // "no pixel"
+    for (int j = 0; j < C4; ++j) {
+      const long pix = ((it0 + j) * gridDim.x + blockIdx.x) * PPB + pl;
+      const bool ok = pix < pixels;
+      f32x4 v = ok ? ld4(a + pix * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (bnin) {
+        v = fma4(v, isc, ish);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = ok ? fmaxf(v[e], 0.f) : 0.f;
+        for (int e = 0; e < 4; ++e) v[e] = ok ? fmaxf(v[e], 0.f) : 0.f;
+      }
+      float z0 = v[0] * k0[0] + v[1] * k0[1] + v[2] * k0[2] + v[3] * k0[3];
+      float z1 = v[0] * k1[0] + v[1] * k1[1] + v[2] * k1[2] + v[3] * k1[3];
+      for (int s = 1; s < C4; s <<= 1) { z0 += __shfl_xor(z0, s); z1 += __shfl_xor(z1, s); }
+      if (j == q) { kz0 = z0; kz1 = z1; kpix = pix; }
     }
-    float z0 = v[0] * k0[0] + v[1] * k0[1] + v[2] * k0[2] + v[3] * k0[3];
-    float z1 = v[0] * k1[0] + v[1] * k1[1] + v[2] * k1[2] + v[3] * k1[3];
-    for (int s = 1; s < C4; s <<= 1) { z0 += __shfl_xor(z0, s); z1 += __shfl_xor(z1, s); }
-    if (ok && q == 0) {
-      z0 += b0; z1 += b1;
+    if (kpix < pixels) {
+      const long pix = kpix;
+      const float z0 = kz0 + b0, z1 = kz1 + b1;
       // 2-way softmax, max-subtracted, class 1
       const float m = fmaxf(z0, z1);
       const float e0 = expf(z0 - m), e1 = expf(z1 - m);
@@ -734,7 +743,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   }
   if (partial) {
 #pragma unroll
-    for (int k = 0; k < DC_HEAD_SUMS; ++k) sm[tid][k] = (q == 0) ? acc[k] : 0.f;
+    for (int k = 0; k < DC_HEAD_SUMS; ++k) sm[tid][k] = acc[k];
     __syncthreads();
     if (tid < DC_HEAD_SUMS) {
       double s = 0.0;
