@@ -273,7 +273,7 @@ def test_conv3x3_identity_kernel_kat(dclib):
         assert np.array_equal(z.cpu().numpy(), exp)
 
 
-@pytest.mark.parametrize('N,H,W,Co', [(2, 32, 32, 32), (1, 20, 36, 8), (3, 16, 16, 4)])
+@pytest.mark.parametrize('N,H,W,Co', [(2, 32, 32, 32), (1, 20, 36, 8), (3, 16, 16, 4), (1, 6, 10, 16), (2, 64, 64, 32)])
 def test_conv3x3_c1(dclib, N, H, W, Co):
     L = dclib
     rs = np.random.RandomState(5)
