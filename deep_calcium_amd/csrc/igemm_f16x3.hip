@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   const int n0 = (work - tile_id * nblk) * BN;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
-  const int Cin4 = p.Cin >> 2, Cin8 = (p.Cin + 7) >> 3;
+  const int Cin8 = (p.Cin + 7) >> 3;
   const float in_scale = p.inScale ? *p.inScale : 1.f;
   // BatchNorm + ReLU on load (non-materialised input activation): the per-channel (scale, shift) pairs sit behind the
   // operand images in LDS; the staging pass reads its 4 channels' pairs once per chunk.
