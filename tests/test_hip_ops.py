@@ -54,6 +54,9 @@ CONV_SHAPES = [
     (1, 20, 36, 8, 24),         # ragged: partial tiles, Cin < CK, Cout not a multiple of 32
     (3, 40, 40, 32, 32),        # B32, partial tiles in y
     (1, 6, 6, 16, 64),          # 96^2-window bottleneck size
+    (1, 32, 64, 128, 64),       # deep-layer shape at W > 16: many chunks, interior tiles
+    (2, 40, 40, 144, 96),       # ragged in y, x and columns, Cout % 64 != 0
+    (1, 24, 48, 136, 64),       # partial last chunk (Cin % 16 = 8)
 ]
 
 
@@ -150,7 +153,7 @@ def test_conv3x3_f16x3_fwd_dgrad(dclib, N, H, W, Ci, Co):
 
 
 @pytest.mark.parametrize('N,H,W,Ci,Co', [(2, 32, 32, 32, 64), (1, 64, 64, 64, 32), (2, 16, 16, 128, 128),
-                                         (1, 20, 36, 8, 24), (3, 40, 40, 32, 32), (1, 6, 6, 16, 64)])
+                                         (1, 20, 36, 8, 24), (3, 40, 40, 32, 32), (1, 6, 6, 16, 64), (1, 24, 40, 128, 64)])
 def test_bn_relu_on_load_conv_convT_wgrad_head(dclib, N, H, W, Ci, Co):
     """"bnin" entry points: the consumer takes the producer's pre-BN tensor z plus the per-channel training affine
     and forms relu(fmaf(z, sc, sh)) while staging -- results must equal the materialised path (and the oracle),
