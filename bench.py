@@ -145,6 +145,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='per-GPU batch (default 16 = BASELINE config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--bn', default='local', choices=['local', 'sync'],
+                    help="BatchNorm under data parallelism: per-rank statistics (default) or all-reduced ('sync')")
     ap.add_argument('--mode', default='train', choices=['train', 'infer'],
                     help="'infer' times the forward-only path (BASELINE configs[1]) for information; the contract line is 'train'")
     args = ap.parse_args()
@@ -166,6 +168,7 @@ def main():
     model = Model((H, W), NFB, device=dev)
     model.compile(Adam(0.002), 'binary_crossentropy')
     eng = model.engine
+    eng.bn_mode = args.bn
     parallel.broadcast_params(eng.pflat, eng.sflat)
     # synthetic shard of the global batch, resident in HBM (SURVEY 8d seeds, offset per rank)
     x, y = on.synthetic_batch(B, H, W, seed_x=865 + 1000 * rank, seed_y=866 + 1000 * rank)
@@ -239,7 +242,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'UNet2DS train step (fwd+BCE+bwd+Keras-Adam), batch=%d 512x512 per GPU, nfb=32 '
                                    '(BASELINE.json configs[2]; configs[3] at 8 GPUs)' % B,
-                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'bn': 'local',
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'bn': eng.bn_mode,
                        'contraction': 'fp32 operands split exactly into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 '
                                       'accumulate' if eng.mfma == 'f16x3' else 'fp32 MFMA',
                        'loss': float(vals[0])},

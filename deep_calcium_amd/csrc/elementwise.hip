@@ -100,6 +100,62 @@ extern "C" int dc_bn_stats_finalize_affine(const float* partial, int parts, int 
   return DC_OK;
 }
 
+// ---- synchronised BatchNorm (data-parallel 'sync' mode): the per-channel sums leave the device-local finalize so that
+// they can be all-reduced over the ranks: reduce (partials -> double sums) | all-reduce | finalize from sums.
+__global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __restrict__ partial, int parts, int groups,
+                                                             int C, double* __restrict__ sums) {
+  __shared__ double sh1[256], sh2[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int Ct = groups * C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = tid; i < parts * groups; i += 256) {
+    const int pt = i / groups, g = i - pt * groups;
+    const float* src = partial + ((long)pt * Ct + g * C + c) * 2;
+    s1 += (double)src[0];
+    s2 += (double)src[1];
+  }
+  sh1[tid] = s1; sh2[tid] = s2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { sh1[tid] += sh1[tid + s]; sh2[tid] += sh2[tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) { sums[2 * c] = sh1[0]; sums[2 * c + 1] = sh2[0]; }
+}
+extern "C" int dc_bn_stats_reduce(const float* partial, int parts, int groups, int C, double* sums, dc_stream_t stream) {
+  DC_REQUIRE(partial && sums && parts > 0 && groups > 0 && C > 0, DC_EINVAL, "dc_bn_stats_reduce: bad arguments");
+  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C, sums);
+  DC_CHECK_LAUNCH("dc_bn_stats_reduce");
+  return DC_OK;
+}
+__global__ void bn_stats_finalize_sums_kernel(const double* __restrict__ sums, int C, double count, float eps,
+                                              float momentum, float* mean, float* invstd, float* mmean, float* mvar,
+                                              const float* gamma, const float* beta, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = sums[2 * c] / count;
+  double var = sums[2 * c + 1] / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float muf = (float)mu, isf = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = muf;
+  invstd[c] = isf;
+  if (scale) dc_bn_affine(muf, isf, gamma[c], beta[c], scale[c], shift[c]);
+  if (momentum >= 0.f && mmean && mvar) {
+    mmean[c] = (float)((double)mmean[c] * momentum + mu * (1.0 - (double)momentum));
+    mvar[c] = (float)((double)mvar[c] * momentum + var * (1.0 - (double)momentum));
+  }
+}
+extern "C" int dc_bn_stats_finalize_sums(const double* sums, int C, double count, float eps, float momentum, float* mean,
+                                         float* invstd, float* moving_mean, float* moving_var, const float* gamma,
+                                         const float* beta, float* scale, float* shift, dc_stream_t stream) {
+  DC_REQUIRE(sums && mean && invstd && C > 0 && count > 0, DC_EINVAL, "dc_bn_stats_finalize_sums: bad arguments");
+  DC_REQUIRE(!scale || (gamma && beta && shift), DC_EINVAL, "dc_bn_stats_finalize_sums: scale needs gamma, beta and shift");
+  hipLaunchKernelGGL(bn_stats_finalize_sums_kernel, dim3(dc_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, C,
+                     count, eps, momentum, mean, invstd, moving_mean, moving_var, gamma, beta, scale, shift);
+  DC_CHECK_LAUNCH("dc_bn_stats_finalize_sums");
+  return DC_OK;
+}
+
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mmean, const float* mvar,
                                const float* bias, float eps, float* scale, float* shift, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,6 +185,7 @@ struct BnParams {
   float* partial;
   float* absmax;   // bn_bwd_apply: per-block max |dz| (nullable)
   long pixels; int C;
+  double count;   // elements per channel the statistics were taken over (> pixels in 'sync' data parallelism)
 };
 
 // dropout keep-factor (0 or 1/keep) for the 4 channels of element quad `e4` (element index = pix*C + c)
@@ -238,7 +295,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnParams p) {
   const int C4 = p.C >> 2, PPB = 256 / C4;
   const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
   const f32x4 mu = ld4(p.mean + 4 * q), is = ld4(p.invstd + 4 * q), ga = ld4(p.gamma + 4 * q), be = ld4(p.beta + 4 * q);
-  const float invM = 1.f / (float)p.pixels;
+  const float invM = (float)(1.0 / p.count);
   const f32x4 mdy = ld4(p.dbeta + 4 * q) * invM, mdyx = ld4(p.dgamma + 4 * q) * invM;
   const f32x4 gs = ga * is;
   const bool drop = p.keep < 1.f;
@@ -373,10 +430,29 @@ extern "C" int dc_bn_bwd_reduce(const float* da, long da_ld, const float* z, con
   return DC_OK;
 }
 
+static int bn_bwd_apply_impl(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
+                             const float* dgamma, const float* dbeta, float* dz, float* dbias_partial,
+                             float* absmax_partial, long pixels, double count, int C, dc_stream_t stream);
 extern "C" int dc_bn_bwd_apply(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
                                const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
                                const float* dgamma, const float* dbeta, float* dz, float* dbias_partial,
                                float* absmax_partial, long pixels, int C, dc_stream_t stream) {
+  return bn_bwd_apply_impl(da, da_ld, z, mean, invstd, gamma, beta, mask, keep, seed, dgamma, dbeta, dz, dbias_partial,
+                           absmax_partial, pixels, (double)pixels, C, stream);
+}
+extern "C" int dc_bn_bwd_apply_count(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
+                                     const float* dgamma, const float* dbeta, float* dz, float* dbias_partial,
+                                     float* absmax_partial, long pixels, double count, int C, dc_stream_t stream) {
+  DC_REQUIRE(count >= (double)pixels, DC_EINVAL, "dc_bn_bwd_apply_count: count < pixels");
+  return bn_bwd_apply_impl(da, da_ld, z, mean, invstd, gamma, beta, mask, keep, seed, dgamma, dbeta, dz, dbias_partial,
+                           absmax_partial, pixels, count, C, stream);
+}
+static int bn_bwd_apply_impl(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
+                             const float* dgamma, const float* dbeta, float* dz, float* dbias_partial,
+                             float* absmax_partial, long pixels, double count, int C, dc_stream_t stream) {
   DC_REQUIRE(da && z && mean && invstd && gamma && beta && dgamma && dbeta && dz, DC_EINVAL,
              "dc_bn_bwd_apply: null pointer");
   DC_REQUIRE(pixels > 0 && da_ld >= C && da_ld % 4 == 0 && keep > 0.f, DC_EINVAL, "dc_bn_bwd_apply: bad sizes");
@@ -385,7 +461,7 @@ extern "C" int dc_bn_bwd_apply(const float* da, long da_ld, const float* z, cons
   BnParams p{};
   p.da = da; p.da_ld = da_ld; p.z = z; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
   p.mask = mask; p.keep = keep; p.seed = seed; p.dgamma = dgamma; p.dbeta = dbeta; p.out = dz; p.out_ld = C;
-  p.partial = dbias_partial; p.absmax = absmax_partial; p.pixels = pixels; p.C = C;
+  p.partial = dbias_partial; p.absmax = absmax_partial; p.pixels = pixels; p.C = C; p.count = count;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(pixels, C)), dim3(256), 0, (hipStream_t)stream, p);
   DC_CHECK_LAUNCH("dc_bn_bwd_apply");
   return DC_OK;

@@ -18,6 +18,7 @@ import os
 import numpy as np
 import torch
 
+from . import parallel
 from ._lib import lib, DcunetError
 
 BN_EPS = 1e-3
@@ -69,7 +70,7 @@ def build_layer_table(nfb=32, drp=0.25, upsampling=False):
 
 class UNetEngine(object):
     def __init__(self, window_shape, nb_filters_base=32, prop_dropout_base=0.25, device=None, seed=7535, mfma=None,
-                 upsampling=False):
+                 upsampling=False, bn_mode=None):
         # mfma: 'f16x3' (default; fp32-grade split-fp16 products on the fp16 matrix cores) or 'f32' (fp32 MFMA)
         self.mfma = mfma or os.environ.get('DC_MFMA', 'f16x3')
         if self.mfma not in ('f16x3', 'f32'):
@@ -82,6 +83,13 @@ class UNetEngine(object):
         self.bnin = self.mfma == 'f16x3' and os.environ.get('DC_BNIN', '1') == '1'
         # BatchNorm-backward pass-1 sums emitted by the kernel that produces da (head / max-pool backward)
         self.bnred = os.environ.get('DC_BNRED', '1') == '1'
+        # BatchNorm under batch-sharded data parallelism: 'local' = each rank normalises over its own shard
+        # (standard DP semantics); 'sync' = the per-channel sums are all-reduced in forward and backward, so G ranks x B
+        # images reproduce ONE device's step on the G*B batch
+        bn_mode = bn_mode or os.environ.get('DC_BN_MODE', 'local')
+        if bn_mode not in ('local', 'sync'):
+            raise ValueError("bn_mode must be 'local' or 'sync', got %r" % (bn_mode,))
+        self.bn_mode = bn_mode
         self.loss_kind = 0      # 0 binary_crossentropy, 1 weighted_binary_crossentropy, 2 dice_loss, 3 dicesq_loss
         H, W = window_shape
         if H % 16 or W % 16:
@@ -486,6 +494,7 @@ class UNetEngine(object):
         T['red_tmp'] = torch.empty(32 * 1024, dtype=torch.float32, device=dev)
         T['wgrad_ws'] = torch.empty(ws_floats, dtype=torch.float32, device=dev)
         T['sums'] = torch.zeros(12, dtype=torch.float64, device=dev)
+        T['bn_sums'] = torch.zeros(2 * max(l.cout for l in self.layers if l.kind != 'head'), dtype=torch.float64, device=dev)
         big = N * self.H * self.W * nfb
         # dz rotates over 3 buffers: the weight-gradient kernels run on a side stream and may still be reading the
         # dz of block L while the main stream already produces the dz of block L-1 / L-2
@@ -526,6 +535,8 @@ class UNetEngine(object):
         A, T = self._acts(N), self._train_bufs(N)
         step_seed = self.drop_seed + self.iterations
         self._last = (N, masks, step_seed, x_dev, y_dev)
+        world = parallel.world_size()
+        sync = self.bn_mode == 'sync' and world > 1
         for step in self._plan(A):
             if step[0] == 'pool':
                 _, lvl, src, coff, ld, h, w = step
@@ -557,7 +568,20 @@ class UNetEngine(object):
                 self._convT_fwd(xin, l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h // 2, w // 2, st, bnin=bn)
             pixels = N * h * w
             mom = l.mom if update_moving else -1.0
-            if l.name in self.nm:
+            if sync:
+                # 'sync' BatchNorm: per-channel (sum, sum of squares) -> all-reduce over the ranks -> statistics
+                bs = T['bn_sums'][:2 * l.cout]
+                L.dc_bn_stats_reduce(stats, tiles, groups, l.cout, bs.data_ptr(), st)
+                parallel.all_reduce_sum(bs)
+                nm_l = l.name in self.nm
+                L.dc_bn_stats_finalize_sums(bs.data_ptr(), l.cout, float(world * pixels), BN_EPS, mom,
+                                            self.stat_ptr(l, 0), self.stat_ptr(l, 1), self.sview(l, 'mmean'),
+                                            self.sview(l, 'mvar'), self.pview(self.pflat, l, 'gamma'),
+                                            self.pview(self.pflat, l, 'beta'), self.stat_ptr(l, 4) if nm_l else None,
+                                            self.stat_ptr(l, 5) if nm_l else None, st)
+                if nm_l:
+                    continue
+            elif l.name in self.nm:
                 # activation not materialised: emit the per-channel affine its consumers apply on load
                 L.dc_bn_stats_finalize_affine(stats, tiles, groups, l.cout, float(pixels), BN_EPS, mom,
                                               self.stat_ptr(l, 0), self.stat_ptr(l, 1), self.sview(l, 'mmean'),
@@ -565,9 +589,10 @@ class UNetEngine(object):
                                               self.pview(self.pflat, l, 'beta'), self.stat_ptr(l, 4),
                                               self.stat_ptr(l, 5), st)
                 continue
-            L.dc_bn_stats_finalize(stats, tiles, groups, l.cout, float(pixels), BN_EPS, mom,
-                                   self.stat_ptr(l, 0), self.stat_ptr(l, 1), self.sview(l, 'mmean'),
-                                   self.sview(l, 'mvar'), st)
+            if not sync:
+                L.dc_bn_stats_finalize(stats, tiles, groups, l.cout, float(pixels), BN_EPS, mom,
+                                       self.stat_ptr(l, 0), self.stat_ptr(l, 1), self.sview(l, 'mmean'),
+                                       self.sview(l, 'mvar'), st)
             mptr, keep, seed = self._drop_args(l, masks, step_seed)
             L.dc_bn_relu_drop_fwd(_ptr(z), self.stat_ptr(l, 0), self.stat_ptr(l, 1),
                                   self.pview(self.pflat, l, 'gamma'), self.pview(self.pflat, l, 'beta'),
@@ -645,6 +670,9 @@ class UNetEngine(object):
             else:
                 L.dc_convT2x2_dgrad(dz, wpd, dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
 
+        world = parallel.world_size()
+        sync = self.bn_mode == 'sync' and world > 1
+
         def block_bwd(l, x_in, da_ptr, da_ld, dx_ptr, prod=None, fused=None):
             """da (strided) -> grads of l; dx written to dx_ptr (dense [.., cin]) unless None.  prod: the layer that
             produced x_in (its activation may be non-materialised: BN + ReLU on load)."""
@@ -668,8 +696,20 @@ class UNetEngine(object):
                 L.dc_bn_bwd_finalize(_ptr(T['part_ws']), blocks, l.cout, dgamma, dbeta, st)
             if two and self._dz_free[k] is not None:
                 main.wait_event(self._dz_free[k])       # the wgrad that last read this dz buffer has finished
-            L.dc_bn_bwd_apply(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed, dgamma, dbeta,
-                              dz, _ptr(T['part_ws2']), _ptr(T['absmax']), pixels, l.cout, st)
+            if sync:
+                # (dgamma, dbeta) are adjacent in gflat: one all-reduce makes them the GLOBAL sums the apply pass needs;
+                # afterwards they are pre-divided by the world size because the end-of-step all-reduce of gflat adds
+                # the (now identical) copies of all ranks again
+                g0, _ = l.off['gamma']
+                gb = self.gflat[g0:g0 + 2 * l.cout]
+                parallel.all_reduce_sum(gb)
+                L.dc_bn_bwd_apply_count(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed, dgamma, dbeta,
+                                        dz, _ptr(T['part_ws2']), _ptr(T['absmax']), pixels, float(world * pixels),
+                                        l.cout, st)
+                gb.mul_(1.0 / world)
+            else:
+                L.dc_bn_bwd_apply(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed, dgamma, dbeta,
+                                  dz, _ptr(T['part_ws2']), _ptr(T['absmax']), pixels, l.cout, st)
             f16 = self.mfma == 'f16x3'
             # one launch: conv-bias gradient (column sums of the dz partials) + -- f16x3 -- the exact power-of-two scale
             # that brings max|dz| to [512, 1024] before the fp16 split

@@ -191,6 +191,21 @@ int dc_maxpool2x2_bwd_bnred(const float* dy, const uint8_t* idx, const float* sk
                             const float* beta, const uint8_t* mask, float keep, uint64_t seed, float* bn_partial,
                             int N, int H, int W, int C, dc_stream_t stream);
 
+/* ---- synchronised BatchNorm for batch-sharded data parallelism ('sync' mode) ---------------------
+ * The per-channel sums leave the device between two launches so the host can all-reduce them over the ranks:
+ *   forward : dc_bn_stats_reduce (conv partials -> double sums[C][2]) | all-reduce(sum) | dc_bn_stats_finalize_sums with
+ *             count = GLOBAL elements per channel (scale/shift nullable: the training affine of the _bnin consumers);
+ *   backward: dc_bn_bwd_finalize | all-reduce(sum) of (dgamma, dbeta) | dc_bn_bwd_apply_count with the same count.
+ * With one rank (or count == pixels) the results equal the local entry points'. */
+int dc_bn_stats_reduce(const float* partial, int parts, int groups, int C, double* sums, dc_stream_t stream);
+int dc_bn_stats_finalize_sums(const double* sums, int C, double count, float eps, float momentum, float* mean,
+                              float* invstd, float* moving_mean, float* moving_var, const float* gamma,
+                              const float* beta, float* scale, float* shift, dc_stream_t stream);
+int dc_bn_bwd_apply_count(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
+                          const float* dgamma, const float* dbeta, float* dz, float* dbias_partial,
+                          float* absmax_partial, long pixels, double count, int C, dc_stream_t stream);
+
 /* ---- MaxPooling2D(2, strides=2)  :176 ----------------------------------------
  * in strided [N,H,W,C] (in_ld), out dense [N,H/2,W/2,C], idx (nullable) uint8 in {0..3}: FIRST max in
  * row-major window order (bit-exact contract). */

@@ -1,0 +1,58 @@
+"""Worker of tests/test_sync_bn_gpu.py (one process per rank, launched by torch.distributed.run): 'sync' BatchNorm over
+G ranks x B images must reproduce ONE device's train step on the G*B batch -- checked against the float64 oracle."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deep_calcium_amd import parallel                      # noqa: E402
+from deep_calcium_amd.net import UNetEngine                # noqa: E402
+from oracle import unet_numpy as on                        # noqa: E402
+
+
+def main():
+    out_path = sys.argv[1]
+    rank, world = parallel.init_from_env()
+    NG, H, W, nfb = 2 * world, 32, 32, 8
+    Wt = on.init_weights(nfb, seed=99, randomize_bn=True)
+    x, y = on.synthetic_batch(NG, H, W)
+    masks = on.make_drop_masks(nfb, NG, H, W)
+    sl = parallel.shard_slice(NG)
+    res = {}
+    for mode in ('sync', 'local'):
+        eng = UNetEngine((H, W), nb_filters_base=nfb, bn_mode=mode)
+        eng.set_weights(Wt)
+        xd, yd = torch.from_numpy(x[sl]).cuda(), torch.from_numpy(y[sl]).cuda()
+        md = {k: torch.from_numpy(np.ascontiguousarray(v[sl])).cuda() for k, v in masks.items()}
+        p = eng.forward_train(xd, yd, md, update_moving=True).cpu().numpy()
+        sums = eng._train_bufs(xd.shape[0])['sums'].clone()
+        eng.backward()
+        parallel.all_reduce_sum(eng.gflat)
+        parallel.all_reduce_sum(sums)
+        eng.gflat.mul_(1.0 / world)
+        torch.cuda.synchronize()
+        res[mode] = (p, float(sums[0].item()) / (NG * H * W), eng.grads(), eng.get_weights())
+    if rank == 0:
+        orc = on.UNetOracle(Wt, nfb)
+        loss_ref, p_ref, G_ref, _ = orc.loss_and_grads(x, y, masks)
+        p, loss, G, Wn = res['sync']
+        fg = np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(G[n]) if not (j == 1 and n != 'out')]).astype(np.float64)
+        fr = np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(G_ref[n]) if not (j == 1 and n != 'out')])
+        pl, lossl, Gl, _ = res['local']
+        fl = np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(Gl[n]) if not (j == 1 and n != 'out')]).astype(np.float64)
+        out = dict(world=world,
+                   p_err=float(np.abs(p - p_ref[sl]).max()), loss_err=abs(loss - loss_ref),
+                   grad_cos=float(fg.dot(fr) / (np.linalg.norm(fg) * np.linalg.norm(fr))),
+                   grad_rel=float(np.linalg.norm(fg - fr) / np.linalg.norm(fr)),
+                   # 'local' mode is a different function of the batch: it must NOT match the batch-4 oracle
+                   local_p_err=float(np.abs(pl - p_ref[sl]).max()),
+                   local_grad_rel=float(np.linalg.norm(fl - fr) / np.linalg.norm(fr)))
+        json.dump(out, open(out_path, 'w'))
+    parallel.barrier()
+
+
+if __name__ == '__main__':
+    main()

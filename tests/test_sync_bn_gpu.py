@@ -1,0 +1,27 @@
+"""Data-parallel BatchNorm modes on the GPU: two ranks share the one GPU of the test box over gloo
+(DC_DIST_BACKEND), each trains on half of a batch of 4; 'sync' mode must equal the oracle's single-device batch-4 step."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_sync_bn_two_ranks_equal_one_device_batch(tmp_path):
+    out = str(tmp_path / 'res.json')
+    env = dict(os.environ, DC_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(HERE, '_sync_bn_worker.py'), out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(out))
+    assert res['world'] == 2
+    assert res['p_err'] < 1e-4 and res['loss_err'] < 1e-4, res
+    assert res['grad_cos'] > 0.9995 and res['grad_rel'] < 0.05, res
+    assert res['local_p_err'] > 1e-3 and res['local_grad_rel'] > 0.05, res      # the two modes really differ
