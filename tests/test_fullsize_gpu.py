@@ -93,3 +93,33 @@ def test_fullsize_train_step_is_bit_reproducible(setup):
         torch.cuda.synchronize()
         outs.append((e.gflat.clone(), e.read_sums().copy()))
     assert torch.equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_fullsize_window_train_step_vs_float64_torch_oracle():
+    """One train-mode forward + backward on FULL 512x512 windows (batch 2, nb_filters_base 32) against the float64 torch
+    oracle (autograd): probabilities and loss within 1e-4, gradients in rel-L2 / cosine (single ReLU-gate flips between
+    fp32 and float64 are legitimate discontinuities)."""
+    from deep_calcium_amd.net import UNetEngine
+    from oracle.unet_torch import UNetTorch
+    n = 2
+    Wt = on.init_weights(NFB, seed=77, randomize_bn=True)
+    x, y = on.synthetic_batch(n, H, W)
+    masks = on.make_drop_masks(NFB, n, H, W)
+    ref = UNetTorch(Wt, NFB, dtype=torch.float64)
+    loss_ref, p_ref, G_ref, _ = ref.loss_and_grads(x, y, masks)
+    eng = UNetEngine((H, W), nb_filters_base=NFB, prop_dropout_base=0.25)
+    eng.set_weights(Wt)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    md = {k: torch.from_numpy(v).cuda() for k, v in masks.items()}
+    p = eng.forward_train(xd, yd, md, update_moving=False).cpu().numpy()
+    loss = eng.read_sums()[0] / (n * H * W)
+    eng.backward()
+    G = eng.grads()
+    assert np.abs(p - p_ref).max() < 1e-4
+    assert abs(loss - loss_ref) < 1e-4
+    fg = np.concatenate([g.ravel() for k in G_ref for j, g in enumerate(G[k]) if not (j == 1 and k != 'out')]).astype(np.float64)
+    fr = np.concatenate([np.asarray(g).ravel() for k in G_ref for j, g in enumerate(G_ref[k]) if not (j == 1 and k != 'out')])
+    assert fg.shape == fr.shape
+    cos = fg.dot(fr) / (np.linalg.norm(fg) * np.linalg.norm(fr))
+    rel = np.linalg.norm(fg - fr) / np.linalg.norm(fr)
+    assert cos > 0.9995 and rel < 0.05, (cos, rel)
