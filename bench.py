@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- 512x512 summary images/sec for one UNet2DS train step (fwd + BCE + bwd + Adam) on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: bench.py starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Workload = BASELINE.json configs[2] per GPU (batch 16 of 512x512, fp32), i.e. configs[3] (global batch 128) at
@@ -138,6 +138,77 @@ def cpu_baseline(budget_s=25.0):
                       "reference's CPU path, is not installable offline)" % (steps, bs, dt, warm, threads)}
 
 
+def kernel_source_sha():
+    """Fingerprint of the sources the dominant kernel is compiled from: PMC traffic measured on another build is stale."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('igemm_f16x3.hip', 'igemm_common.h', 'common.h'):
+        h.update(open(os.path.join(ROOT, 'deep_calcium_amd', 'csrc', f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kname):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (scripts/pmc_passes.sh ->
+    profiles/pmc_traffic.json).  Counters cannot be read from inside the process, so the figure comes from the committed
+    profile of THIS kernel source (sha-stamped); a stale or missing profile reports null."""
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        t = json.load(open(tpath))
+    except Exception:
+        return None, 'no profiles/pmc_traffic.json'
+    if t.get('kernel') != kname:
+        return None, 'profiles/pmc_traffic.json is for another kernel'
+    if t.get('kernel_source_sha') != kernel_source_sha():
+        return None, 'profiles/pmc_traffic.json was measured on an older build of this kernel (re-run scripts/pmc_passes.sh)'
+    return t.get('bytes_per_launch'), 'rocprofv3 PMC passes of this kernel source, %s' % t.get('source', '')
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) from THIS process,
+    which has not touched the GPU (no HIP call, only a device count), wait for them and return their exit code.
+    Rank 0 inherits stdout (it prints the JSON line); the other ranks' stdout goes to stderr."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()            # does not initialise the GPU on this image
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+               OMP_NUM_THREADS=str(max(1, host_cores() // n)))
+    if ndev < n and 'DC_DIST_BACKEND' not in env:
+        if ndev < 1:
+            raise SystemExit('bench.py: no GPU visible')
+        # fewer GPUs than ranks (a 1-GPU box): RCCL cannot place two ranks on one device, gloo can -- a FUNCTIONAL run of
+        # the N-rank path, flagged in the JSON line (config.shared_gpus)
+        sys.stderr.write('bench.py: %d ranks on %d GPU(s): ranks share devices over gloo (functional run)\n' % (n, ndev))
+        env['DC_DIST_BACKEND'] = 'gloo'
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in procs:          # one rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -151,6 +222,10 @@ def main():
                     help="'infer' times the forward-only path (BASELINE configs[1]) for information; the contract line is 'train'")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))         # before anything in this process touches the GPU
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
     import torch
     from deep_calcium_amd import parallel
     from deep_calcium_amd.model import Model, Adam
@@ -158,8 +233,8 @@ def main():
 
     rank, world = parallel.init_from_env()
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    shared_gpus = torch.cuda.device_count() < world
     local = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -191,6 +266,7 @@ def main():
 
     timer = KernelTimer(eng.L)
     eng.L = timer
+    parallel.barrier()
 
     for _ in range(args.warmup):
         model.train_on_device_batch(xd, yd)
@@ -210,10 +286,25 @@ def main():
 
     # ---- roofline of the dominant kernel: 2 instrumented steps outside the timed region --------------------
     timer.enabled = True
+    model.ar_events = []                  # also bracket the part of the gradient exchange the step waits for
     for _ in range(2):
         model.train_on_device_batch(xd, yd)
     torch.cuda.synchronize()
     n_launch, k_ms, k_flops = timer.summarize()
+    ar_exposed = [a.elapsed_time(b) for a, b in model.ar_events]
+    model.ar_events = None
+    ar_alone = None
+    if world > 1:                         # the whole 31 MB flat gradient in ONE blocking all-reduce, nothing else running
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        parallel.all_reduce_sum(eng.gflat)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        e0.record()
+        for _ in range(5):
+            parallel.all_reduce_sum(eng.gflat)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_alone = e0.elapsed_time(e1) / 5
     # the same kernel without the concurrent weight-gradient stream (production overlaps them: +6.6 % step
     # throughput, but co-running kernels stretch each other's launch time)
     streams = eng.streams
@@ -228,13 +319,7 @@ def main():
     if rank == 0:
         achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         kname, peak, mfma_per_flop = KernelTimer.KERNELS[eng.mfma]
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get('bytes_per_launch')
-            except Exception:
-                traffic = None
+        traffic, traffic_note = pmc_traffic(kname)
         out = {
             'metric': '512x512 summary images/sec (train step)', 'value': round(world * B * args.steps / dt, 3),
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -245,7 +330,8 @@ def main():
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'bn': eng.bn_mode,
                        'contraction': 'fp32 operands split exactly into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 '
                                       'accumulate' if eng.mfma == 'f16x3' else 'fp32 MFMA',
-                       'loss': float(vals[0])},
+                       'loss': float(vals[0]), 'shared_gpus': bool(shared_gpus),
+                       'dist_backend': (torch.distributed.get_backend() if world > 1 else None)},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
                          'kernel': kname, 'launches': n_launch,
@@ -254,8 +340,13 @@ def main():
                          'mfma_flops_per_algorithmic_flop': mfma_per_flop,
                          'matrix_pipe_frac': round(mfma_per_flop * achieved / peak, 4),
                          'achieved_without_concurrent_wgrad_stream': round(iso_flops / (iso_ms * 1e-3) / 1e12, 3) if iso_ms > 0 else None,
-                         'streams': streams},
+                         'streams': streams, 'traffic_note': traffic_note},
         }
+        if world > 1:
+            out['allreduce_ms'] = round(ar_alone, 4)
+            out['allreduce_exposed_ms'] = round(sum(ar_exposed) / max(len(ar_exposed), 1), 4)
+            out['allreduce_bytes'] = int(eng.n_train * 4)
+            out['allreduce_buckets'] = 1 if os.environ.get('DC_AR_BUCKETS', '3') == '1' else 3
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

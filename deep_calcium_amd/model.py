@@ -245,22 +245,52 @@ class Model(object):
             out[i:i + batch_size] = self.engine.forward_infer(xb).cpu().numpy()[:xb.shape[0]]
         return out
 
-    def train_on_batch(self, x, y, drop_masks=None):
+    def train_on_batch(self, x, y, drop_masks=None, presharded=False):
         """One optimizer step; returns [loss, F1, prec, reca, dice, dicesq, posyt, posyp] (Keras order).
         Under torch.distributed (one process per GPU) every rank is handed the SAME global batch and trains on
-        its contiguous slice; gradients and metric sums are all-reduced over RCCL."""
+        its contiguous slice (presharded=True: x, y are already this rank's slice); gradients and metric sums are
+        all-reduced over RCCL.  Host -> device: the slice is staged in pinned memory and copied on a separate HIP
+        stream into one of two rotating device buffers, so the transfer of step k+1 overlaps the backward of step k."""
         if self.optimizer is None:
             raise RuntimeError('compile() the model first')
         eng = self.engine
-        x = np.ascontiguousarray(x, dtype=np.float32)
-        y = np.ascontiguousarray(y, dtype=np.uint8)
-        sl = parallel.shard_slice(x.shape[0])
-        xd = torch.from_numpy(x[sl]).to(eng.device)
-        yd = torch.from_numpy(y[sl]).to(eng.device)
+        sl = slice(0, len(x)) if presharded else parallel.shard_slice(len(x))
+        xs = np.asarray(x[sl], dtype=np.float32)
+        ys = np.asarray(y[sl], dtype=np.uint8)
+        if xs.ndim != 3 or tuple(xs.shape[1:]) != self.config['window_shape'] or ys.shape != xs.shape:
+            raise ValueError('expected x, y of shape (N,%d,%d), got %r and %r' % (self.config['window_shape'] + (xs.shape, ys.shape)))
+        xd, yd, slot = self._stage(xs, ys)
         masks = None
         if drop_masks is not None:
             masks = {k: torch.from_numpy(np.ascontiguousarray(v[sl])).to(eng.device) for k, v in drop_masks.items()}
-        return self.train_on_device_batch(xd, yd, masks)
+        out = self.train_on_device_batch(xd, yd, masks)
+        slot['done'].record(torch.cuda.current_stream(eng.device))      # the step's last reader of xd / yd (Adam) is queued
+        return out
+
+    def _stage(self, xs, ys):
+        """numpy slice -> (pinned host buffer -> device buffer) of a 2-deep ring, copied on the copy stream."""
+        eng = self.engine
+        key = tuple(xs.shape)
+        st = getattr(self, '_staging', None)
+        if st is None or st['key'] != key:
+            with torch.cuda.device(eng.device):
+                st = dict(key=key, turn=0, copy=torch.cuda.Stream(device=eng.device), slots=[
+                    dict(xh=torch.empty(key, dtype=torch.float32).pin_memory(), yh=torch.empty(key, dtype=torch.uint8).pin_memory(),
+                         xd=torch.empty(key, dtype=torch.float32, device=eng.device),
+                         yd=torch.empty(key, dtype=torch.uint8, device=eng.device),
+                         done=torch.cuda.Event(), ready=torch.cuda.Event()) for _ in range(2)])
+            self._staging = st
+        slot = st['slots'][st['turn']]
+        st['turn'] ^= 1
+        slot['done'].synchronize()            # the step that last used this slot (two steps ago) has finished with it
+        slot['xh'].numpy()[...] = xs
+        slot['yh'].numpy()[...] = ys
+        with torch.cuda.stream(st['copy']):
+            slot['xd'].copy_(slot['xh'], non_blocking=True)
+            slot['yd'].copy_(slot['yh'], non_blocking=True)
+            slot['ready'].record(st['copy'])
+        torch.cuda.current_stream(eng.device).wait_event(slot['ready'])
+        return slot['xd'], slot['yd'], slot
 
     def train_on_device_batch(self, xd, yd, masks=None):
         """train_on_batch for a LOCAL shard already resident in HBM (xd float32 (n,H,W), yd uint8 (n,H,W)):
@@ -270,26 +300,71 @@ class Model(object):
         eng = self.engine
         eng.forward_train(xd, yd, masks)
         world = parallel.world_size()
+        sync = world > 1 and eng.bn_mode == 'sync'
         # The loss / metric sums are complete once the forward's head kernel has run: their (all-reduced) copy goes to
         # pinned host memory right away and the host only waits for THAT copy -- backward and Adam of this step are still
         # executing when the call returns, so the next step's launches queue up behind them with no idle gap.
         sums = eng._train_bufs(xd.shape[0])['sums']
+        grad_scale = 1.0 / world
         if world > 1:
-            sums = sums.clone()              # the backward of the dice losses reads the rank-local sums
-            parallel.all_reduce_sum(sums)
+            if sync:
+                # 'sync' = ONE device's step on the global batch: the dice losses' backward must see the GLOBAL sums
+                # (in place), and their per-pixel gradient carries no 1/count, so the summed gradient is already the
+                # global one (BCE kinds divide by the LOCAL pixel count -> mean over ranks)
+                parallel.all_reduce_sum(sums)
+                if eng.loss_kind >= 2:
+                    grad_scale = 1.0
+            else:
+                # 'local' = the mean of G independent shard losses: each rank's backward keeps its own sums
+                sums = sums.clone()
+                parallel.all_reduce_sum(sums)
         if getattr(self, '_sums_host', None) is None:
             self._sums_host = torch.empty(sums.shape, dtype=sums.dtype).pin_memory()
         self._sums_host.copy_(sums, non_blocking=True)
         copied = torch.cuda.Event()
         copied.record()
-        eng.backward()
         if world > 1:
-            parallel.all_reduce_sum(eng.gflat)
+            self._backward_allreduce()
+        else:
+            eng.backward()
         o = self.optimizer
-        eng.adam_step(o.lr, o.beta_1, o.beta_2, o.epsilon, grad_scale=1.0 / world)
+        eng.adam_step(o.lr, o.beta_1, o.beta_2, o.epsilon, grad_scale=grad_scale)
         copied.synchronize()
         m = metrics_from_sums(self._sums_host.numpy().copy(), float(world * xd.shape[0] * xd.shape[1] * xd.shape[2]), self.loss)
         return [m[k] for k in self.metrics_names]
+
+    def _backward_allreduce(self):
+        """Backward + gradient all-reduce (RCCL over xGMI; gloo in the CPU-launched tests).  The flat gradient goes
+        out in the three contiguous ranges of UNetEngine.grad_buckets(): decoder + head (39 % of the 31 MB) and the
+        bottleneck (46 %) are reduced while the encoder's backward -- the long 256^2 / 512^2 layers -- is still running;
+        only the encoder's 15 % is exposed.  DC_AR_BUCKETS=1: one blocking all-reduce after the backward."""
+        import torch.distributed as dist
+        eng = self.engine
+        if os.environ.get('DC_AR_BUCKETS', '3') == '1':
+            eng.backward()
+            t0 = self._ar_mark()
+            parallel.all_reduce_sum(eng.gflat)
+            self._ar_mark(t0)
+            return
+        works = []
+        eng.backward(bucket_cb=lambda lo, hi: works.append(dist.all_reduce(eng.gflat[lo:hi], async_op=True)))
+        t0 = self._ar_mark()
+        lo, hi = eng.grad_buckets()[-1]
+        dist.all_reduce(eng.gflat[lo:hi])
+        for w in works:
+            w.wait()
+        self._ar_mark(t0)
+
+    def _ar_mark(self, start=None):
+        """bench.py instrumentation: HIP events around the part of the gradient exchange the step actually waits for."""
+        rec = getattr(self, 'ar_events', None)
+        if rec is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if start is not None:
+            rec.append((start, ev))
+        return ev
 
     def fit_generator(self, generator, steps_per_epoch, epochs=1, verbose=1, callbacks=None, max_queue_size=10,
                       initial_epoch=0):
@@ -303,6 +378,8 @@ class Model(object):
             cb.set_params(dict(epochs=epochs, steps=steps_per_epoch, verbose=verbose, metrics=self.metrics_names))
         q = queue.Queue(maxsize=max(1, max_queue_size))
         stop = threading.Event()
+        # a generator that already yields this rank's slice of the global batch (UNet2DSummary._batch_gen under DP)
+        presharded = bool(getattr(generator, 'presharded', False))
 
         def producer():
             try:
@@ -337,7 +414,7 @@ class Model(object):
                     blogs = {'batch': step, 'size': len(xb)}
                     for cb in cbs:
                         cb.on_batch_begin(step, blogs)
-                    vals = self.train_on_batch(xb, yb)
+                    vals = self.train_on_batch(xb, yb, presharded=presharded)
                     for k, v in zip(self.metrics_names, vals):
                         blogs[k] = v
                         totals[k] += v * len(xb)

@@ -28,6 +28,20 @@ def _ptr(t, offset_floats=0):
     return t.data_ptr() + 4 * offset_floats
 
 
+def _on_device(fn):
+    """The C ABI launches on the CURRENT HIP device (dcunet.h: 'caller sets the device'): make the engine's device
+    current for the duration of the call, so Model(device='cuda:1') works while device 0 is current."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        if torch.cuda.current_device() == self.device.index:
+            return fn(self, *a, **k)
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 class LayerSpec(object):
     __slots__ = ('name', 'kind', 'cin', 'cout', 'mom', 'lvl', 'drop', 'off', 'soff', 'index')
 
@@ -102,6 +116,10 @@ class UNetEngine(object):
         self.L = lib()
         self.H, self.W, self.nfb, self.drp = H, W, nfb, float(prop_dropout_base)
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        if self.device.type != 'cuda':
+            raise DcunetError('the UNet2DS engine runs on a GPU only, got device %r' % (device,))
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.upsampling = bool(upsampling)
         self.layers = build_layer_table(nfb, self.drp, self.upsampling)
         # dropout after the up layer of each level (unet_2d_summary.py:198,204,210,216)
@@ -261,6 +279,7 @@ class UNetEngine(object):
             self._bufs[name] = t
         return t
 
+    @_on_device
     def repack(self):
         """HWIO / (2,2,Cout,Cin) kernels -> the [tap][K/4][N][4] layouts of the implicit-GEMM kernels."""
         if not self._packed_dirty:
@@ -424,10 +443,21 @@ class UNetEngine(object):
         return plan
 
     # ---- inference ---------------------------------------------------------------------------------------
+    def _check_input(self, name, t, dtype, shape=None):
+        """Raw pointers cross the C ABI: a wrong dtype / layout / device would silently compute garbage."""
+        shape = tuple(shape) if shape is not None else (t.shape[0], self.H, self.W)
+        if not isinstance(t, torch.Tensor) or t.dtype != dtype or tuple(t.shape) != shape or not t.is_contiguous() \
+                or t.device != self.device:
+            raise ValueError('%s must be a contiguous %s tensor of shape %r on %s, got %s' % (
+                name, dtype, shape, self.device,
+                '%s %r on %s%s' % (t.dtype, tuple(t.shape), t.device, '' if t.is_contiguous() else ' (non-contiguous)')
+                if isinstance(t, torch.Tensor) else type(t).__name__))
+
+    @_on_device
     def forward_infer(self, x_dev):
         """x_dev: float32 cuda tensor (N,H,W) -> p: (N,H,W) probabilities (BN folded into the conv epilogue)."""
         N = x_dev.shape[0]
-        assert tuple(x_dev.shape[1:]) == (self.H, self.W) and x_dev.dtype == torch.float32 and x_dev.is_contiguous()
+        self._check_input('x', x_dev, torch.float32)
         L, st = self.L, self._stream()
         self.repack()
         self.refold()
@@ -495,6 +525,7 @@ class UNetEngine(object):
         T['wgrad_ws'] = torch.empty(ws_floats, dtype=torch.float32, device=dev)
         T['sums'] = torch.zeros(12, dtype=torch.float64, device=dev)
         T['bn_sums'] = torch.zeros(2 * max(l.cout for l in self.layers if l.kind != 'head'), dtype=torch.float64, device=dev)
+        T['bn_gsum'] = torch.zeros(2 * max(l.cout for l in self.layers if l.kind != 'head'), dtype=torch.float32, device=dev)
         big = N * self.H * self.W * nfb
         # dz rotates over 3 buffers: the weight-gradient kernels run on a side stream and may still be reading the
         # dz of block L while the main stream already produces the dz of block L-1 / L-2
@@ -515,7 +546,9 @@ class UNetEngine(object):
             m = masks[l.name]
             assert m.dtype == torch.uint8 and m.is_contiguous()
             return m.data_ptr(), keep, 0
-        return None, keep, (step_seed * 1000003 + l.index * 7919) & 0xFFFFFFFFFFFFFFFF
+        h, w = self._hw(l.lvl)
+        seed = (step_seed * 1000003 + l.index * 7919) & 0xFFFFFFFFFFFFFFFF
+        return None, keep, parallel.shard_drop_seed(seed, self._last[0] * h * w * l.cout)
 
     def _up_drop_args(self, lvl, masks, step_seed):
         rate = self.up_drop[lvl]
@@ -525,11 +558,26 @@ class UNetEngine(object):
             m = masks['u%d' % lvl]
             assert m.dtype == torch.uint8 and m.is_contiguous()
             return m.data_ptr(), 1.0 - rate, 0
-        return None, 1.0 - rate, (step_seed * 1000003 + (100 + lvl) * 7919) & 0xFFFFFFFFFFFFFFFF
+        h, w = self._hw(lvl)
+        seed = (step_seed * 1000003 + (100 + lvl) * 7919) & 0xFFFFFFFFFFFFFFFF
+        return None, 1.0 - rate, parallel.shard_drop_seed(seed, self._last[0] * h * w * self._cup(lvl))
 
+    @_on_device
     def forward_train(self, x_dev, y_dev, masks=None, update_moving=True):
         """Training-mode forward (batch statistics, dropout).  Returns p; loss/metric sums land in T['sums']."""
         N = x_dev.shape[0]
+        self._check_input('x', x_dev, torch.float32)
+        self._check_input('y', y_dev, torch.uint8, (N, self.H, self.W))
+        if masks is not None:
+            for l in self.layers:
+                if l.drop > 0.0:
+                    h, w = self._hw(l.lvl)
+                    self._check_input('masks[%r]' % l.name, masks.get(l.name), torch.uint8, (N, h, w, l.cout))
+            if self.upsampling:
+                for lvl, rate in self.up_drop.items():
+                    if rate > 0.0:
+                        h, w = self._hw(lvl)
+                        self._check_input("masks['u%d']" % lvl, masks.get('u%d' % lvl), torch.uint8, (N, h, w, self._cup(lvl)))
         L, st = self.L, self._stream()
         self.repack()
         A, T = self._acts(N), self._train_bufs(N)
@@ -613,8 +661,18 @@ class UNetEngine(object):
         L.dc_reduce_partials_f64(_ptr(T['part_ws']), hb, 12, T['sums'].data_ptr(), st)
         return A['p']
 
-    def backward(self):
-        """Backward of the last forward_train: fills gflat (same layout as pflat)."""
+    @_on_device
+    def grad_buckets(self):
+        """gflat as three contiguous ranges in the order the backward completes them: decoder + head, bottleneck,
+        encoder (flat layout = Keras get_weights order: encoder, bottleneck, decoder, head)."""
+        o_ba, o_dec = self.by_name['ba'].off['k'][0], self.layers[10].off['k'][0]
+        return [(o_dec, self.n_train), (o_ba, o_dec), (0, o_ba)]
+
+    def backward(self, bucket_cb=None):
+        """Backward of the last forward_train: fills gflat (same layout as pflat).  bucket_cb(lo, hi), if given, is called
+        with the side (weight-gradient) stream current as soon as gflat[lo:hi] is complete on it -- data-parallel training
+        starts that range's all-reduce there, so it overlaps with the rest of the backward (grad_buckets()[:2]; the last
+        range is complete when backward() returns)."""
         N, masks, step_seed, x_dev, y_dev = self._last
         L, st = self.L, self._stream()
         A, T = self._acts(N), self._train_bufs(N)
@@ -697,16 +755,16 @@ class UNetEngine(object):
             if two and self._dz_free[k] is not None:
                 main.wait_event(self._dz_free[k])       # the wgrad that last read this dz buffer has finished
             if sync:
-                # (dgamma, dbeta) are adjacent in gflat: one all-reduce makes them the GLOBAL sums the apply pass needs;
-                # afterwards they are pre-divided by the world size because the end-of-step all-reduce of gflat adds
-                # the (now identical) copies of all ranks again
+                # (dgamma, dbeta) are adjacent in gflat and stay the rank-LOCAL sums there (the end-of-step all-reduce
+                # of gflat makes them global exactly once); the apply pass needs the GLOBAL sums now: all-reduce a
+                # scratch copy (a device memcpy, no arithmetic outside the kernels)
                 g0, _ = l.off['gamma']
-                gb = self.gflat[g0:g0 + 2 * l.cout]
-                parallel.all_reduce_sum(gb)
-                L.dc_bn_bwd_apply_count(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed, dgamma, dbeta,
-                                        dz, _ptr(T['part_ws2']), _ptr(T['absmax']), pixels, float(world * pixels),
-                                        l.cout, st)
-                gb.mul_(1.0 / world)
+                gg = T['bn_gsum'][:2 * l.cout]
+                gg.copy_(self.gflat[g0:g0 + 2 * l.cout])
+                parallel.all_reduce_sum(gg)
+                L.dc_bn_bwd_apply_count(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed,
+                                        _ptr(gg), _ptr(gg, l.cout), dz, _ptr(T['part_ws2']), _ptr(T['absmax']), pixels,
+                                        float(world * pixels), l.cout, st)
             else:
                 L.dc_bn_bwd_apply(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed, dgamma, dbeta,
                                   dz, _ptr(T['part_ws2']), _ptr(T['absmax']), pixels, l.cout, st)
@@ -765,10 +823,21 @@ class UNetEngine(object):
                 L.dc_upsample2x_drop_bwd(_ptr(dcat), 3 * c, mptr, keep, seed, _ptr(g), N, h // 2, w // 2, 2 * c, st)
             else:
                 block_bwd(self.by_name['u%d' % lvl], _ptr(x_up), _ptr(dcat), 2 * c, _ptr(g), prod=l_up)
+        def bucket_done(i):
+            if bucket_cb is None:
+                return
+            if two:
+                side.wait_stream(main)      # dbias / dgamma / dbeta / head gradients are written on the main stream
+            with torch.cuda.stream(side):
+                bucket_cb(*self.grad_buckets()[i])
+
+        bucket_done(0)
         for lvl in (4, 3, 2, 1, 0):
             c = nfb << lvl
             h, w = self._hw(lvl)
             tag = 'b' if lvl == 4 else 'e%d' % lvl
+            if lvl == 3:
+                bucket_done(1)
             if lvl < 4:
                 # g = d(pool output); route through the argmax and add the skip gradient (second half of dcat)
                 cup = self._cup(lvl)
@@ -804,6 +873,7 @@ class UNetEngine(object):
         if side is not None:
             torch.cuda.current_stream(self.device).wait_stream(side)
 
+    @_on_device
     def adam_step(self, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-8, grad_scale=1.0):
         """Keras-2.0.6 Adam over the flat buffers; `iterations` counts completed steps."""
         t = self.iterations + 1

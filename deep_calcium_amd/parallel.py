@@ -31,11 +31,14 @@ def init_from_env(backend=None):
     if ws <= 1 or is_dist():
         return rank(), world_size()
     local = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
+    # RCCL's intra-node transport needs dmabuf IPC (HSA_ENABLE_IPC_MODE_LEGACY=0).  The variable is read when the HSA
+    # runtime initialises, i.e. at the first GPU call of the process: launchers (bench.py, torchrun wrappers) must export
+    # it; setting it here only helps when nothing has touched the GPU yet.
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         torch.cuda.set_device(local % torch.cuda.device_count())
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     # DC_DIST_BACKEND=gloo lets several ranks share ONE GPU (functional testing of the N>1 path on a 1-GPU box)
     backend = backend or os.environ.get('DC_DIST_BACKEND') or ('nccl' if use_cuda else 'gloo')
     dist.init_process_group(backend)
@@ -83,3 +86,28 @@ def broadcast_params(*tensors, src=0):
     if is_dist() and world_size() > 1:
         for t in tensors:
             dist.broadcast(t, src)
+
+
+def broadcast_numpy_rng(src=0):
+    """Make numpy's GLOBAL RNG (the stream the reference's _batch_gen draws from, unet_2d_summary.py:434-530) identical
+    on every rank: rank `src`'s state is broadcast, so a seeded multi-GPU run samples exactly the batches the same
+    seeded single-GPU run would, whatever the other ranks did with their RNG before."""
+    if not (is_dist() and world_size() > 1):
+        return
+    import numpy as np
+    box = [np.random.get_state() if rank() == src else None]
+    dist.broadcast_object_list(box, src)
+    np.random.set_state(box[0])
+
+
+GOLDEN64 = 0x9E3779B97F4A7C15        # the multiplier of dc_hash32 (csrc/common.h)
+
+
+def shard_drop_seed(seed, local_elems, r=None):
+    """Dropout seed of rank r's shard such that its element e draws the bits a single device would have drawn for
+    element r*local_elems + e of the global batch: dc_hash32 mixes idx*GOLDEN64 + seed, so an index offset is a seed
+    offset (mod 2^64).  Without it every rank would apply the same masks to its shard."""
+    r = rank() if r is None else r
+    if seed == 0 or r == 0:
+        return seed
+    return (seed + r * int(local_elems) * GOLDEN64) & 0xFFFFFFFFFFFFFFFF

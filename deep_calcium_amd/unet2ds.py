@@ -90,9 +90,14 @@ def _summarize_series(dspath):
 def _summarize_mask(dspath):
     """Flatten the neuron mask stack to one (H,W) mask, dropping pixels owned by >1 neuron and pixels whose
     8-neighbourhood (among the surviving single-owner pixels) touches another neuron, unet_2d_summary.py:244-291.
-    The reference removes neighbourhoods sequentially in dict order while iterating a snapshot of the keys; this
-    vectorised form reproduces that order-dependent deletion by a raster-order sweep."""
-    msks = np.asarray(_get(dspath, 'masks/raw'))
+    The reference removes neighbourhoods sequentially in dict order while iterating a snapshot of the keys, so the
+    result depends on that order.  Surviving pixels only ever disappear, hence only pixels whose INITIAL neighbourhood
+    holds two owners can ever trigger a removal: those candidates (the seams between touching neurons, found with
+    array ops) are swept in the reference's key order; everything else is vectorised."""
+    return _flatten_mask_stack(np.asarray(_get(dspath, 'masks/raw')))
+
+
+def _flatten_mask_stack(msks):
     zz, yy, xx = np.where(msks == 1)
     H, W = msks.shape[1:]
     count = np.zeros((H, W), np.int32)
@@ -100,22 +105,25 @@ def _summarize_mask(dspath):
     owner = np.full((H, W), -1, np.int64)
     owner[yy, xx] = zz
     owner[count != 1] = -1
-    # keys in first-insertion order of the reference's dict = np.where order (z, then y, then x)
-    seen = np.zeros((H, W), bool)
-    keys = []
-    for y, x in zip(yy, xx):
-        if not seen[y, x]:
-            seen[y, x] = True
-            if count[y, x] == 1:
-                keys.append((y, x))
     alive = owner >= 0
-    for y, x in keys:
-        nb = [(y - 1, x), (y + 1, x), (y, x - 1), (y, x + 1), (y + 1, x + 1), (y - 1, x - 1), (y + 1, x - 1),
-              (y - 1, x + 1), (y, x)]
-        nb = [(a, b) for a, b in nb if 0 <= a < H and 0 <= b < W and alive[a, b]]
-        if len(set(owner[a, b] for a, b in nb)) > 1:
-            for a, b in nb:
-                alive[a, b] = False
+    # smallest / largest owner over the 3x3 neighbourhood of surviving pixels
+    big = np.iinfo(np.int64).max
+    lo = np.pad(np.where(alive, owner, big), 1, constant_values=big)
+    hi = np.pad(owner, 1, constant_values=-1)
+    nlo, nhi = lo[1:-1, 1:-1].copy(), hi[1:-1, 1:-1].copy()
+    for dy in (0, 1, 2):
+        for dx in (0, 1, 2):
+            np.minimum(nlo, lo[dy:dy + H, dx:dx + W], out=nlo)
+            np.maximum(nhi, hi[dy:dy + H, dx:dx + W], out=nhi)
+    cand = (nhi >= 0) & (nlo != nhi) & (count == 1)
+    # the reference's dict keys in insertion order = np.where order (z, then y, then x) of the single-owner pixels
+    sel = cand[yy, xx]
+    for y, x in zip(yy[sel].tolist(), xx[sel].tolist()):
+        y0, y1, x0, x1 = max(y - 1, 0), min(y + 2, H), max(x - 1, 0), min(x + 2, W)
+        a = alive[y0:y1, x0:x1]
+        o = owner[y0:y1, x0:x1][a]
+        if o.size and o.min() != o.max():
+            a[...] = False
     return alive.astype(np.float64)
 
 
@@ -181,6 +189,22 @@ class _ValidationMetricsCB(Callback):
         logger.info('mean f1 = %.3lf  (validation %.3lf s)' % (logs['val_nf_f1_mean'], time() - tic))
 
 
+class _PreshardedBatches(object):
+    """Iterator over this rank's slices of the global batches; `presharded` tells fit_generator not to slice again."""
+    presharded = True
+
+    def __init__(self, gen):
+        self._gen = gen
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return next(self._gen)
+
+    next = __next__
+
+
 class UNet2DSummary(object):
     """Same constructor as the reference (unet_2d_summary.py:316-331); `net_builder_func` is the plug-point."""
 
@@ -228,7 +252,11 @@ class UNet2DSummary(object):
         M_summ = [self.mask_summary_func(d) for d in dataset_paths]
         ycval = [(s.shape[0] - int(s.shape[0] * prop_val), s.shape[0]) for s in S_summ]
         yctrn = [(0, int(s.shape[0] * prop_trn)) for s in S_summ]
-        gen_trn = self._batch_gen(S_summ, M_summ, names, yctrn, batch_size_trn, nb_steps_trn, shape_trn, 15)
+        # data parallel: every rank replays the reference's single RNG stream (rank 0's state, broadcast) but only
+        # materialises its own slice of each global batch
+        parallel.broadcast_numpy_rng()
+        gen_trn = self._batch_gen(S_summ, M_summ, names, yctrn, batch_size_trn, nb_steps_trn, shape_trn, 15,
+                                  shard=(parallel.rank(), parallel.world_size()))
 
         tic = int(time())
         callbacks = [_ValidationMetricsCB(model_val, S_summ, M_summ, names, ycval)]
@@ -246,11 +274,23 @@ class UNet2DSummary(object):
         return trained.history, '%s/model_val_nf_f1_mean.hdf5' % self.cpdir
 
     def _batch_gen(self, S_summ, M_summ, names, y_coords, batch_size, nb_steps, window_shape, nb_max_augment=0,
-                   scores_path=None):
+                   scores_path=None, shard=None):
         """Infinite generator of (s_batch (B,h,w) f32, m_batch (B,h,w) u8): neuron-centred random crops with
         random flips / rot90s, drawing from numpy's GLOBAL RNG in the reference's order
-        (unet_2d_summary.py:434-530) so that a seeded run yields the reference's batches."""
+        (unet_2d_summary.py:434-530) so that a seeded run yields the reference's batches.
+        shard=(r, G) (data parallel, not in the reference): EVERY random draw of the global batch is still made, in
+        order -- the stream stays the single-device one -- but only items [r*B/G, (r+1)*B/G) are cropped and augmented,
+        and the generator yields that slice: the array work per rank is 1/G of the global batch."""
+        if shard is not None and shard[1] > 1:
+            return _PreshardedBatches(self._batch_gen_impl(S_summ, M_summ, names, y_coords, batch_size, nb_steps, window_shape,
+                                                           nb_max_augment, scores_path, parallel.shard_slice(batch_size, *shard)))
+        return self._batch_gen_impl(S_summ, M_summ, names, y_coords, batch_size, nb_steps, window_shape, nb_max_augment,
+                                    scores_path, None)
+
+    def _batch_gen_impl(self, S_summ, M_summ, names, y_coords, batch_size, nb_steps, window_shape, nb_max_augment,
+                        scores_path, mine):
         rng = np.random
+        b0, b1 = (mine.start, mine.stop) if mine is not None else (0, batch_size)
         hw, ww = window_shape
         nb_yields = 0
         n_ds = len(S_summ)
@@ -265,8 +305,8 @@ class UNet2DSummary(object):
                     scores = pickle.load(fp)
                 probs = np.array([1 - np.mean(scores[n]) for n in names])
                 probs /= probs.sum()
-            s_batch = np.zeros((batch_size, hw, ww), dtype=np.float32)
-            m_batch = np.zeros((batch_size, hw, ww), dtype=np.uint8)
+            s_batch = np.zeros((b1 - b0, hw, ww), dtype=np.float32)
+            m_batch = np.zeros((b1 - b0, hw, ww), dtype=np.uint8)
             for b in range(batch_size):
                 k = rng.choice(np.arange(n_ds), p=probs)
                 s, m = S_summ[k], M_summ[k]
@@ -279,10 +319,14 @@ class UNet2DSummary(object):
                 y1 = min(y0 + hw, ymax)
                 x0 = max(0, int(cx - (ww / 2)))
                 x1 = min(x0 + ww, ws)
-                m_batch[b, :y1 - y0, :x1 - x0] = m[y0:y1, x0:x1]      # short crops stay zero-filled
-                s_batch[b, :y1 - y0, :x1 - x0] = s[y0:y1, x0:x1]
-                for j in rng.choice(len(_SIX), rng.randint(0, nb_max_augment + 1)):
-                    s_batch[b], m_batch[b] = _SIX[j](s_batch[b]), _SIX[j](m_batch[b])
+                augs = rng.choice(len(_SIX), rng.randint(0, nb_max_augment + 1))
+                if not b0 <= b < b1:
+                    continue                                          # another rank's item: draws made, no array work
+                i = b - b0
+                m_batch[i, :y1 - y0, :x1 - x0] = m[y0:y1, x0:x1]      # short crops stay zero-filled
+                s_batch[i, :y1 - y0, :x1 - x0] = s[y0:y1, x0:x1]
+                for j in augs:
+                    s_batch[i], m_batch[i] = _SIX[j](s_batch[i]), _SIX[j](m_batch[i])
             nb_yields += 1
             yield s_batch, m_batch
 

@@ -5,8 +5,10 @@
 #   3. PMC passes (FETCH_SIZE | WRITE_SIZE | MFMA busy), single stream -> pmc/
 set -u
 OUT=${1:-gpurun_out/final}
-mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p "$OUT"
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export TMPDIR=/tmp
+cd "$ROOT"
 python3 bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --mode infer --steps 20 --warmup 5 > $OUT/bench_infer.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1

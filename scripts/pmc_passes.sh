@@ -4,8 +4,10 @@
 #   bash scripts/pmc_passes.sh gpurun_out/pmc
 set -u
 OUT=${1:-gpurun_out/pmc}
-mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p "$OUT"
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export TMPDIR=/tmp
+cd "$ROOT"
 export DC_STREAMS=1
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES"; do
   tag=$(echo $pass | cut -d' ' -f1)

@@ -71,6 +71,26 @@ def main():
             r['hbm_GBs'], 100 * r['hbm_frac_of_8TBs'], '-' if not r['mfma_util'] else '%.0f %%' % (100 * r['mfma_util'])))
     if '--json' in sys.argv:
         json.dump(rows, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1)
+    if '--traffic' in sys.argv:
+        # profiles/pmc_traffic.json: what bench.py's roofline.traffic reports for the dominant kernel, stamped with the
+        # fingerprint of the kernel source it was measured on (bench.py reports null when the source has changed since)
+        import os
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+        import bench
+        kname = bench.KernelTimer.KERNELS['f16x3'][0]
+        r = [r for r in rows if r['kernel'].replace(' ', '') == kname.replace(' ', '')]
+        if not r:
+            raise SystemExit('kernel %s not in the trace' % kname)
+        r = r[0]
+        out = dict(kernel=kname, kernel_source_sha=bench.kernel_source_sha(),
+                   bytes_per_launch=int((r['fetch_MB'] + r['write_MB']) * 1e6), fetch_bytes_per_launch=int(r['fetch_MB'] * 1e6),
+                   write_bytes_per_launch=int(r['write_MB'] * 1e6), launches=r['launches'], mean_us=r['mean_us'],
+                   mfma_busy_frac=r['mfma_util'],
+                   method='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (scripts/pmc_passes.sh); KiB counters; '
+                          'FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md '
+                          'section HBM); WRITE_SIZE as is',
+                   source=root)
+        json.dump(out, open(sys.argv[sys.argv.index('--traffic') + 1], 'w'), indent=1)
 
 
 if __name__ == '__main__':

@@ -32,9 +32,9 @@ def main():
         eng.backward()
         parallel.all_reduce_sum(eng.gflat)
         parallel.all_reduce_sum(sums)
-        eng.gflat.mul_(1.0 / world)
         torch.cuda.synchronize()
-        res[mode] = (p, float(sums[0].item()) / (NG * H * W), eng.grads(), eng.get_weights())
+        G = {k: [g / world for g in v] for k, v in eng.grads().items()}     # what Adam's grad_scale = 1/world applies
+        res[mode] = (p, float(sums[0].item()) / (NG * H * W), G, eng.get_weights())
     if rank == 0:
         orc = on.UNetOracle(Wt, nfb)
         loss_ref, p_ref, G_ref, _ = orc.loss_and_grads(x, y, masks)
@@ -43,7 +43,19 @@ def main():
         fr = np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(G_ref[n]) if not (j == 1 and n != 'out')])
         pl, lossl, Gl, _ = res['local']
         fl = np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(Gl[n]) if not (j == 1 and n != 'out')]).astype(np.float64)
+        # 'local' mode = G independent shard steps (each shard its own BatchNorm statistics), gradients averaged
+        gs, ls, ps = [], [], []
+        for r in range(world):
+            s_r = parallel.shard_slice(NG, r, world)
+            l_r, p_r, G_r, _ = on.UNetOracle(Wt, nfb).loss_and_grads(x[s_r], y[s_r], {k: v[s_r] for k, v in masks.items()})
+            gs.append(np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(G_r[n]) if not (j == 1 and n != 'out')]))
+            ls.append(l_r)
+            ps.append(p_r)
+        fs = np.mean(gs, 0)
         out = dict(world=world,
+                   local_vs_shards_p_err=float(np.abs(pl - ps[0]).max()),
+                   local_vs_shards_loss_err=abs(lossl - float(np.mean(ls))),
+                   local_vs_shards_grad_rel=float(np.linalg.norm(fl - fs) / np.linalg.norm(fs)),
                    p_err=float(np.abs(p - p_ref[sl]).max()), loss_err=abs(loss - loss_ref),
                    grad_cos=float(fg.dot(fr) / (np.linalg.norm(fg) * np.linalg.norm(fr))),
                    grad_rel=float(np.linalg.norm(fg - fr) / np.linalg.norm(fr)),

@@ -159,6 +159,22 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'summaries.npz'), series_mean=mean_img, masks_raw=msk,
                         name=np.array('neurofinder.99.99'),
                         summ_series=U._summarize_series('fake.hdf5'), summ_mask=U._summarize_mask('fake.hdf5'))
+    # (vi) _summarize_mask on crowded random stacks (many touching / overlapping / diagonal seams): pins the
+    # order-dependent sequential deletion (unet_2d_summary.py:275-284) far beyond the 6-neuron case above
+    rnd = {}
+    for case, (n, hh, ww, rmax, seed) in enumerate([(40, 72, 80, 6, 11), (90, 96, 96, 5, 12), (25, 48, 64, 9, 13)]):
+        rs = np.random.RandomState(seed)
+        msk = np.zeros((n, hh, ww), np.int8)
+        gy, gx = np.mgrid[:hh, :ww]
+        for z in range(n):
+            cy, cx = rs.randint(0, hh), rs.randint(0, ww)
+            ry, rx = rs.randint(2, rmax + 1), rs.randint(2, rmax + 1)
+            msk[z] = (((gy - cy) / ry) ** 2 + ((gx - cx) / rx) ** 2 <= 1.0)
+        h5py.File.store['rand%d.hdf5' % case] = {'masks/raw': msk, 'name': 'rand%d' % case}
+        rnd['masks_raw_%d' % case] = np.packbits(msk.astype(np.uint8), axis=None)
+        rnd['shape_%d' % case] = np.array(msk.shape)
+        rnd['summ_mask_%d' % case] = U._summarize_mask('rand%d.hdf5' % case).astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, 'summaries_rand.npz'), **rnd)
     print('wrote', sorted(f for f in os.listdir(OUT) if f.endswith('.npz')))
 
 

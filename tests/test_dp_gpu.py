@@ -1,0 +1,82 @@
+"""Batch-sharded data parallelism on the GPU.  The test box has ONE GPU: ranks share it over gloo
+(DC_DIST_BACKEND=gloo; the collective calls are the ones RCCL serves on a multi-GPU node)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _run_ranks(script, out, port):
+    env = dict(os.environ, DC_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(HERE, script), out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return json.load(open(out))
+
+
+def test_local_mode_step_equals_independent_shards(tmp_path):
+    res = _run_ranks('_dp_step_worker.py', str(tmp_path / 'res.json'), 29541)
+    print(res)
+    assert res['world'] == 2
+    assert res['loss_err'] < 1e-4 and res['grad_rel'] < 0.05, res
+    # three overlapped all-reduces of contiguous ranges == one all-reduce of the flat gradient, bit for bit
+    assert res['buckets_bitwise_grad'] and res['buckets_bitwise_params'], res
+    assert res['seeds_distinct'] and res['rng_same'], res
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (what the driver runs) starts its own rank processes and
+    prints ONE JSON line for the 2-rank job."""
+    env = dict(os.environ, DC_DIST_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['scaling'] == 'weak'
+    assert out['value'] > 0 and out['allreduce_ms'] > 0 and out['allreduce_bytes'] == 4 * 7766402
+    assert out['config']['shared_gpus'] is True and np.isfinite(out['config']['loss'])
+
+
+def test_shard_dropout_seed_reproduces_single_device_masks():
+    """RNG dropout under data parallelism: rank r's shard with the offset seed gets the keep-bits ONE device draws for the
+    same elements of the global batch (common.h dc_hash32: an element-index offset is a seed offset)."""
+    from deep_calcium_amd import parallel
+    from deep_calcium_amd._lib import lib
+    L = lib()
+    N, h, w, C = 4, 8, 8, 16
+    pix = N * h * w
+    dev = 'cuda'
+    z = torch.ones(N, h, w, C, device=dev)
+    mean, beta = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    invstd, gamma = torch.ones(C, device=dev), torch.ones(C, device=dev)
+    seed, keep = 0x5eed1234abcd, 0.5
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(zz, s):
+        out = torch.empty_like(zz)
+        L.dc_bn_relu_drop_fwd(zz.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, keep, s,
+                              out.data_ptr(), C, zz.numel() // C, C, st)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    full = run(z, seed)
+    assert 0.3 < (full > 0).mean() < 0.7
+    world = 2
+    per = N // world
+    for r in range(world):
+        part = run(z[r * per:(r + 1) * per].contiguous(), parallel.shard_drop_seed(seed, per * h * w * C, r))
+        assert np.array_equal(part, full[r * per:(r + 1) * per])
+    assert not np.array_equal(run(z[per:].contiguous(), seed), full[per:])      # without the offset the masks repeat

@@ -25,3 +25,7 @@ def test_sync_bn_two_ranks_equal_one_device_batch(tmp_path):
     assert res['p_err'] < 1e-4 and res['loss_err'] < 1e-4, res
     assert res['grad_cos'] > 0.9995 and res['grad_rel'] < 0.05, res
     assert res['local_p_err'] > 1e-3 and res['local_grad_rel'] > 0.05, res      # the two modes really differ
+    # 'local' mode == the oracle run as independent shards with averaged gradients
+    assert res['local_vs_shards_p_err'] < 1e-4 and res['local_vs_shards_loss_err'] < 1e-4, res
+    assert res['local_vs_shards_grad_rel'] < 0.05, res
+    print(res)
