@@ -41,10 +41,9 @@ class KernelTimer(object):
         'f16x3': ('igemm_f16x3_kernel<3,3,1,1,32,4,2,2,16>', PEAK_FP16_MFMA_TFLOPS, 3),
         'f32': ('igemm_kernel<3,3,1,1,32,4,2,2,16>', PEAK_FP32_MFMA_TFLOPS, 1),
     }
-    # name -> index of N in the argument list (N, H, W, Cin, Cout follow), and which count is the column count
-    SITES = {'dc_conv3x3_fwd': (9, 'cout'), 'dc_conv3x3_dgrad': (3, 'cin'),
-             'dc_conv3x3_fwd_f16x3': (10, 'cout'), 'dc_conv3x3_dgrad_f16x3': (4, 'cin'),
-             'dc_conv3x3_fwd_bnin_f16x3': (11, 'cout')}
+    # entry point -> which channel count is the GEMM column count (every one ends with N, H, W, Cin, Cout, stream)
+    SITES = {'dc_conv3x3_fwd': 'cout', 'dc_conv3x3_dgrad': 'cin', 'dc_conv3x3_fwd_f16x3': 'cout',
+             'dc_conv3x3_dgrad_f16x3': 'cin', 'dc_conv3x3_fwd_bnin_f16x3': 'cout'}
 
     def __init__(self, lib):
         self._lib = lib
@@ -55,12 +54,12 @@ class KernelTimer(object):
         fn = getattr(self._lib, name)
         if name not in self.SITES:
             return fn
-        i0, colkey = self.SITES[name]
+        colkey = self.SITES[name]
 
         def wrapped(*args):
             if not self.enabled:
                 return fn(*args)
-            N, Hh, Ww, Cin, Cout = args[i0:i0 + 5]
+            N, Hh, Ww, Cin, Cout = args[-6:-1]
             ncols = Cout if colkey == 'cout' else Cin
             if not (Ww > 16 and ncols > 32):
                 return fn(*args)

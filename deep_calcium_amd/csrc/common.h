@@ -63,6 +63,69 @@ __host__ __device__ __forceinline__ void dc_bn_affine(float mu, float is, float 
   sh = __builtin_fmaf(-mu, sc, be);
 }
 
+// ---- per-channel moments that survive |mean| >> sigma ------------------------------------------------------------
+// BatchNorm statistics leave the convolution epilogues as per-(tile, channel) partials.  Summing v and v*v in fp32
+// loses the variance once |mean|/sigma reaches ~1e3 (catastrophic cancellation in E[v^2] - E[v]^2).  Instead every lane
+// accumulates SHIFTED sums around its own first value K (d = v - K: s1 = sum d, s2 = sum d^2), turns them into
+// (count, mean, M2 = sum (v - mean)^2), and the lanes / waves of a tile are merged with Chan's parallel update.  The
+// tile's result is stored as DOUBLES (S = n*mean, Q = M2 + S*mean = sum v^2): the finalize kernels keep summing
+// (S, Q) over tiles -- in double, where the cancellation is harmless -- so their interface is unchanged.
+struct DcMoments { float n, mean, m2; };
+__device__ __forceinline__ DcMoments dc_moments_from_shifted(float n, float K, float s1, float s2) {
+  DcMoments r;
+  r.n = n;
+  const float ms = n > 0.f ? s1 / n : 0.f;
+  r.mean = n > 0.f ? K + ms : 0.f;
+  r.m2 = n > 0.f ? fmaxf(__builtin_fmaf(-s1, ms, s2), 0.f) : 0.f;
+  return r;
+}
+__device__ __forceinline__ DcMoments dc_moments_merge(const DcMoments a, const DcMoments b) {
+  DcMoments r;
+  r.n = a.n + b.n;
+  const float w = r.n > 0.f ? b.n / r.n : 0.f;
+  const float d = b.mean - a.mean;
+  r.mean = __builtin_fmaf(d, w, a.mean);
+  r.m2 = a.m2 + b.m2 + d * d * a.n * w;
+  return r;
+}
+__device__ __forceinline__ void dc_moments_store(double* dst, const DcMoments m) {
+  const double S = (double)m.n * (double)m.mean;
+  dst[0] = S;
+  dst[1] = (double)m.m2 + S * (double)m.mean;
+}
+
+// ---- fp16 range guard of the split-fp16 (f16x3) contractions -----------------------------------------------------
+// The fp16 hi/lo split keeps fp32-grade accuracy only while the operand sits inside fp16's exponent range: above
+// 65504 hi becomes inf, far below 2^-3 the lo term is an fp16 subnormal.  Every f16x3 consumer therefore multiplies
+// its activation operand by an exact POWER OF TWO derived from a per-channel magnitude bound of that tensor
+// (`abound[c]`, written by the producing layer: |gamma|*sqrt(count) + |beta| for a training-mode BatchNorm output --
+// |xhat| <= sqrt(count - 1) holds for ANY data -- or the measured max|a| in inference) and undoes it in the epilogue:
+// max_c abound[c] lands in [2^14, 2^15).  Block-cooperative: every thread of the block calls it (two barriers);
+// tmp = 16 floats of LDS that nothing else uses until the call returns.  abound == NULL: scale 1.
+__device__ __forceinline__ float dc_pow2_guard(float amax) {
+  const unsigned e = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;     // biased exponent of the bound
+  if (amax <= 0.f || e < 14u || e == 0xffu) return 1.f;                     // zero / denormal / inf / nan: leave alone
+  return __builtin_bit_cast(float, (268u - e) << 23);                       // 2^(14 - floor(log2 amax))
+}
+__device__ __forceinline__ float dc_block_guard_scale(const float* __restrict__ abound, int n, float* tmp) {
+  if (abound == nullptr) return 1.f;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(abound[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) tmp[wave] = m;
+  __syncthreads();
+  m = tmp[0];
+  for (int w = 1; w < nw; ++w) m = fmaxf(m, tmp[w]);
+  __syncthreads();
+  return dc_pow2_guard(m);
+}
+// running max |v| per channel (inference: the measured bound of a folded-BN activation); order-independent
+__device__ __forceinline__ void dc_atomic_absmax(float* dst, float v) {
+  atomicMax(reinterpret_cast<unsigned*>(dst), __builtin_bit_cast(unsigned, fabsf(v)));
+}
+
 // Buffer descriptor from provably wave-uniform inputs (readfirstlane), so hipcc does not wrap every buffer op in a
 // waterfall loop.  Out-of-range offsets read zeros / drop stores (hardware bounds check on num_records = bytes).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t dc_make_rsrc(const void* ptr, unsigned bytes) {

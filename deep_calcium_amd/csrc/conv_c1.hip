@@ -10,17 +10,78 @@ struct C1Params {
   const float* w;  // HWIO (3,3,1,Cout)
   const float* bias;
   float* z;
-  float* stats;
+  double* stats;
   const float* scale;
   const float* shift;
+  float* absmax;   // nullable: per-channel max |output| (atomic max), the next layer's fp16 range-guard bound
   int N, H, W, Cout, relu;
   long pixels, zLd;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// Per-thread BatchNorm partials as SHIFTED sums around the thread's first value (common.h DcMoments), merged over the
+// block's pixel lanes with Chan's update and stored as doubles (sum v, sum v^2) per (block, channel).
+struct C1Acc {
+  f32x4 K, s1, s2, amax;
+  float n;
+  __device__ __forceinline__ void init() {
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    K = z4; s1 = z4; s2 = z4; amax = z4; n = 0.f;
+  }
+  __device__ __forceinline__ void add(const f32x4& v) {
+    if (n == 0.f) K = v;
+    const f32x4 d = v - K;
+    s1 += d;
+    s2 += d * d;
+    n += 1.f;
+  }
+  __device__ __forceinline__ void add_shifted(const f32x4& v) {      // K was set up front
+    const f32x4 d = v - K;
+    s1 += d;
+    s2 += d * d;
+    n += 1.f;
+  }
+  __device__ __forceinline__ void track(const f32x4& v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) amax[e] = fmaxf(amax[e], fabsf(v[e]));
+  }
+};
+__device__ __forceinline__ void c1_finish(const C1Params& p, const C1Acc& a, int tid, int q, int pl, int C4, int PPB) {
+  __shared__ DcMoments sm[4][256];
+  if (p.absmax) {
+    // pixel lanes of one channel quad sit C4 threads apart: fold them through LDS, one atomic per channel per block
+    float* fm = reinterpret_cast<float*>(&sm[0][0]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) fm[e * 256 + tid] = a.amax[e];
+    __syncthreads();
+    if (pl == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float m = a.amax[e];
+        for (int k = 1; k < PPB; ++k) m = fmaxf(m, fm[e * 256 + k * C4 + q]);
+        dc_atomic_absmax(p.absmax + 4 * q + e, m);
+      }
+    }
+    __syncthreads();
+  }
+  if (p.stats) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[e][tid] = dc_moments_from_shifted(a.n, a.K[e], a.s1[e], a.s2[e]);
+    __syncthreads();
+    if (pl == 0) {
+      double* dst = p.stats + ((long)blockIdx.x * p.Cout + 4 * q) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        DcMoments m = sm[e][q];
+        for (int k = 1; k < PPB; ++k) m = dc_moments_merge(m, sm[e][k * C4 + q]);
+        dc_moments_store(dst + 2 * e, m);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(C1Params p) {
-  __shared__ f32x4 sm1[256], sm2[256];
   const int C4 = p.Cout >> 2, PPB = 256 / C4;
   const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
   f32x4 w[9];
@@ -30,7 +91,8 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(C1Params p) {
   const f32x4 b = p.bias ? ld4(p.bias + 4 * q) : z4;
   const f32x4 sc = p.scale ? ld4(p.scale + 4 * q) : one4;
   const f32x4 sh = p.shift ? ld4(p.shift + 4 * q) : z4;
-  f32x4 s1 = z4, s2 = z4;
+  C1Acc a;
+  a.init();
   const long HW = (long)p.H * p.W;
   for (long pix = (long)blockIdx.x * PPB + pl; pix < p.pixels; pix += (long)gridDim.x * PPB) {
     const long img = pix / HW;
@@ -48,31 +110,15 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(C1Params p) {
         v += xv * w[dy * 3 + dx];
       }
     }
-    s1 += v;
-    s2 += v * v;
+    a.add(v);
     if (p.scale) v = v * sc + sh;
     if (p.relu) {
       v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
     }
+    if (p.absmax) a.track(v);
     *reinterpret_cast<f32x4*>(p.z + pix * p.zLd + 4 * q) = v;
   }
-  if (p.stats) {
-    sm1[tid] = s1;
-    sm2[tid] = s2;
-    __syncthreads();
-    if (pl == 0) {
-      for (int k = 1; k < PPB; ++k) {
-        s1 += sm1[k * C4 + q];
-        s2 += sm2[k * C4 + q];
-      }
-      float* dst = p.stats + ((long)blockIdx.x * p.Cout + 4 * q) * 2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        dst[2 * e] = s1[e];
-        dst[2 * e + 1] = s2[e];
-      }
-    }
-  }
+  c1_finish(p, a, tid, q, pl, C4, PPB);
 }
 
 // dW[tap][co] partial per block = sum_p x[p+tap] * dz[p][co]
@@ -135,7 +181,6 @@ __device__ __forceinline__ void c1_window(const float* __restrict__ xi, int y, i
 }
 
 __global__ __launch_bounds__(256) void conv_c1_fwd4_kernel(C1Params p) {
-  __shared__ f32x4 sm1[256], sm2[256];
   const int C4 = p.Cout >> 2, PPB = 256 / C4;
   const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
   f32x4 w[9];
@@ -145,9 +190,27 @@ __global__ __launch_bounds__(256) void conv_c1_fwd4_kernel(C1Params p) {
   const f32x4 b = p.bias ? ld4(p.bias + 4 * q) : z4;
   const f32x4 sc = p.scale ? ld4(p.scale + 4 * q) : one4;
   const f32x4 sh = p.shift ? ld4(p.shift + 4 * q) : z4;
-  f32x4 s1 = z4, s2 = z4;
+  C1Acc a;
+  a.init();
   const int W4 = p.W >> 2, HW4 = p.H * W4;
   const int groups = (int)(p.pixels >> 2);
+  // shift of the BatchNorm partial sums = the bias + the thread's first window centre times the centre tap: one fma,
+  // no per-pixel select (any finite shift is valid; this one tracks a DC offset of the image as well as a large bias)
+  {
+    const int g0 = blockIdx.x * PPB + pl;
+    if (g0 < groups) {
+      const int img = g0 / HW4, rem = g0 - img * HW4;
+      const int y = rem / W4, x0 = (rem - y * W4) * 4;
+      const float xc = p.x[((long)img * p.H + y) * p.W + x0];
+      float ws[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ws[e] += w[t][e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a.K[e] = __builtin_fmaf(xc, ws[e], b[e]);
+    }
+  }
   for (int g = blockIdx.x * PPB + pl; g < groups; g += gridDim.x * PPB) {
     const int img = g / HW4, rem = g - img * HW4;
     const int y = rem / W4, x0 = (rem - y * W4) * 4;
@@ -161,32 +224,16 @@ __global__ __launch_bounds__(256) void conv_c1_fwd4_kernel(C1Params p) {
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) v += win[dy][i + dx] * w[dy * 3 + dx];
-      s1 += v;
-      s2 += v * v;
+      a.add_shifted(v);
       if (p.scale) v = v * sc + sh;
       if (p.relu) {
         v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
       }
+      if (p.absmax) a.track(v);
       *reinterpret_cast<f32x4*>(p.z + (pix0 + i) * p.zLd + 4 * q) = v;
     }
   }
-  if (p.stats) {
-    sm1[tid] = s1;
-    sm2[tid] = s2;
-    __syncthreads();
-    if (pl == 0) {
-      for (int k = 1; k < PPB; ++k) {
-        s1 += sm1[k * C4 + q];
-        s2 += sm2[k * C4 + q];
-      }
-      float* dst = p.stats + ((long)blockIdx.x * p.Cout + 4 * q) * 2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        dst[2 * e] = s1[e];
-        dst[2 * e + 1] = s2[e];
-      }
-    }
-  }
+  c1_finish(p, a, tid, q, pl, C4, PPB);
 }
 
 __global__ __launch_bounds__(256) void conv_c1_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ dz,
@@ -244,16 +291,16 @@ static int check_c1(const char* fn, int N, int H, int W, int Cout) {
   return DC_OK;
 }
 
-extern "C" int dc_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, float* z, long z_ld, float* stats,
-                                 const float* scale, const float* shift, int relu, int N, int H, int W, int Cout,
-                                 dc_stream_t stream) {
+extern "C" int dc_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, float* z, long z_ld, double* stats,
+                                 const float* scale, const float* shift, int relu, float* out_absmax, int N, int H,
+                                 int W, int Cout, dc_stream_t stream) {
   DC_REQUIRE(x && w && z, DC_EINVAL, "dc_conv3x3_c1_fwd: null pointer");
   DC_REQUIRE(dc_aligned16(w) && dc_aligned16(z), DC_EINVAL, "dc_conv3x3_c1_fwd: w and z must be 16-byte aligned");
   DC_REQUIRE((scale == nullptr) == (shift == nullptr), DC_EINVAL, "dc_conv3x3_c1_fwd: scale and shift go together");
   int rc = check_c1("dc_conv3x3_c1_fwd", N, H, W, Cout);
   if (rc) return rc;
   C1Params p;
-  p.x = x; p.w = w; p.bias = bias; p.z = z; p.stats = stats; p.scale = scale; p.shift = shift;
+  p.x = x; p.w = w; p.bias = bias; p.z = z; p.stats = stats; p.scale = scale; p.shift = shift; p.absmax = out_absmax;
   p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.pixels = (long)N * H * W; p.zLd = z_ld;
   DC_REQUIRE(z_ld >= Cout && z_ld % 4 == 0, DC_EINVAL, "dc_conv3x3_c1_fwd: bad z_ld");
   // same grid (= the BN-partial row count dc_conv3x3_c1_tiles reports) for both kernels

@@ -39,20 +39,25 @@ static int ew_blocks(long pixels, int C) {
 
 // ------------------------------------------------------------------------------------------------
 // BN statistics finalize: one block per channel, double accumulation over all partials.
-__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int parts, int groups,
+// abound (nullable): |gamma|*sqrt(count) + |beta| >= max |gamma*xhat + beta| for ANY data (|xhat| <= sqrt(count-1)): the
+// magnitude bound the f16x3 consumers' fp16 range guard reads (common.h dc_block_guard_scale).
+__device__ __forceinline__ float bn_abound(float gamma, float beta, double count, float inv_keep) {
+  return (fabsf(gamma) * (float)sqrt(count) + fabsf(beta)) * inv_keep;
+}
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ partial, int parts, int groups,
                                                                int C, double count, float eps, float momentum,
                                                                float* mean, float* invstd, float* mmean, float* mvar,
                                                                const float* gamma, const float* beta, float* scale,
-                                                               float* shift) {
+                                                               float* shift, float* abound) {
   __shared__ double sh1[256], sh2[256];
   const int c = blockIdx.x, tid = threadIdx.x;
   const int Ct = groups * C;
   double s1 = 0.0, s2 = 0.0;
   for (int i = tid; i < parts * groups; i += 256) {
     const int pt = i / groups, g = i - pt * groups;
-    const float* src = partial + ((long)pt * Ct + g * C + c) * 2;
-    s1 += (double)src[0];
-    s2 += (double)src[1];
+    const double* src = partial + ((long)pt * Ct + g * C + c) * 2;
+    s1 += src[0];
+    s2 += src[1];
   }
   sh1[tid] = s1; sh2[tid] = s2;
   __syncthreads();
@@ -68,6 +73,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
     mean[c] = muf;
     invstd[c] = isf;
     if (scale) dc_bn_affine(muf, isf, gamma[c], beta[c], scale[c], shift[c]);
+    if (abound) abound[c] = bn_abound(gamma[c], beta[c], count, 1.f);
     if (momentum >= 0.f && mmean && mvar) {
       mmean[c] = (float)((double)mmean[c] * momentum + mu * (1.0 - (double)momentum));
       mvar[c] = (float)((double)mvar[c] * momentum + var * (1.0 - (double)momentum));
@@ -75,34 +81,34 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
   }
 }
 
-extern "C" int dc_bn_stats_finalize(const float* partial, int parts, int groups, int C, double count, float eps,
+extern "C" int dc_bn_stats_finalize(const double* partial, int parts, int groups, int C, double count, float eps,
                                     float momentum, float* mean, float* invstd, float* moving_mean, float* moving_var,
                                     dc_stream_t stream) {
   DC_REQUIRE(partial && mean && invstd, DC_EINVAL, "dc_bn_stats_finalize: null pointer");
   DC_REQUIRE(parts > 0 && groups > 0 && C > 0 && count > 0, DC_EINVAL, "dc_bn_stats_finalize: bad sizes");
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C,
                      count, eps, momentum, mean, invstd, moving_mean, moving_var, (const float*)nullptr,
-                     (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                     (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   DC_CHECK_LAUNCH("dc_bn_stats_finalize");
   return DC_OK;
 }
 
-extern "C" int dc_bn_stats_finalize_affine(const float* partial, int parts, int groups, int C, double count, float eps,
+extern "C" int dc_bn_stats_finalize_affine(const double* partial, int parts, int groups, int C, double count, float eps,
                                            float momentum, float* mean, float* invstd, float* moving_mean,
                                            float* moving_var, const float* gamma, const float* beta, float* scale,
-                                           float* shift, dc_stream_t stream) {
+                                           float* shift, float* abound, dc_stream_t stream) {
   DC_REQUIRE(partial && mean && invstd && gamma && beta && scale && shift, DC_EINVAL,
              "dc_bn_stats_finalize_affine: null pointer");
   DC_REQUIRE(parts > 0 && groups > 0 && C > 0 && count > 0, DC_EINVAL, "dc_bn_stats_finalize_affine: bad sizes");
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C,
-                     count, eps, momentum, mean, invstd, moving_mean, moving_var, gamma, beta, scale, shift);
+                     count, eps, momentum, mean, invstd, moving_mean, moving_var, gamma, beta, scale, shift, abound);
   DC_CHECK_LAUNCH("dc_bn_stats_finalize_affine");
   return DC_OK;
 }
 
 // ---- synchronised BatchNorm (data-parallel 'sync' mode): the per-channel sums leave the device-local finalize so that
 // they can be all-reduced over the ranks: reduce (partials -> double sums) | all-reduce | finalize from sums.
-__global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __restrict__ partial, int parts, int groups,
+__global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const double* __restrict__ partial, int parts, int groups,
                                                              int C, double* __restrict__ sums) {
   __shared__ double sh1[256], sh2[256];
   const int c = blockIdx.x, tid = threadIdx.x;
@@ -110,9 +116,9 @@ __global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __res
   double s1 = 0.0, s2 = 0.0;
   for (int i = tid; i < parts * groups; i += 256) {
     const int pt = i / groups, g = i - pt * groups;
-    const float* src = partial + ((long)pt * Ct + g * C + c) * 2;
-    s1 += (double)src[0];
-    s2 += (double)src[1];
+    const double* src = partial + ((long)pt * Ct + g * C + c) * 2;
+    s1 += src[0];
+    s2 += src[1];
   }
   sh1[tid] = s1; sh2[tid] = s2;
   __syncthreads();
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __res
   }
   if (tid == 0) { sums[2 * c] = sh1[0]; sums[2 * c + 1] = sh2[0]; }
 }
-extern "C" int dc_bn_stats_reduce(const float* partial, int parts, int groups, int C, double* sums, dc_stream_t stream) {
+extern "C" int dc_bn_stats_reduce(const double* partial, int parts, int groups, int C, double* sums, dc_stream_t stream) {
   DC_REQUIRE(partial && sums && parts > 0 && groups > 0 && C > 0, DC_EINVAL, "dc_bn_stats_reduce: bad arguments");
   hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C, sums);
   DC_CHECK_LAUNCH("dc_bn_stats_reduce");
@@ -130,7 +136,8 @@ extern "C" int dc_bn_stats_reduce(const float* partial, int parts, int groups, i
 }
 __global__ void bn_stats_finalize_sums_kernel(const double* __restrict__ sums, int C, double count, float eps,
                                               float momentum, float* mean, float* invstd, float* mmean, float* mvar,
-                                              const float* gamma, const float* beta, float* scale, float* shift) {
+                                              const float* gamma, const float* beta, float* scale, float* shift,
+                                              float* abound) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double mu = sums[2 * c] / count;
@@ -140,6 +147,7 @@ __global__ void bn_stats_finalize_sums_kernel(const double* __restrict__ sums, i
   mean[c] = muf;
   invstd[c] = isf;
   if (scale) dc_bn_affine(muf, isf, gamma[c], beta[c], scale[c], shift[c]);
+  if (abound) abound[c] = bn_abound(gamma[c], beta[c], count, 1.f);
   if (momentum >= 0.f && mmean && mvar) {
     mmean[c] = (float)((double)mmean[c] * momentum + mu * (1.0 - (double)momentum));
     mvar[c] = (float)((double)mvar[c] * momentum + var * (1.0 - (double)momentum));
@@ -147,11 +155,13 @@ __global__ void bn_stats_finalize_sums_kernel(const double* __restrict__ sums, i
 }
 extern "C" int dc_bn_stats_finalize_sums(const double* sums, int C, double count, float eps, float momentum, float* mean,
                                          float* invstd, float* moving_mean, float* moving_var, const float* gamma,
-                                         const float* beta, float* scale, float* shift, dc_stream_t stream) {
+                                         const float* beta, float* scale, float* shift, float* abound,
+                                         dc_stream_t stream) {
   DC_REQUIRE(sums && mean && invstd && C > 0 && count > 0, DC_EINVAL, "dc_bn_stats_finalize_sums: bad arguments");
   DC_REQUIRE(!scale || (gamma && beta && shift), DC_EINVAL, "dc_bn_stats_finalize_sums: scale needs gamma, beta and shift");
+  DC_REQUIRE(!abound || (gamma && beta), DC_EINVAL, "dc_bn_stats_finalize_sums: abound needs gamma and beta");
   hipLaunchKernelGGL(bn_stats_finalize_sums_kernel, dim3(dc_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, C,
-                     count, eps, momentum, mean, invstd, moving_mean, moving_var, gamma, beta, scale, shift);
+                     count, eps, momentum, mean, invstd, moving_mean, moving_var, gamma, beta, scale, shift, abound);
   DC_CHECK_LAUNCH("dc_bn_stats_finalize_sums");
   return DC_OK;
 }
@@ -209,6 +219,10 @@ __global__ __launch_bounds__(256) void bn_relu_drop_fwd_kernel(BnParams p) {
   const float inv_keep = drop ? 1.f / p.keep : 1.f;
   f32x4 sc, sh;
   bn_affine4(mu, is, ga, be, sc, sh);
+  if (p.partial && blockIdx.x == 0 && pl == 0) {       // p.partial doubles as the range-guard bound output here
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p.partial[4 * q + e] = bn_abound(ga[e], be[e], p.count, inv_keep);
+  }
   for (long pix = (long)blockIdx.x * PPB + pl; pix < p.pixels; pix += (long)gridDim.x * PPB) {
     const long elem = pix * p.C + 4 * q;
     const f32x4 z = ld4(p.z + elem);
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(256) void bn_relu_drop_fwd_kernel(BnParams p) {
 
 extern "C" int dc_bn_relu_drop_fwd(const float* z, const float* mean, const float* invstd, const float* gamma,
                                    const float* beta, const uint8_t* mask, float keep, uint64_t seed, float* out,
-                                   long out_ld, long pixels, int C, dc_stream_t stream) {
+                                   long out_ld, long pixels, int C, double count, float* abound, dc_stream_t stream) {
   DC_REQUIRE(z && mean && invstd && gamma && beta && out, DC_EINVAL, "dc_bn_relu_drop_fwd: null pointer");
   DC_REQUIRE(pixels > 0 && out_ld >= C && out_ld % 4 == 0 && keep > 0.f, DC_EINVAL, "dc_bn_relu_drop_fwd: bad sizes");
   int rc = chan_check("dc_bn_relu_drop_fwd", C);
@@ -230,6 +244,7 @@ extern "C" int dc_bn_relu_drop_fwd(const float* z, const float* mean, const floa
   BnParams p{};
   p.z = z; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.mask = mask; p.keep = keep;
   p.seed = seed; p.out = out; p.out_ld = out_ld; p.pixels = pixels; p.C = C;
+  p.partial = abound; p.count = count > 0 ? count : (double)pixels;
   hipLaunchKernelGGL(bn_relu_drop_fwd_kernel, dim3(ew_blocks(pixels, C)), dim3(256), 0, (hipStream_t)stream, p);
   DC_CHECK_LAUNCH("dc_bn_relu_drop_fwd");
   return DC_OK;
@@ -659,11 +674,14 @@ extern "C" int dc_maxpool2x2_bwd_bnred(const float* dy, const uint8_t* idx, cons
 // The dropout element index is that of the dense up-sampled tensor.
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                           long out_ld, const uint8_t* __restrict__ mask, float keep,
-                                                          uint64_t seed, int N, int H, int W, int C) {
+                                                          uint64_t seed, int N, int H, int W, int C,
+                                                          const float* __restrict__ ab_in, float* __restrict__ ab_out) {
   const int C4 = C >> 2;
   const long total = (long)N * 4 * H * W * C4;
   const bool drop = keep < 1.f;
   const float inv_keep = drop ? 1.f / keep : 1.f;
+  if (ab_out && blockIdx.x == 0)       // range-guard bound of the up-sampled tensor = the source's, times 1/keep
+    for (int c = threadIdx.x; c < C; c += 256) ab_out[c] = ab_in[c] * inv_keep;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
     const int q = (int)(i % C4);
     long r = i / C4;
@@ -722,13 +740,15 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
 }
 
 extern "C" int dc_upsample2x_drop_fwd(const float* in, float* out, long out_ld, const uint8_t* mask, float keep,
-                                      uint64_t seed, int N, int H, int W, int C, dc_stream_t stream) {
+                                      uint64_t seed, const float* abound_in, float* abound_out, int N, int H, int W, int C,
+                                      dc_stream_t stream) {
+  DC_REQUIRE((abound_in == nullptr) == (abound_out == nullptr), DC_EINVAL, "dc_upsample2x_drop_fwd: abound_in and abound_out go together");
   DC_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0 && out_ld >= C && out_ld % 4 == 0 && keep > 0.f,
              DC_EINVAL, "dc_upsample2x_drop_fwd: bad arguments");
   const long total = (long)N * 4 * H * W * (C / 4);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(upsample_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, out_ld, mask, keep,
-                     seed, N, H, W, C);
+                     seed, N, H, W, C, abound_in, abound_out);
   DC_CHECK_LAUNCH("dc_upsample2x_drop_fwd");
   return DC_OK;
 }

@@ -7,7 +7,7 @@ struct IgemmParams {
   const float* wp;
   const float* bias;
   float* out;
-  float* stats;
+  double* stats;  // per-(tile, column) BatchNorm partials (sum v, sum v^2) as doubles, see DcMoments (common.h)
   const float* scale;
   const float* shift;
   int N, Hin, Win, Cin;
@@ -22,5 +22,11 @@ struct IgemmParams {
   // pre-BN tensor z and the operand relu(fmaf(z, inSc[c], inSh[c])) is formed while it is staged (padding stays 0).
   const float* inSc;
   const float* inSh;
+  // f16x3 only: fp16 range guard (common.h).  inAbound: per-input-channel magnitude bound of the activation operand
+  // (Cin floats, nullable -> scale 1).  The packed weights carry their own power-of-two scale in a 16-byte trailer
+  // (dc_pack_weights_f16x3).  outAbsmax (nullable, biasMod floats): the epilogue folds max |output| per channel into it
+  // (atomic max; the caller zeroes it) -- the bound the NEXT layer's guard reads in inference.
+  const float* inAbound;
+  float* outAbsmax;
 };
 

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 
   // ---- epilogue ---------------------------------------------------------------------------------
   // C/D map of the 32x32 MFMA: col = lane&31 (column n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel m).
-  float* red = reinterpret_cast<float*>(smem);  // [4 waves][NB][32][2], LDS is free after the last barrier
+  DcMoments* red = reinterpret_cast<DcMoments*>(smem);  // [4 waves][NB][32], LDS is free after the last barrier
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int n = n0 + (wave_n * NB + nb) * 32 + li;
@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     const float bv = (p.bias && n_ok) ? p.bias[n % p.biasMod] : 0.f;
     const float sc = (p.scale && n_ok) ? p.scale[n % p.biasMod] : 1.f;
     const float sh = (p.shift && n_ok) ? p.shift[n % p.biasMod] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    const float K = acc[0][nb][0] + bv;      // shifted sums around the lane's first value (common.h DcMoments)
+    float s1 = 0.f, s2 = 0.f, cnt = 0.f;
     long obase;
     long ostride_y, ostride_x;  // in floats
     if (p.scatterCo > 0) {
@@ -206,8 +207,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         const bool ok = n_ok && oy < p.Hout && ox < p.Wout;
         float v = acc[mb][nb][r] + bv;
         if (ok) {
-          s1 += v;
-          s2 += v * v;
+          const float d = v - K;
+          s1 += d;
+          s2 += d * d;
+          cnt += 1.f;
           if (p.scale) v = v * sc + sh;
           if (p.relu) v = fmaxf(v, 0.f);
           p.out[obase + oy * ostride_y + ox * ostride_x] = v;
@@ -215,12 +218,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
       }
     }
     if (p.stats) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (h == 0) {
-        red[((wave * NB + nb) * 32 + li) * 2 + 0] = s1;
-        red[((wave * NB + nb) * 32 + li) * 2 + 1] = s2;
-      }
+      DcMoments m = dc_moments_from_shifted(cnt, K, s1, s2);
+      DcMoments o;
+      o.n = __shfl_xor(m.n, 32); o.mean = __shfl_xor(m.mean, 32); o.m2 = __shfl_xor(m.m2, 32);
+      m = dc_moments_merge(m, o);
+      if (h == 0) red[(wave * NB + nb) * 32 + li] = m;
     }
   }
   if (p.stats) {
@@ -229,19 +231,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     if (tid < Cfg::WAVES_N * NB * 32) {
       const int wn = tid / (NB * 32), rem = tid % (NB * 32);
       const int nb = rem / 32, l = rem % 32;
-      float s1 = 0.f, s2 = 0.f;
+      DcMoments m = red[((wn * WAVES_M) * NB + nb) * 32 + l];
 #pragma unroll
-      for (int wm = 0; wm < WAVES_M; ++wm) {
-        const int w = wn * WAVES_M + wm;
-        s1 += red[((w * NB + nb) * 32 + l) * 2 + 0];
-        s2 += red[((w * NB + nb) * 32 + l) * 2 + 1];
-      }
+      for (int wm = 1; wm < WAVES_M; ++wm) m = dc_moments_merge(m, red[((wn * WAVES_M + wm) * NB + nb) * 32 + l]);
       const int n = n0 + (wn * NB + nb) * 32 + l;
-      if (n < p.Ncols) {
-        float* dst = p.stats + ((long)tile_id * p.Ncols + n) * 2;
-        dst[0] = s1;
-        dst[1] = s2;
-      }
+      if (n < p.Ncols) dc_moments_store(p.stats + ((long)tile_id * p.Ncols + n) * 2, m);
     }
   }
 }
@@ -348,7 +342,7 @@ static int check_conv_args(const char* fn, const void* a, const void* b, const v
 
 extern "C" int dc_conv3x3_tiles(int N, int H, int W, int Cout) { return conv3x3_tiles_impl(N, H, W, Cout); }
 
-extern "C" int dc_conv3x3_fwd(const float* x, const float* wp, const float* bias, float* z, long z_ld, float* stats,
+extern "C" int dc_conv3x3_fwd(const float* x, const float* wp, const float* bias, float* z, long z_ld, double* stats,
                               const float* scale, const float* shift, int relu, int N, int H, int W, int Cin, int Cout,
                               dc_stream_t stream) {
   int rc = check_conv_args("dc_conv3x3_fwd", x, wp, z, N, H, W, Cin, Cout);
@@ -375,7 +369,7 @@ extern "C" int dc_conv3x3_dgrad(const float* dz, const float* wp, float* dx, int
 
 extern "C" int dc_convT2x2_tiles(int N, int H, int W, int Cout) { return convT_tiles_impl(N, H, W, 4 * Cout); }
 
-extern "C" int dc_convT2x2_fwd(const float* x, const float* wp, const float* bias, float* z, long z_ld, float* stats,
+extern "C" int dc_convT2x2_fwd(const float* x, const float* wp, const float* bias, float* z, long z_ld, double* stats,
                                const float* scale, const float* shift, int relu, int N, int H, int W, int Cin,
                                int Cout, dc_stream_t stream) {
   int rc = check_conv_args("dc_convT2x2_fwd", x, wp, z, N, H, W, Cin, Cout);

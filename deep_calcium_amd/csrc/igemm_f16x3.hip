@@ -7,9 +7,11 @@
 // and accumulates   a_hi*b_hi + a_hi*b_lo + a_lo*b_hi   in the fp32 accumulator (the dropped lo*lo term is
 // 2^-22 relative): 3 MFMAs replace 8, i.e. 16/3 = 5.3x the fp32 matrix rate at ~4x fp32's rounding noise,
 // well inside the 1e-4 parity budget (tests/test_hip_ops.py, tests/test_engine_gpu.py run both paths).
-// fp16's narrow exponent range is handled with a per-tensor POWER-OF-TWO input scale (exact in fp32) read from
-// device memory: 1 for forward activations (O(1) after BatchNorm), 2^k for gradients (their 1/(N*H*W) factor
-// would otherwise underflow), undone exactly in the epilogue.
+// fp16's narrow exponent range is handled with per-tensor POWER-OF-TWO scales (exact in fp32), undone exactly in the
+// epilogue: gradients bring theirs as a device scalar (dc_bn_bwd_apply_finalize: their 1/(N*H*W) factor would otherwise
+// underflow), forward activations get one from the per-channel magnitude bound of the producing layer (common.h
+// dc_block_guard_scale: no input can reach inf), and the packed weights carry the scale that brought max|w| into
+// [2^10, 2^11) in a 16-byte trailer (dc_pack_weights_f16x3): small-magnitude kernels keep their 22-bit split.
 //
 // Structure = the fp32 kernel's (igemm_conv.hip): halo'd input patch staged once per 16-channel chunk, taps are
 // shifted ds_read_b128 windows of the same LDS patch, channel on the lane in the epilogue.  Differences:
@@ -94,16 +96,12 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
   const int Cin8 = (p.Cin + 7) >> 3;
-  const float in_scale = p.inScale ? *p.inScale : 1.f;
+  const float w_scale = p.wp[(long)TAPS * Cin8 * 2 * p.Ncols * 4];       // trailer of the packed weights
   // BatchNorm + ReLU on load (non-materialised input activation): the per-channel (scale, shift) pairs sit behind the
   // operand images in LDS; the staging pass reads its 4 channels' pairs once per chunk.
   const bool bnin = p.inSc != nullptr;
   float* lds_sc = reinterpret_cast<float*>(smem + Cfg::LDS_BYTES);
   const int Cinp = (p.Cin + 3) & ~3;
-  if (bnin) {
-    for (int i = tid; i < p.Cin; i += 256) { lds_sc[i] = p.inSc[i]; lds_sc[Cinp + i] = p.inSh[i]; }
-    __syncthreads();
-  }
 
   // Staging addresses: one buffer descriptor per operand (this image's activations / the packed weight slabs) and
   // ONE 32-bit byte offset per load, computed once.  Pixels outside the image, columns beyond Ncols and padding
@@ -176,6 +174,14 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
   load_chunk(0);
+  // Per-channel tables and the operand scale AFTER the first chunk's loads are in flight (their latency is the same
+  // L2 round trip): the BN-on-load (scale, shift) pairs, and the powers of two -- device scalar of a gradient tensor x
+  // range guard of an activation tensor (common.h dc_block_guard_scale; its barriers also publish the table).
+  if (bnin)
+    for (int i = tid; i < p.Cin; i += 256) { lds_sc[i] = p.inSc[i]; lds_sc[Cinp + i] = p.inSh[i]; }
+  const float in_scale = (p.inScale ? *p.inScale : 1.f) *
+                         dc_block_guard_scale(p.inAbound, p.Cin, reinterpret_cast<float*>(smem));
+  if (bnin && p.inAbound == nullptr) __syncthreads();
   for (int c0 = 0; c0 < p.Cin; c0 += CK) {
     f32x4 csc = {1.f, 1.f, 1.f, 1.f}, csh = {0.f, 0.f, 0.f, 0.f};
     const bool ch_ok = c0 + 4 * a_g < p.Cin;
@@ -252,8 +258,8 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   // ---- epilogue: C/D col = lane&31 -> output column n, row m = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel --------
   // Stores go through a buffer descriptor of this image's output; pixels outside the image / columns beyond
   // Ncols get an out-of-range offset and are dropped by the bounds check (no branches, 32-bit offsets).
-  const float out_scale = 1.f / in_scale;
-  float* red = reinterpret_cast<float*>(smem);
+  const float out_scale = 1.f / (in_scale * w_scale);
+  DcMoments* red = reinterpret_cast<DcMoments*>(smem);
   const bool scatter = p.scatterCo > 0;
   const long out_img_floats = scatter ? 4L * p.Hout * p.Wout * p.outLd : (long)p.Hout * p.Wout * p.outLd;
   const __amdgpu_buffer_rsrc_t rsrcO = dc_make_rsrc(p.out + (long)img * out_img_floats, (unsigned)(out_img_floats * 4));
@@ -263,8 +269,9 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   // Interior items (every pixel and column of the tile exists: all but the ragged border) take a lean epilogue: no
   // per-element validity selects, and the per-element address term rides in the scalar soffset operand.
   const bool interior = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (n0 + BN <= p.Ncols);   // wave-uniform
-  auto epilogue = [&](auto interior_tag) {
+  auto epilogue = [&](auto interior_tag, auto track_tag) {
     constexpr bool INT = decltype(interior_tag)::value;
+    constexpr bool TRACK = decltype(track_tag)::value;     // inference: fold max |output| per channel into outAbsmax
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const int n = n0 + (wave_n * NB + nb) * 32 + li;
@@ -272,7 +279,9 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
       const float bv = (p.bias && n_ok) ? p.bias[n % p.biasMod] : 0.f;
       const float sc = (p.scale && n_ok) ? p.scale[n % p.biasMod] : 1.f;
       const float sh = (p.shift && n_ok) ? p.shift[n % p.biasMod] : 0.f;
-      float s1 = 0.f, s2 = 0.f;
+      // BatchNorm partials as shifted sums around this lane's first value (common.h DcMoments)
+      const float K = __builtin_fmaf(acc[0][nb][0], out_scale, bv);
+      float s1 = 0.f, s2 = 0.f, cnt = 0.f, amax = 0.f;
       int colterm = n;
       if (scatter) {
         const int ab = n / p.scatterCo, o = n - ab * p.scatterCo;
@@ -288,53 +297,67 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
           const int mr = (r & 3) + 8 * (r >> 2);                 // compile-time; + 4h stays inside one tile row
           const int rowc = mr / TW, colc = mr % TW;
           float v = __builtin_fmaf(acc[mb][nb][r], out_scale, bv);
+          const float d = v - K;
           if constexpr (INT) {
-            s1 += v;
-            s2 = __builtin_fmaf(v, v, s2);
+            s1 += d;
+            s2 = __builtin_fmaf(d, d, s2);
             if (p.scale) v = v * sc + sh;
             if (p.relu) v = fmaxf(v, 0.f);
+            if constexpr (TRACK) amax = fmaxf(amax, fabsf(v));
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, base,
                                                   (rowc * sy + colc * sx) * 4, 0);      // scalar addend
           } else {
             const bool ok = n_ok && (oyb + rowc) < p.Hout && (oxb + colc) < p.Wout;
-            s1 += ok ? v : 0.f;
-            s2 += ok ? v * v : 0.f;
+            s1 += ok ? d : 0.f;
+            s2 += ok ? d * d : 0.f;
+            cnt += ok ? 1.f : 0.f;
             if (p.scale) v = v * sc + sh;
             if (p.relu) v = fmaxf(v, 0.f);
+            if constexpr (TRACK) amax = fmaxf(amax, ok ? fabsf(v) : 0.f);
             const unsigned off = ok ? base + (unsigned)((rowc * sy + colc * sx) * 4) : OOB;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, off, 0, 0);
           }
         }
       }
       if (p.stats) {
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (h == 0) {
-          red[((wave * NB + nb) * 32 + li) * 2 + 0] = s1;
-          red[((wave * NB + nb) * 32 + li) * 2 + 1] = s2;
+        DcMoments m;
+        if constexpr (INT) {      // every lane holds 16*MB values: no divisions
+          constexpr float NL = (float)(16 * MB);
+          const float ms = s1 * (1.f / NL);
+          m.n = NL; m.mean = K + ms; m.m2 = fmaxf(__builtin_fmaf(-s1, ms, s2), 0.f);
+          const float om = __shfl_xor(m.mean, 32), o2 = __shfl_xor(m.m2, 32), d = om - m.mean;
+          m.m2 = m.m2 + o2 + d * d * (0.5f * NL);
+          m.mean = __builtin_fmaf(d, 0.5f, m.mean);
+          m.n = 2.f * NL;
+        } else {
+          m = dc_moments_from_shifted(cnt, K, s1, s2);
+          DcMoments o;
+          o.n = __shfl_xor(m.n, 32); o.mean = __shfl_xor(m.mean, 32); o.m2 = __shfl_xor(m.m2, 32);
+          m = dc_moments_merge(m, o);
         }
+        if (h == 0) red[(wave * NB + nb) * 32 + li] = m;
+      }
+      if constexpr (TRACK) {
+        amax = fmaxf(amax, __shfl_xor(amax, 32));
+        if (h == 0 && n_ok) dc_atomic_absmax(p.outAbsmax + n % p.biasMod, amax);
       }
     }
   };
-  if (interior) epilogue(std::true_type{}); else epilogue(std::false_type{});
+  if (p.outAbsmax) {
+    if (interior) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{});
+  } else {
+    if (interior) epilogue(std::true_type{}, std::false_type{}); else epilogue(std::false_type{}, std::false_type{});
+  }
   if (p.stats) {
     __syncthreads();
     if (tid < Cfg::WAVES_N * NB * 32) {
       const int wn = tid / (NB * 32), rem = tid % (NB * 32);
       const int nb = rem / 32, l = rem % 32;
-      float s1 = 0.f, s2 = 0.f;
+      DcMoments m = red[((wn * WAVES_M) * NB + nb) * 32 + l];
 #pragma unroll
-      for (int wm = 0; wm < WAVES_M; ++wm) {
-        const int w = wn * WAVES_M + wm;
-        s1 += red[((w * NB + nb) * 32 + l) * 2 + 0];
-        s2 += red[((w * NB + nb) * 32 + l) * 2 + 1];
-      }
+      for (int wm = 1; wm < WAVES_M; ++wm) m = dc_moments_merge(m, red[((wn * WAVES_M + wm) * NB + nb) * 32 + l]);
       const int n = n0 + (wn * NB + nb) * 32 + l;
-      if (n < p.Ncols) {
-        float* dst = p.stats + ((long)tile_id * p.Ncols + n) * 2;
-        dst[0] = s1;
-        dst[1] = s2;
-      }
+      if (n < p.Ncols) dc_moments_store(p.stats + ((long)tile_id * p.Ncols + n) * 2, m);
     }
   }
 }
@@ -388,82 +411,120 @@ static int convT_dgrad_h_launch(IgemmParams p, hipStream_t st) {
   return igemm_h_launch<2, 2, 2, 0, 8, 2, 1, 2>(p, st, "convT2x2_dgrad_f16x3");
 }
 
-// dst (fp16 pairs, same byte size as the fp32 source):
-//   [tap][K/8][hi|lo][n][8 halfs]  with  value(tap,k,n) = src[(flip ? taps-1-tap : tap)*s_tap + k*s_k + n*s_n]
-__global__ void pack_weights_f16x3_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int taps, int K,
-                                          int Ncols, long s_tap, long s_k, long s_n, int flip, long total) {
-  const int K8 = (K + 7) >> 3;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(i & 7);
-    long r = i >> 3;
-    const int n = (int)(r % Ncols); r /= Ncols;
-    const int k8 = (int)(r % K8);
-    const int tap = (int)(r / K8);
-    const int k = k8 * 8 + e;
-    const int ts = flip ? (taps - 1 - tap) : tap;
-    const float x = (k < K) ? src[ts * s_tap + k * s_k + n * s_n] : 0.f;
-    const _Float16 hi = (_Float16)x;
-    const _Float16 lo = (_Float16)(x - (float)hi);
-    const long slot = ((long)(tap * K8 + k8) * 2) * Ncols + n;
-    dst[slot * 8 + e] = hi;
-    dst[(slot + Ncols) * 8 + e] = lo;
+// dst (fp16 pairs, same byte size as the fp32 source) + a 16-byte trailer {w_scale, max|src| bits, 0, 0}:
+//   [tap][K/8][hi|lo][n][8 halfs]  with  value(tap,k,n) = w_scale * src[(flip ? taps-1-tap : tap)*s_tap + k*s_k + n*s_n]
+// w_scale = the power of two that brings max|src| into [2^10, 2^11) (1 for an all-zero kernel): the fp16 hi/lo split is
+// relative only inside fp16's NORMAL range, so unscaled he-normal weights of ~0.02 (lo in the subnormals) or trained
+// kernels of 1e-4 would lose bits; the contraction kernels undo the scale exactly in their epilogue.
+// One job = DC_PACK_JOB_LONGS longs { src pointer, dst pointer, taps, K, Ncols, s_tap, s_k, s_n, flip, first block };
+// a trailing sentinel entry carries the grid size in its last field.  Three launches: zero the trailers' max slots,
+// max|src| per job (order-independent atomic max on the float bits), scale + split.
+#define DC_PACK_JOB_LONGS 10
+struct PackJob {
+  const float* src; _Float16* dst; int taps, K, Ncols, flip, b0, nb; long s_tap, s_k, s_n, total; float* trailer;
+};
+__device__ __forceinline__ PackJob pack_job(const long* __restrict__ jobs, int njobs) {
+  int j = 0;
+  while (j + 1 < njobs && jobs[(j + 1) * DC_PACK_JOB_LONGS + 9] <= (long)blockIdx.x) ++j;
+  const long* jb = jobs + (long)j * DC_PACK_JOB_LONGS;
+  PackJob q;
+  q.src = reinterpret_cast<const float*>(jb[0]);
+  q.dst = reinterpret_cast<_Float16*>(jb[1]);
+  q.taps = (int)jb[2]; q.K = (int)jb[3]; q.Ncols = (int)jb[4]; q.flip = (int)jb[8];
+  q.s_tap = jb[5]; q.s_k = jb[6]; q.s_n = jb[7];
+  q.b0 = (int)jb[9]; q.nb = (int)jb[DC_PACK_JOB_LONGS + 9] - q.b0;
+  q.total = (long)q.taps * ((q.K + 7) >> 3) * 8 * q.Ncols;
+  q.trailer = reinterpret_cast<float*>(q.dst + 2 * q.total);
+  return q;
+}
+__device__ __forceinline__ float pack_src(const PackJob& q, long i, int& e, long& slot) {
+  const int K8 = (q.K + 7) >> 3;
+  e = (int)(i & 7);
+  long r = i >> 3;
+  const int n = (int)(r % q.Ncols); r /= q.Ncols;
+  const int k8 = (int)(r % K8);
+  const int tap = (int)(r / K8);
+  const int k = k8 * 8 + e;
+  const int ts = q.flip ? (q.taps - 1 - tap) : tap;
+  slot = ((long)(tap * K8 + k8) * 2) * q.Ncols + n;
+  return (k < q.K) ? q.src[ts * q.s_tap + k * q.s_k + n * q.s_n] : 0.f;
+}
+__global__ void pack_zero_kernel(const long* __restrict__ jobs, int njobs) {
+  for (int j = threadIdx.x; j < njobs; j += blockDim.x) {
+    const long* jb = jobs + (long)j * DC_PACK_JOB_LONGS;
+    const long total = jb[2] * ((jb[3] + 7) >> 3) * 8 * jb[4];
+    reinterpret_cast<unsigned*>(reinterpret_cast<_Float16*>(jb[1]) + 2 * total)[1] = 0u;
   }
 }
+__device__ __forceinline__ void pack_absmax_body(const PackJob& q) {
+  // the source tensor is contiguous (taps * K * Ncols floats, K a multiple of 4): a linear float4 sweep
+  const long n4 = (long)q.taps * q.K * q.Ncols / 4;
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(q.src);
+  float m = 0.f;
+  for (long i = (blockIdx.x - q.b0) * (long)blockDim.x + threadIdx.x; i < n4; i += (long)q.nb * blockDim.x) {
+    const f32x4 v = s4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) dc_atomic_absmax(q.trailer + 1, m);
+}
+__device__ __forceinline__ void pack_split_body(const PackJob& q) {
+  const float amax = q.trailer[1];
+  const unsigned ex = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;
+  // 2^(10 - floor(log2 amax)); all-zero / denormal / non-finite kernels stay unscaled
+  const float ws = (amax > 0.f && ex >= 14u && ex != 0xffu) ? __builtin_bit_cast(float, (264u - ex) << 23) : 1.f;
+  if (blockIdx.x == (unsigned)q.b0 && threadIdx.x == 0) q.trailer[0] = ws;
+  for (long i = (blockIdx.x - q.b0) * (long)blockDim.x + threadIdx.x; i < q.total; i += (long)q.nb * blockDim.x) {
+    int e; long slot;
+    const float x = pack_src(q, i, e, slot) * ws;
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    q.dst[slot * 8 + e] = hi;
+    q.dst[(slot + q.Ncols) * 8 + e] = lo;
+  }
+}
+__global__ __launch_bounds__(256) void pack_absmax_kernel(const long* __restrict__ jobs, int njobs) {
+  pack_absmax_body(pack_job(jobs, njobs));
+}
+__global__ __launch_bounds__(256) void pack_weights_f16x3_batch_kernel(const long* __restrict__ jobs, int njobs) {
+  pack_split_body(pack_job(jobs, njobs));
+}
+__global__ __launch_bounds__(256) void pack1_absmax_kernel(PackJob q) { pack_absmax_body(q); }
+__global__ __launch_bounds__(256) void pack1_split_kernel(PackJob q) { pack_split_body(q); }
 
 extern "C" int dc_pack_weights_f16x3(const float* src, void* dst, int taps, int K, int Ncols, long s_tap, long s_k,
                                      long s_n, int flip, dc_stream_t stream) {
   DC_REQUIRE(src && dst, DC_EINVAL, "dc_pack_weights_f16x3: null pointer");
   DC_REQUIRE(taps > 0 && K > 0 && Ncols > 0 && K % 4 == 0, DC_EINVAL, "dc_pack_weights_f16x3: K=%d must be a positive multiple of 4", K);
-  const long total = (long)taps * ((K + 7) / 8) * 8 * Ncols;
-  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(pack_weights_f16x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
-                     reinterpret_cast<_Float16*>(dst), taps, K, Ncols, s_tap, s_k, s_n, flip, total);
+  PackJob q;
+  q.src = src; q.dst = reinterpret_cast<_Float16*>(dst); q.taps = taps; q.K = K; q.Ncols = Ncols; q.flip = flip;
+  q.s_tap = s_tap; q.s_k = s_k; q.s_n = s_n;
+  q.total = (long)taps * ((K + 7) / 8) * 8 * Ncols;
+  q.trailer = reinterpret_cast<float*>(q.dst + 2 * q.total);
+  q.b0 = 0;
+  q.nb = (int)((q.total + 255) / 256 > 4096 ? 4096 : (q.total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(q.trailer, 0, 16, st);
+  DC_REQUIRE(e == hipSuccess, DC_EHIP, "dc_pack_weights_f16x3: hipMemsetAsync: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(pack1_absmax_kernel, dim3(q.nb), dim3(256), 0, st, q);
+  hipLaunchKernelGGL(pack1_split_kernel, dim3(q.nb), dim3(256), 0, st, q);
   DC_CHECK_LAUNCH("dc_pack_weights_f16x3");
   return DC_OK;
 }
 
-// All layers' re-packs in ONE launch (the weights change every optimizer step: 2 packs x 21 layers were 42 launches
-// of ~4 us each).  jobs (device memory): DC_PACK_JOB_LONGS longs per job =
-//   { src pointer, dst pointer, taps, K, Ncols, s_tap, s_k, s_n, flip, first block of the job }, plus one trailing
-//   sentinel entry whose "first block" field is the grid size.
-#define DC_PACK_JOB_LONGS 10
-__global__ void pack_weights_f16x3_batch_kernel(const long* __restrict__ jobs, int njobs) {
-  int j = 0;
-  while (j + 1 < njobs && jobs[(j + 1) * DC_PACK_JOB_LONGS + 9] <= (long)blockIdx.x) ++j;
-  const long* jb = jobs + (long)j * DC_PACK_JOB_LONGS;
-  const float* src = reinterpret_cast<const float*>(jb[0]);
-  _Float16* dst = reinterpret_cast<_Float16*>(jb[1]);
-  const int taps = (int)jb[2], K = (int)jb[3], Ncols = (int)jb[4], flip = (int)jb[8];
-  const long s_tap = jb[5], s_k = jb[6], s_n = jb[7];
-  const int b0 = (int)jb[9], nb = (int)jb[DC_PACK_JOB_LONGS + 9] - b0;
-  const int K8 = (K + 7) >> 3;
-  const long total = (long)taps * K8 * 8 * Ncols;
-  for (long i = (blockIdx.x - b0) * (long)blockDim.x + threadIdx.x; i < total; i += (long)nb * blockDim.x) {
-    const int e = (int)(i & 7);
-    long r = i >> 3;
-    const int n = (int)(r % Ncols); r /= Ncols;
-    const int k8 = (int)(r % K8);
-    const int tap = (int)(r / K8);
-    const int k = k8 * 8 + e;
-    const int ts = flip ? (taps - 1 - tap) : tap;
-    const float x = (k < K) ? src[ts * s_tap + k * s_k + n * s_n] : 0.f;
-    const _Float16 hi = (_Float16)x;
-    const _Float16 lo = (_Float16)(x - (float)hi);
-    const long slot = ((long)(tap * K8 + k8) * 2) * Ncols + n;
-    dst[slot * 8 + e] = hi;
-    dst[(slot + Ncols) * 8 + e] = lo;
-  }
-}
 extern "C" int dc_pack_weights_f16x3_batch(const long* jobs_dev, int njobs, int total_blocks, dc_stream_t stream) {
   DC_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, DC_EINVAL, "dc_pack_weights_f16x3_batch: bad arguments");
-  hipLaunchKernelGGL(pack_weights_f16x3_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev,
-                     njobs);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(pack_zero_kernel, dim3(1), dim3(64), 0, st, jobs_dev, njobs);
+  hipLaunchKernelGGL(pack_absmax_kernel, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs);
+  hipLaunchKernelGGL(pack_weights_f16x3_batch_kernel, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs);
   DC_CHECK_LAUNCH("dc_pack_weights_f16x3_batch");
   return DC_OK;
 }
 
 extern "C" long dc_pack_weights_f16x3_floats(int taps, int K, int Ncols) {
-  return (long)taps * ((K + 7) / 8) * 8 * Ncols;   // 2 halfs per element = one float's worth of bytes
+  return (long)taps * ((K + 7) / 8) * 8 * Ncols + 4;   // 2 halfs per element = one float's worth of bytes; + trailer
 }
 
 static int check_h(const char* fn, const void* a, const void* b, const void* c, int N, int H, int W, int Cin, int Cout) {
@@ -475,22 +536,23 @@ static int check_h(const char* fn, const void* a, const void* b, const void* c, 
 }
 
 extern "C" int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld,
-                                    float* stats, const float* scale, const float* shift, int relu,
-                                    const float* in_scale, int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
+                                    double* stats, const float* scale, const float* shift, int relu,
+                                    const float* in_abound, float* out_absmax, int N, int H, int W, int Cin, int Cout,
+                                    dc_stream_t stream) {
   int rc = check_h("dc_conv3x3_fwd_f16x3", x, wp16, z, N, H, W, Cin, Cout);
   if (rc) return rc;
   DC_REQUIRE((scale == nullptr) == (shift == nullptr), DC_EINVAL, "dc_conv3x3_fwd_f16x3: scale and shift go together");
   DC_REQUIRE(z_ld >= Cout, DC_EINVAL, "dc_conv3x3_fwd_f16x3: z_ld < Cout");
   IgemmParams p{};
   p.in = x; p.wp = reinterpret_cast<const float*>(wp16); p.bias = bias; p.out = z; p.stats = stats;
-  p.scale = scale; p.shift = shift; p.inScale = in_scale;
+  p.scale = scale; p.shift = shift; p.inAbound = in_abound; p.outAbsmax = out_absmax;
   p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = Cout;
   p.relu = relu; p.scatterCo = 0; p.biasMod = Cout; p.outLd = z_ld;
   return conv3x3_h_launch(p, (hipStream_t)stream);
 }
 
-extern "C" int dc_conv3x3_fwd_bnin_f16x3(const float* z_in, const float* in_sc, const float* in_sh, const void* wp16,
-                                         const float* bias, float* z, long z_ld, float* stats, const float* scale,
+extern "C" int dc_conv3x3_fwd_bnin_f16x3(const float* z_in, const float* in_sc, const float* in_sh, const float* in_abound,
+    const void* wp16, const float* bias, float* z, long z_ld, double* stats, const float* scale,
                                          const float* shift, int relu, int N, int H, int W, int Cin, int Cout,
                                          dc_stream_t stream) {
   int rc = check_h("dc_conv3x3_fwd_bnin_f16x3", z_in, wp16, z, N, H, W, Cin, Cout);
@@ -500,14 +562,14 @@ extern "C" int dc_conv3x3_fwd_bnin_f16x3(const float* z_in, const float* in_sc, 
   DC_REQUIRE(z_ld >= Cout, DC_EINVAL, "dc_conv3x3_fwd_bnin_f16x3: z_ld < Cout");
   IgemmParams p{};
   p.in = z_in; p.wp = reinterpret_cast<const float*>(wp16); p.bias = bias; p.out = z; p.stats = stats;
-  p.scale = scale; p.shift = shift; p.inSc = in_sc; p.inSh = in_sh;
+  p.scale = scale; p.shift = shift; p.inSc = in_sc; p.inSh = in_sh; p.inAbound = in_abound;
   p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = Cout;
   p.relu = relu; p.scatterCo = 0; p.biasMod = Cout; p.outLd = z_ld;
   return conv3x3_h_launch(p, (hipStream_t)stream);
 }
 
-extern "C" int dc_convT2x2_fwd_bnin_f16x3(const float* z_in, const float* in_sc, const float* in_sh, const void* wp16,
-                                          const float* bias, float* z, long z_ld, float* stats, const float* scale,
+extern "C" int dc_convT2x2_fwd_bnin_f16x3(const float* z_in, const float* in_sc, const float* in_sh, const float* in_abound,
+    const void* wp16, const float* bias, float* z, long z_ld, double* stats, const float* scale,
                                           const float* shift, int relu, int N, int H, int W, int Cin, int Cout,
                                           dc_stream_t stream) {
   int rc = check_h("dc_convT2x2_fwd_bnin_f16x3", z_in, wp16, z, N, H, W, Cin, Cout);
@@ -517,7 +579,7 @@ extern "C" int dc_convT2x2_fwd_bnin_f16x3(const float* z_in, const float* in_sc,
   DC_REQUIRE(z_ld >= Cout, DC_EINVAL, "dc_convT2x2_fwd_bnin_f16x3: z_ld < Cout");
   IgemmParams p{};
   p.in = z_in; p.wp = reinterpret_cast<const float*>(wp16); p.bias = bias; p.out = z; p.stats = stats;
-  p.scale = scale; p.shift = shift; p.inSc = in_sc; p.inSh = in_sh;
+  p.scale = scale; p.shift = shift; p.inSc = in_sc; p.inSh = in_sh; p.inAbound = in_abound;
   p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = 4 * Cout;
   p.relu = relu; p.scatterCo = Cout; p.biasMod = Cout; p.outLd = z_ld;
   return convT_fwd_h_launch(p, (hipStream_t)stream);
@@ -535,15 +597,16 @@ extern "C" int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* 
 }
 
 extern "C" int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld,
-                                     float* stats, const float* scale, const float* shift, int relu,
-                                     const float* in_scale, int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
+                                     double* stats, const float* scale, const float* shift, int relu,
+                                     const float* in_abound, float* out_absmax, int N, int H, int W, int Cin, int Cout,
+                                     dc_stream_t stream) {
   int rc = check_h("dc_convT2x2_fwd_f16x3", x, wp16, z, N, H, W, Cin, Cout);
   if (rc) return rc;
   DC_REQUIRE((scale == nullptr) == (shift == nullptr), DC_EINVAL, "dc_convT2x2_fwd_f16x3: scale and shift go together");
   DC_REQUIRE(z_ld >= Cout, DC_EINVAL, "dc_convT2x2_fwd_f16x3: z_ld < Cout");
   IgemmParams p{};
   p.in = x; p.wp = reinterpret_cast<const float*>(wp16); p.bias = bias; p.out = z; p.stats = stats;
-  p.scale = scale; p.shift = shift; p.inScale = in_scale;
+  p.scale = scale; p.shift = shift; p.inAbound = in_abound; p.outAbsmax = out_absmax;
   p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = 4 * Cout;
   p.relu = relu; p.scatterCo = Cout; p.biasMod = Cout; p.outLd = z_ld;
   return convT_fwd_h_launch(p, (hipStream_t)stream);

@@ -39,6 +39,9 @@ struct WgradHParams {
   // producer waves while they split it (zero padding stays zero).  Nullable, per channel of that operand.
   const float* aSc; const float* aSh;
   const float* bSc; const float* bSh;
+  // fp16 range guard of the ACTIVATION operand (common.h dc_block_guard_scale): its per-channel magnitude bound
+  // (xChannels floats, nullable).  The gradient operand brings its scale in aScale / bScale.
+  const float* xAbound; int xChannels;
 };
 
 // WM x WNW waves tile the CTA's (m, n) block, each wave covering 32 m x (32*NBW) n; the remaining
@@ -101,6 +104,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // 0..7, provably wave-uniform
+  // operand scales (powers of two, undone in the epilogue): the gradient operand's device scalar, the activation
+  // operand's range guard -- every wave needs them (producers to split, consumers to un-scale)
+  const float x_scale = dc_block_guard_scale(hp.xAbound, hp.xChannels, reinterpret_cast<float*>(smem));
+  const float a_scale = A_SCALED ? (hp.aScale ? *hp.aScale : 1.f) : x_scale;
+  const float b_scale = A_SCALED ? x_scale : (hp.bScale ? *hp.bScale : 1.f);
   // XCD-aware rasterisation (speed only): ids b and b+8 share an L2, so each XCD walks a contiguous range of
   // (pixel split, channel block) pairs with the channel block fastest -- the CTAs that stream the same pixel range
   // for different (m,n) blocks run side by side on one L2.
@@ -115,8 +123,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
   if (wave >= 4) {
     // ================= producer waves: HBM -> registers -> fp16 hi/lo images in LDS =========================
     const int st = tid & 255;
-    const float a_scale = hp.aScale ? *hp.aScale : 1.f;
-    const float b_scale = hp.bScale ? *hp.bScale : 1.f;
     const int a_c4 = st % AC4, b_c4 = st % BC4;
     const bool a_ch_ok = (m0 + 4 * a_c4) < p.Cm, b_ch_ok = (n0 + 4 * b_c4) < p.Cn;
     const int a_rowb = p.Wa * p.Cm * 4, b_rowb = p.Wb * p.Cn * 4;
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
       for (int j = 0; j < NA; ++j) {
         const int pix = st / AC4 + j * (256 / AC4);
         u32x2 hi, lo;
-        split4_f16<A_SCALED>(a_bn ? bn_relu(ra[j], a_sc, a_sh, (ma >> j) & 1u) : ra[j], a_scale, hi, lo);
+        split4_f16<true>(a_bn ? bn_relu(ra[j], a_sc, a_sh, (ma >> j) & 1u) : ra[j], a_scale, hi, lo);
         if (pix < APIX) {
           *reinterpret_cast<u32x2*>(set + a_lbase + pix * 64) = hi;
           *reinterpret_cast<u32x2*>(set + A_IMG + a_lbase + pix * 64) = lo;
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
       for (int k = 0; k < NB; ++k) {
         const int pix = st / BC4 + k * (256 / BC4);
         u32x2 hi, lo;
-        split4_f16<!A_SCALED>(b_bn ? bn_relu(rb[k], b_sc, b_sh, (mb >> k) & 1u) : rb[k], b_scale, hi, lo);
+        split4_f16<true>(b_bn ? bn_relu(rb[k], b_sc, b_sh, (mb >> k) & 1u) : rb[k], b_scale, hi, lo);
         if (pix < BPIX) {
           *reinterpret_cast<u32x2*>(set + b_lbase + pix * 64) = hi;
           *reinterpret_cast<u32x2*>(set + B_IMG + b_lbase + pix * 64) = lo;
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
     __syncthreads();   // this set may be overwritten, the other one is complete
   }
 
-  const float out_scale = 1.f / ((hp.aScale ? *hp.aScale : 1.f) * (hp.bScale ? *hp.bScale : 1.f));
+  const float out_scale = 1.f / (a_scale * b_scale);
 #pragma unroll
   for (int w = 0; w < NBW; ++w)   // one 32x32 block at a time through the shared cross-wave reduction + store
     wgrad_store<TAPS, WM, WNW, WK>(p, acc[w], smem, split, m0, n0 + 32 * (wnw * NBW + w) - 32 * wnw, wm, wnw, wk, lane,
@@ -331,7 +337,7 @@ static long wgrad_h_ws(int N, int Hb, int Wb, int Cm, int Cn) {
 
 template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW, bool A_SCALED>
 static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, const float* aScale, const float* bScale,
-                          const float* xSc, const float* xSh, int N, int Ha, int Wa, int Hb, int Wb, int Cm, int Cn,
+                          const float* xSc, const float* xSh, const float* xAbound, int N, int Ha, int Wa, int Hb, int Wb, int Cm, int Cn,
                           hipStream_t st, const char* name) {
   using Cfg = WgradHCfg<KH, KW, S, PAD, TW, RW, WM, WNW, NBW>;
   auto kern = wgrad_f16x3_kernel<KH, KW, S, PAD, TW, RW, WM, WNW, NBW, A_SCALED>;
@@ -352,6 +358,7 @@ static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, 
   // the activation operand is the UNscaled one: A for conv3x3 (A_SCALED = false), B for convT2x2
   hp.aSc = A_SCALED ? nullptr : xSc; hp.aSh = A_SCALED ? nullptr : xSh;
   hp.bSc = A_SCALED ? xSc : nullptr; hp.bSh = A_SCALED ? xSh : nullptr;
+  hp.xAbound = xAbound; hp.xChannels = A_SCALED ? Cn : Cm;
   dim3 grid((unsigned)(pl.splits * dc_cdiv(Cm, Cfg::CM) * dc_cdiv(Cn, Cfg::CN)));
   hipLaunchKernelGGL(kern, grid, dim3(512), Cfg::LDS_BYTES, st, hp);
   DC_CHECK_LAUNCH(name);
@@ -395,53 +402,55 @@ static int check_h(const char* fn, const void* a, const void* b, const void* c, 
   return DC_OK;
 }
 
-static int conv_h_impl(const float* x, const float* xSc, const float* xSh, const float* dz, float* dw, float* ws,
-                       const float* dzScale, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+static int conv_h_impl(const float* x, const float* xSc, const float* xSh, const float* xAb, const float* dz, float* dw,
+                       float* ws, const float* dzScale, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
   const float* none = nullptr;
-  CONV_H_DISPATCH(wgrad_h_launch, , false>(x, dz, dw, ws, none, dzScale, xSc, xSh, N, H, W, H, W, Cin, Cout, st, "conv3x3_wgrad_f16x3"))
+  CONV_H_DISPATCH(wgrad_h_launch, , false>(x, dz, dw, ws, none, dzScale, xSc, xSh, xAb, N, H, W, H, W, Cin, Cout, st, "conv3x3_wgrad_f16x3"))
 }
-static int convT_h_impl(const float* x, const float* xSc, const float* xSh, const float* dz, float* dw, float* ws,
-                        const float* dzScale, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+static int convT_h_impl(const float* x, const float* xSc, const float* xSh, const float* xAb, const float* dz, float* dw,
+                        float* ws, const float* dzScale, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
   const float* none = nullptr;
-  CONVT_H_DISPATCH(wgrad_h_launch, , true>(dz, x, dw, ws, dzScale, none, xSc, xSh, N, 2 * H, 2 * W, H, W, Cout, Cin, st, "convT2x2_wgrad_f16x3"))
+  CONVT_H_DISPATCH(wgrad_h_launch, , true>(dz, x, dw, ws, dzScale, none, xSc, xSh, xAb, N, 2 * H, 2 * W, H, W, Cout, Cin, st, "convT2x2_wgrad_f16x3"))
 }
 
 // same workspace (dc_*_wgrad_ws_floats) as the fp32 entry points; dz_scale = device scalar from
 // dc_pow2_scale_from_absmax (nullable).
 extern "C" int dc_conv3x3_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,
-                                      int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
+                                      const float* x_abound, int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
   if (Cin == 1) {
     DC_REQUIRE(x && dz && dw && ws, DC_EINVAL, "dc_conv3x3_wgrad_f16x3: null pointer");
     return dc_conv3x3_c1_wgrad(x, dz, dw, ws, N, H, W, Cout, (hipStream_t)stream);
   }
   int rc = check_h("dc_conv3x3_wgrad_f16x3", x, dz, dw, ws, N, H, W, Cin, Cout);
   if (rc) return rc;
-  return conv_h_impl(x, nullptr, nullptr, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
+  return conv_h_impl(x, nullptr, nullptr, x_abound, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
 }
 extern "C" int dc_convT2x2_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,
-                                       int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
+                                       const float* x_abound, int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
   int rc = check_h("dc_convT2x2_wgrad_f16x3", x, dz, dw, ws, N, H, W, Cin, Cout);
   if (rc) return rc;
-  return convT_h_impl(x, nullptr, nullptr, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
+  return convT_h_impl(x, nullptr, nullptr, x_abound, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
 }
 
 // BN + ReLU on load: z_in is the producer's pre-BN tensor, (in_scale_c, in_shift_c) its per-channel training-mode affine
 // (dc_bn_stats_finalize_affine); the layer input relu(fmaf(z, sc, sh)) is never materialised.
-extern "C" int dc_conv3x3_wgrad_bnin_f16x3(const float* z_in, const float* in_sc, const float* in_sh, const float* dz,
-                                           float* dw, float* ws, const float* dz_scale, int N, int H, int W, int Cin,
-                                           int Cout, dc_stream_t stream) {
+extern "C" int dc_conv3x3_wgrad_bnin_f16x3(const float* z_in, const float* in_sc, const float* in_sh,
+                                           const float* in_abound, const float* dz, float* dw, float* ws,
+                                           const float* dz_scale, int N, int H, int W, int Cin, int Cout,
+                                           dc_stream_t stream) {
   int rc = check_h("dc_conv3x3_wgrad_bnin_f16x3", z_in, dz, dw, ws, N, H, W, Cin, Cout);
   if (rc) return rc;
   DC_REQUIRE(in_sc && in_sh && dc_aligned16(in_sc) && dc_aligned16(in_sh), DC_EINVAL,
              "dc_conv3x3_wgrad_bnin_f16x3: scale/shift must be non-null and 16-byte aligned");
-  return conv_h_impl(z_in, in_sc, in_sh, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
+  return conv_h_impl(z_in, in_sc, in_sh, in_abound, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
 }
-extern "C" int dc_convT2x2_wgrad_bnin_f16x3(const float* z_in, const float* in_sc, const float* in_sh, const float* dz,
-                                            float* dw, float* ws, const float* dz_scale, int N, int H, int W, int Cin,
-                                            int Cout, dc_stream_t stream) {
+extern "C" int dc_convT2x2_wgrad_bnin_f16x3(const float* z_in, const float* in_sc, const float* in_sh,
+                                            const float* in_abound, const float* dz, float* dw, float* ws,
+                                            const float* dz_scale, int N, int H, int W, int Cin, int Cout,
+                                            dc_stream_t stream) {
   int rc = check_h("dc_convT2x2_wgrad_bnin_f16x3", z_in, dz, dw, ws, N, H, W, Cin, Cout);
   if (rc) return rc;
   DC_REQUIRE(in_sc && in_sh && dc_aligned16(in_sc) && dc_aligned16(in_sh), DC_EINVAL,
              "dc_convT2x2_wgrad_bnin_f16x3: scale/shift must be non-null and 16-byte aligned");
-  return convT_h_impl(z_in, in_sc, in_sh, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
+  return convT_h_impl(z_in, in_sc, in_sh, in_abound, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
 }

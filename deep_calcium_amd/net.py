@@ -174,6 +174,20 @@ class UNetEngine(object):
             else:
                 self.wp_fwd[l.name] = torch.empty(n, dtype=torch.float32, device=dev)
                 self.wp_dgrad[l.name] = torch.empty(n, dtype=torch.float32, device=dev)
+        # fp16 range guard of the f16x3 contractions (csrc/common.h dc_block_guard_scale): one per-channel magnitude
+        # bound per activation tensor, written by the layer that produces it (training: |gamma|*sqrt(count)+|beta| from
+        # the BatchNorm finalize / apply kernels; inference: the measured max |a| from the conv epilogues) and read by
+        # the consumers, in THEIR input-channel order: the two producers of a skip-concat buffer share one array.
+        self._ab_off = {}
+        o = 0
+        for lvl in range(4):
+            self._ab_off['cat%d' % lvl] = o
+            o += self._cup(lvl) + (nfb << lvl)
+        for l in self.layers:
+            if l.kind != 'head':
+                self._ab_off[l.name] = o
+                o += l.cout
+        self.abound = torch.zeros(o, dtype=torch.float32, device=dev)
         self._bufs = {}
         self._packed_dirty = True
         self._fold_dirty = True
@@ -325,28 +339,61 @@ class UNetEngine(object):
                          BN_EPS, self.stat_ptr(l, 2), self.stat_ptr(l, 3), l.cout, st)
         self._fold_dirty = False
 
-    def _conv_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None):
-        """bnin = (scale_ptr, shift_ptr): x is the producer's pre-BN tensor, BN + ReLU are applied on load."""
+    def _conv_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None, absmax=None):
+        """bnin = (scale_ptr, shift_ptr): x is the producer's pre-BN tensor, BN + ReLU are applied on load.
+        absmax: inference only, where the epilogue folds max |output| per channel (the next layer's range-guard bound)."""
         if bnin is not None:
-            self.L.dc_conv3x3_fwd_bnin_f16x3(x, bnin[0], bnin[1], _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh,
-                                             relu, N, h, w, l.cin, l.cout, st)
+            self.L.dc_conv3x3_fwd_bnin_f16x3(x, bnin[0], bnin[1], self._ab_in(l), _ptr(self.wp_fwd[l.name]), bias, z, z_ld,
+                                             stats, sc, sh, relu, N, h, w, l.cin, l.cout, st)
         elif self.mfma == 'f16x3':
-            self.L.dc_conv3x3_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu, None,
-                                        N, h, w, l.cin, l.cout, st)
+            self.L.dc_conv3x3_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu, self._ab_in(l),
+                                        absmax, N, h, w, l.cin, l.cout, st)
         else:
             self.L.dc_conv3x3_fwd(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu,
                                   N, h, w, l.cin, l.cout, st)
 
-    def _convT_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None):
+    def _convT_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None, absmax=None):
         if bnin is not None:
-            self.L.dc_convT2x2_fwd_bnin_f16x3(x, bnin[0], bnin[1], _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc,
-                                              sh, relu, N, h, w, l.cin, l.cout, st)
+            self.L.dc_convT2x2_fwd_bnin_f16x3(x, bnin[0], bnin[1], self._ab_in(l), _ptr(self.wp_fwd[l.name]), bias, z, z_ld,
+                                              stats, sc, sh, relu, N, h, w, l.cin, l.cout, st)
         elif self.mfma == 'f16x3':
-            self.L.dc_convT2x2_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu, None,
-                                         N, h, w, l.cin, l.cout, st)
+            self.L.dc_convT2x2_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu, self._ab_in(l),
+                                         absmax, N, h, w, l.cin, l.cout, st)
         else:
             self.L.dc_convT2x2_fwd(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu,
                                    N, h, w, l.cin, l.cout, st)
+
+    def _ab_out(self, l):
+        """Where layer l's activation bound goes (None for the fp32-MFMA engine: no fp16 operands)."""
+        if self.mfma != 'f16x3':
+            return None
+        n = l.name
+        if l.kind == 'convT':
+            return _ptr(self.abound, self._ab_off['cat%d' % l.lvl])                            # up half of the concat
+        if n[0] == 'e' and n[-1] == 'b':
+            return _ptr(self.abound, self._ab_off['cat%d' % l.lvl] + self._cup(l.lvl))         # skip half
+        return _ptr(self.abound, self._ab_off[n])
+
+    def _ab_up(self, lvl):
+        """UpSampling2D branch: (bound of the up-sampled layer, up half of level lvl's concat bound) or (None, None)."""
+        if self.mfma != 'f16x3':
+            return None, None
+        return (_ptr(self.abound, self._ab_off['bb' if lvl == 3 else 'd%db' % (lvl + 1)]),
+                _ptr(self.abound, self._ab_off['cat%d' % lvl]))
+
+    def _ab_in(self, l):
+        """Bound array of layer l's INPUT tensor, in l's input-channel order (None: the image / fp32-MFMA engine)."""
+        if self.mfma != 'f16x3' or (l.kind == 'conv' and l.cin == 1):
+            return None
+        n = l.name
+        if l.kind == 'convT':
+            return _ptr(self.abound, self._ab_off['bb' if l.lvl == 3 else 'd%db' % (l.lvl + 1)])
+        if n[0] == 'd' and n[-1] == 'a':
+            return _ptr(self.abound, self._ab_off['cat%d' % l.lvl])
+        if n[-1] == 'b':
+            return _ptr(self.abound, self._ab_off[n[:-1] + 'a'])
+        lvl = l.lvl - 1                                                                        # e<lvl>a / ba: the pooled skip
+        return _ptr(self.abound, self._ab_off['cat%d' % lvl] + self._cup(lvl))
 
     def _bnin_src(self, prod, T):
         """(pre-BN tensor ptr, (scale_ptr, shift_ptr)) if the producer's activation is not materialised, else None."""
@@ -462,6 +509,8 @@ class UNetEngine(object):
         self.repack()
         self.refold()
         A = self._acts(N)
+        if self.mfma == 'f16x3':
+            self.abound.zero_()           # inference: the conv epilogues fold the measured max |a| per channel into it
         for step in self._plan(A):
             if step[0] == 'pool':
                 _, lvl, src, coff, ld, h, w = step
@@ -469,17 +518,19 @@ class UNetEngine(object):
                 continue
             if step[0] == 'up':
                 _, lvl, src, dst, ld, h, w = step
-                L.dc_upsample2x_drop_fwd(_ptr(src), _ptr(dst), ld, None, 1.0, 0, N, h // 2, w // 2, self._cup(lvl), st)
+                L.dc_upsample2x_drop_fwd(_ptr(src), _ptr(dst), ld, None, 1.0, 0, *self._ab_up(lvl), N, h // 2, w // 2,
+                                         self._cup(lvl), st)
                 continue
             _, l, src, dst, coff, ld, h, w, _prod = step
             sc, sh = self.stat_ptr(l, 2), self.stat_ptr(l, 3)
             if l.kind == 'conv' and l.cin == 1:
                 L.dc_conv3x3_c1_fwd(_ptr(x_dev), self.pview(self.pflat, l, 'k'), None, _ptr(dst, coff), ld, None,
-                                    sc, sh, 1, N, h, w, l.cout, st)
+                                    sc, sh, 1, self._ab_out(l), N, h, w, l.cout, st)
             elif l.kind == 'conv':
-                self._conv_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h, w, st)
+                self._conv_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h, w, st, absmax=self._ab_out(l))
             else:
-                self._convT_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h // 2, w // 2, st)
+                self._convT_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h // 2, w // 2, st,
+                                absmax=self._ab_out(l))
         lo = self.by_name['out']
         L.dc_head_fwd(_ptr(A['d0b']), self.pview(self.pflat, lo, 'k'), self.pview(self.pflat, lo, 'b'), None,
                       _ptr(A['p']), None, N * self.H * self.W, self.nfb, st)
@@ -516,7 +567,7 @@ class UNetEngine(object):
         for lvl in range(4):
             h, w = self._hw(lvl)
             part_floats = max(part_floats, L.dc_maxpool2x2_bwd_blocks(N, h, w, nfb << lvl) * (nfb << lvl) * 2)
-        T['stats_ws'] = torch.empty(stats_floats, dtype=torch.float32, device=dev)
+        T['stats_ws'] = torch.empty(stats_floats, dtype=torch.float64, device=dev)      # (sum, sum of squares) partials
         T['part_ws'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['part_ws2'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['absmax'] = torch.empty(4096, dtype=torch.float32, device=dev)
@@ -594,19 +645,20 @@ class UNetEngine(object):
             if step[0] == 'up':
                 _, lvl, src, dst, ld, h, w = step
                 mptr, keep, seed = self._up_drop_args(lvl, masks, step_seed)
-                L.dc_upsample2x_drop_fwd(_ptr(src), _ptr(dst), ld, mptr, keep, seed, N, h // 2, w // 2, self._cup(lvl), st)
+                L.dc_upsample2x_drop_fwd(_ptr(src), _ptr(dst), ld, mptr, keep, seed, *self._ab_up(lvl), N, h // 2, w // 2,
+                                         self._cup(lvl), st)
                 continue
             _, l, src, dst, coff, ld, h, w, prod = step
             z = T['z_' + l.name]
             bias = self.pview(self.pflat, l, 'b')
-            stats = _ptr(T['stats_ws'])
+            stats = T['stats_ws'].data_ptr()
             groups = 1
             bsrc = self._bnin_src(prod, T)
             xin, bn = (bsrc[0], bsrc[1]) if bsrc is not None else (_ptr(src) if src is not None else None, None)
             if l.kind == 'conv' and l.cin == 1:
                 tiles = L.dc_conv3x3_c1_tiles(N, h, w, l.cout)
                 L.dc_conv3x3_c1_fwd(_ptr(x_dev), self.pview(self.pflat, l, 'k'), bias, _ptr(z), l.cout, stats,
-                                    None, None, 0, N, h, w, l.cout, st)
+                                    None, None, 0, None, N, h, w, l.cout, st)
             elif l.kind == 'conv':
                 tiles = L.dc_conv3x3_tiles(N, h, w, l.cout)
                 self._conv_fwd(xin, l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h, w, st, bnin=bn)
@@ -626,7 +678,7 @@ class UNetEngine(object):
                                             self.stat_ptr(l, 0), self.stat_ptr(l, 1), self.sview(l, 'mmean'),
                                             self.sview(l, 'mvar'), self.pview(self.pflat, l, 'gamma'),
                                             self.pview(self.pflat, l, 'beta'), self.stat_ptr(l, 4) if nm_l else None,
-                                            self.stat_ptr(l, 5) if nm_l else None, st)
+                                            self.stat_ptr(l, 5) if nm_l else None, self._ab_out(l) if nm_l else None, st)
                 if nm_l:
                     continue
             elif l.name in self.nm:
@@ -635,7 +687,7 @@ class UNetEngine(object):
                                               self.stat_ptr(l, 0), self.stat_ptr(l, 1), self.sview(l, 'mmean'),
                                               self.sview(l, 'mvar'), self.pview(self.pflat, l, 'gamma'),
                                               self.pview(self.pflat, l, 'beta'), self.stat_ptr(l, 4),
-                                              self.stat_ptr(l, 5), st)
+                                              self.stat_ptr(l, 5), self._ab_out(l), st)
                 continue
             if not sync:
                 L.dc_bn_stats_finalize(stats, tiles, groups, l.cout, float(pixels), BN_EPS, mom,
@@ -644,7 +696,8 @@ class UNetEngine(object):
             mptr, keep, seed = self._drop_args(l, masks, step_seed)
             L.dc_bn_relu_drop_fwd(_ptr(z), self.stat_ptr(l, 0), self.stat_ptr(l, 1),
                                   self.pview(self.pflat, l, 'gamma'), self.pview(self.pflat, l, 'beta'),
-                                  mptr, keep, seed, _ptr(dst, coff), ld, pixels, l.cout, st)
+                                  mptr, keep, seed, _ptr(dst, coff), ld, pixels, l.cout,
+                                  float((world if sync else 1) * pixels), self._ab_out(l), st)
         if update_moving:
             self._fold_dirty = True
         lo = self.by_name['out']
@@ -788,17 +841,18 @@ class UNetEngine(object):
                 side.wait_event(ready)
             dk, ws = self.pview(self.gflat, l, 'k'), _ptr(T['wgrad_ws'])
             if bsrc is not None and l.kind == 'conv':
-                L.dc_conv3x3_wgrad_bnin_f16x3(bsrc[0], bsrc[1][0], bsrc[1][1], dz, dk, ws, scale, N, h, w, l.cin, l.cout, sw)
+                L.dc_conv3x3_wgrad_bnin_f16x3(bsrc[0], bsrc[1][0], bsrc[1][1], self._ab_in(l), dz, dk, ws, scale, N, h, w,
+                                              l.cin, l.cout, sw)
             elif bsrc is not None:
-                L.dc_convT2x2_wgrad_bnin_f16x3(bsrc[0], bsrc[1][0], bsrc[1][1], dz, dk, ws, scale, N, h // 2, w // 2,
-                                               l.cin, l.cout, sw)
+                L.dc_convT2x2_wgrad_bnin_f16x3(bsrc[0], bsrc[1][0], bsrc[1][1], self._ab_in(l), dz, dk, ws, scale, N,
+                                               h // 2, w // 2, l.cin, l.cout, sw)
             elif l.kind == 'conv':
                 if f16:
-                    L.dc_conv3x3_wgrad_f16x3(x_in, dz, dk, ws, scale, N, h, w, l.cin, l.cout, sw)
+                    L.dc_conv3x3_wgrad_f16x3(x_in, dz, dk, ws, scale, self._ab_in(l), N, h, w, l.cin, l.cout, sw)
                 else:
                     L.dc_conv3x3_wgrad(x_in, dz, dk, ws, N, h, w, l.cin, l.cout, sw)
             elif f16:
-                L.dc_convT2x2_wgrad_f16x3(x_in, dz, dk, ws, scale, N, h // 2, w // 2, l.cin, l.cout, sw)
+                L.dc_convT2x2_wgrad_f16x3(x_in, dz, dk, ws, scale, self._ab_in(l), N, h // 2, w // 2, l.cin, l.cout, sw)
             else:
                 L.dc_convT2x2_wgrad(x_in, dz, dk, ws, N, h // 2, w // 2, l.cin, l.cout, sw)
             if two:

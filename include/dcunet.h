@@ -46,18 +46,20 @@ int dc_pack_weights(const float* src, float* dst, int taps, int K, int Ncols,
 
 /* ---- Conv2D(nf,(3,3),'same')  unet_2d_summary.py:164-165 ---------------------
  * z = conv(x, w) + bias ; optional per-channel (sum, sumsq) partials of z for
- * BatchNorm (stats != NULL: float[tiles][Cout][2], tiles = dc_conv3x3_tiles());
+ * BatchNorm (stats != NULL: double[tiles][Cout][2], tiles = dc_conv3x3_tiles(); formed per tile from shifted sums
+ * and Chan merges, so the variance survives |mean| >> sigma -- csrc/common.h DcMoments);
  * optional fused inference epilogue y = relu?(z*scale + shift).
  * wp = dc_pack_weights(conv3x3 fwd form).  x: [N,H,W,Cin] dense, z: [N,H,W,Cout] with pixel stride z_ld. */
 int dc_conv3x3_tiles(int N, int H, int W, int Cout);
-int dc_conv3x3_fwd(const float* x, const float* wp, const float* bias, float* z, long z_ld, float* stats,
+int dc_conv3x3_fwd(const float* x, const float* wp, const float* bias, float* z, long z_ld, double* stats,
                    const float* scale, const float* shift, int relu,
                    int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 /* First layer (Cin == 1): x is the (N,H,W) image itself, w is the plain HWIO (3,3,1,Cout) kernel.
- * stats: float[dc_conv3x3_c1_tiles()][Cout][2]. */
+ * stats: double[dc_conv3x3_c1_tiles()][Cout][2].  out_absmax (nullable, float[Cout], zeroed by the caller): max |output|
+ * per channel is folded in (atomic max) -- the range-guard bound of the next f16x3 layer in inference. */
 int dc_conv3x3_c1_tiles(int N, int H, int W, int Cout);
-int dc_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, float* z, long z_ld, float* stats,
-                      const float* scale, const float* shift, int relu,
+int dc_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, float* z, long z_ld, double* stats,
+                      const float* scale, const float* shift, int relu, float* out_absmax,
                       int N, int H, int W, int Cout, dc_stream_t stream);
 /* dx = conv3x3_transpose(dz): wp = dc_pack_weights(conv3x3 dgrad form). dz: [N,H,W,Cout], dx: [N,H,W,Cin]. */
 int dc_conv3x3_dgrad(const float* dz, const float* wp, float* dx,
@@ -71,9 +73,15 @@ int dc_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* ws,
 /* ---- split-fp16 ("f16x3") variants: same contraction on the fp16 matrix cores with fp32-grade accuracy ----
  * Every fp32 operand is split exactly into hi + lo fp16 (22-bit significand) and hi*hi + hi*lo + lo*hi is
  * accumulated in fp32: 3 fp16 MFMAs replace 8 fp32 ones.  wp16 = dc_pack_weights_f16x3 (same forms/strides as
- * dc_pack_weights; dc_pack_weights_f16x3_floats() floats of storage).  in_scale: nullable DEVICE scalar, a power of
- * two applied to the input tensor before the split and undone in the epilogue (fp16 range; 1 for activations,
- * dc_pow2_scale_from_absmax() for gradients). */
+ * dc_pack_weights; dc_pack_weights_f16x3_floats() floats of storage).
+ * fp16's exponent range is covered by exact POWER-OF-TWO operand scales, undone in the epilogue:
+ *   - weights: dc_pack_weights_f16x3 brings max|w| into [2^10, 2^11) and stores the scale in a 16-byte trailer of wp16;
+ *   - gradient operands: in_scale / dz_scale, a nullable DEVICE scalar from dc_bn_bwd_apply_finalize;
+ *   - activation operands: in_abound / x_abound, a nullable per-channel magnitude bound (float[Cin]) written by the
+ *     layer that produced the tensor -- dc_bn_stats_finalize_affine / dc_bn_relu_drop_fwd in training
+ *     (|gamma|*sqrt(count)+|beta|, valid for ANY data), the out_absmax of the producing kernel in inference; the
+ *     consumer scales so that the largest bound lands in [2^14, 2^15): no activation can reach fp16 inf, tiny
+ *     ones keep their low bits.  NULL = scale 1. */
 long dc_pack_weights_f16x3_floats(int taps, int K, int Ncols);
 int dc_pack_weights_f16x3(const float* src, void* dst, int taps, int K, int Ncols,
                           long s_tap, long s_k, long s_n, int flip, dc_stream_t stream);
@@ -81,22 +89,22 @@ int dc_pack_weights_f16x3(const float* src, void* dst, int taps, int K, int Ncol
  *   { src pointer, dst pointer, taps, K, Ncols, s_tap, s_k, s_n, flip, first block of the job };
  * the trailing sentinel entry only carries the grid size (= total_blocks) in its last field. */
 int dc_pack_weights_f16x3_batch(const long* jobs_dev, int njobs, int total_blocks, dc_stream_t stream);
-int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, float* stats,
-                         const float* scale, const float* shift, int relu, const float* in_scale,
+int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, double* stats,
+                         const float* scale, const float* shift, int relu, const float* in_abound, float* out_absmax,
                          int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
                            int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
-int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, float* stats,
-                          const float* scale, const float* shift, int relu, const float* in_scale,
+int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, double* stats,
+                          const float* scale, const float* shift, int relu, const float* in_abound, float* out_absmax,
                           int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 int dc_convT2x2_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
                             int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 /* weight gradients: same workspace (dc_*_wgrad_ws_floats) and fixed-order slab reduction as the fp32 entry points;
  * dz_scale = device scalar from dc_pow2_scale_from_absmax (nullable). */
 int dc_conv3x3_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,
-                           int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+                           const float* x_abound, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 int dc_convT2x2_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,
-                            int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+                            const float* x_abound, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 
 /* ---- BatchNorm + ReLU applied ON LOAD ("bnin"): the layer input is a NON-materialised activation -------------
  * Conv2D -> BatchNormalization -> Activation('relu') (unet_2d_summary.py:164-167) feeding the next Conv2D /
@@ -106,21 +114,24 @@ int dc_convT2x2_wgrad_f16x3(const float* x, const float* dz, float* dw, float* w
  * and forms relu(fmaf(z, in_scale, in_shift)) while staging the operand; zero padding stays zero.  Saves one HBM
  * write + one read of the activation per such layer (dc_bn_relu_drop_fwd is skipped).  Other arguments exactly as
  * in the entry point without _bnin. */
-int dc_bn_stats_finalize_affine(const float* partial, int parts, int groups, int C, double count, float eps,
+/* abound (nullable, float[C]): the activation's per-channel magnitude bound |gamma|*sqrt(count) + |beta| for the
+ * consumers' fp16 range guard. */
+int dc_bn_stats_finalize_affine(const double* partial, int parts, int groups, int C, double count, float eps,
                                 float momentum, float* mean, float* invstd, float* moving_mean, float* moving_var,
-                                const float* gamma, const float* beta, float* scale, float* shift, dc_stream_t stream);
-int dc_conv3x3_fwd_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const void* wp16,
-                              const float* bias, float* z, long z_ld, float* stats, const float* scale,
-                              const float* shift, int relu, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
-int dc_convT2x2_fwd_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const void* wp16,
-                               const float* bias, float* z, long z_ld, float* stats, const float* scale,
-                               const float* shift, int relu, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
-int dc_conv3x3_wgrad_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const float* dz,
-                                float* dw, float* ws, const float* dz_scale, int N, int H, int W, int Cin, int Cout,
+                                const float* gamma, const float* beta, float* scale, float* shift, float* abound,
                                 dc_stream_t stream);
-int dc_convT2x2_wgrad_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const float* dz,
-                                 float* dw, float* ws, const float* dz_scale, int N, int H, int W, int Cin, int Cout,
-                                 dc_stream_t stream);
+int dc_conv3x3_fwd_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const float* in_abound,
+                              const void* wp16, const float* bias, float* z, long z_ld, double* stats, const float* scale,
+                              const float* shift, int relu, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+int dc_convT2x2_fwd_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const float* in_abound,
+                               const void* wp16, const float* bias, float* z, long z_ld, double* stats, const float* scale,
+                               const float* shift, int relu, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+int dc_conv3x3_wgrad_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const float* in_abound,
+                                const float* dz, float* dw, float* ws, const float* dz_scale, int N, int H, int W,
+                                int Cin, int Cout, dc_stream_t stream);
+int dc_convT2x2_wgrad_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const float* in_abound,
+                                 const float* dz, float* dw, float* ws, const float* dz_scale, int N, int H, int W,
+                                 int Cin, int Cout, dc_stream_t stream);
 int dc_head_fwd_bnin(const float* z_in, const float* in_scale, const float* in_shift, const float* kh, const float* bh,
                      const uint8_t* y, float* p, float* partial, long pixels, int C, dc_stream_t stream);
 int dc_head_bwd_bnin(const float* z_in, const float* in_scale, const float* in_shift, const float* p, const uint8_t* y,
@@ -130,9 +141,9 @@ int dc_head_bwd_bnin(const float* z_in, const float* in_scale, const float* in_s
 
 /* ---- Conv2DTranspose(nf, 2, strides=2)  unet_2d_summary.py:156-157 -----------
  * x: [N,H,W,Cin] -> z: [N,2H,2W,Cout].  wp = dc_pack_weights(convT fwd form).
- * stats: float[dc_convT2x2_tiles()][4*Cout][2] (finalize with groups = 4). */
+ * stats: double[dc_convT2x2_tiles()][4*Cout][2] (finalize with groups = 4). */
 int dc_convT2x2_tiles(int N, int H, int W, int Cout);
-int dc_convT2x2_fwd(const float* x, const float* wp, const float* bias, float* z, long z_ld, float* stats,
+int dc_convT2x2_fwd(const float* x, const float* wp, const float* bias, float* z, long z_ld, double* stats,
                     const float* scale, const float* shift, int relu,
                     int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 int dc_convT2x2_dgrad(const float* dz, const float* wp, float* dx,
@@ -144,17 +155,20 @@ int dc_convT2x2_wgrad(const float* x, const float* dz, float* dw, float* ws,
 /* ---- BatchNormalization + Activation('relu') + Dropout  :158-159,:166-167,:179 ---
  * finalize: partial (sum,sumsq)[parts][groups*C][2] -> mean[C], invstd[C] = 1/sqrt(var_biased+eps);
  * if momentum >= 0: moving <- moving*momentum + batch*(1-momentum) (biased variance, Keras 2.0.6). */
-int dc_bn_stats_finalize(const float* partial, int parts, int groups, int C, double count, float eps,
+int dc_bn_stats_finalize(const double* partial, int parts, int groups, int C, double count, float eps,
                          float momentum, float* mean, float* invstd, float* moving_mean, float* moving_var,
                          dc_stream_t stream);
 /* inference fold: scale = gamma/sqrt(mvar+eps); shift = beta + (bias - mmean)*scale */
 int dc_bn_fold(const float* gamma, const float* beta, const float* mmean, const float* mvar, const float* bias,
                float eps, float* scale, float* shift, int C, dc_stream_t stream);
 /* a = dropout(relu(gamma*(z-mean)*invstd + beta)).  z dense [pixels][C]; out strided (out_ld).
- * Dropout: keep >= 1 -> none; mask != NULL -> explicit uint8 {0,1} [pixels][C]; else counter-based RNG(seed). */
+ * Dropout: keep >= 1 -> none; mask != NULL -> explicit uint8 {0,1} [pixels][C]; else counter-based RNG(seed).
+ * abound (nullable, float[C]): also writes the activation's per-channel magnitude bound
+ * (|gamma|*sqrt(count) + |beta|)/keep for the consumers' fp16 range guard; count = elements per channel the
+ * statistics were taken over (pixels; world*pixels under 'sync' data parallelism). */
 int dc_bn_relu_drop_fwd(const float* z, const float* mean, const float* invstd, const float* gamma,
                         const float* beta, const uint8_t* mask, float keep, uint64_t seed,
-                        float* out, long out_ld, long pixels, int C, dc_stream_t stream);
+                        float* out, long out_ld, long pixels, int C, double count, float* abound, dc_stream_t stream);
 /* backward, pass 1: partial[blocks][C][2] = (sum dy, sum dy*xhat) with dy = da*relu'(.)*dropmask/keep.
  * blocks = dc_bn_bwd_blocks(pixels, C). */
 int dc_bn_bwd_blocks(long pixels, int C);
@@ -197,10 +211,10 @@ int dc_maxpool2x2_bwd_bnred(const float* dy, const uint8_t* idx, const float* sk
  *             count = GLOBAL elements per channel (scale/shift nullable: the training affine of the _bnin consumers);
  *   backward: dc_bn_bwd_finalize | all-reduce(sum) of (dgamma, dbeta) | dc_bn_bwd_apply_count with the same count.
  * With one rank (or count == pixels) the results equal the local entry points'. */
-int dc_bn_stats_reduce(const float* partial, int parts, int groups, int C, double* sums, dc_stream_t stream);
+int dc_bn_stats_reduce(const double* partial, int parts, int groups, int C, double* sums, dc_stream_t stream);
 int dc_bn_stats_finalize_sums(const double* sums, int C, double count, float eps, float momentum, float* mean,
                               float* invstd, float* moving_mean, float* moving_var, const float* gamma,
-                              const float* beta, float* scale, float* shift, dc_stream_t stream);
+                              const float* beta, float* scale, float* shift, float* abound, dc_stream_t stream);
 int dc_bn_bwd_apply_count(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
                           const float* dgamma, const float* dbeta, float* dz, float* dbias_partial,
@@ -217,9 +231,11 @@ int dc_maxpool2x2_bwd(const float* dy, const uint8_t* idx, const float* skip, lo
 
 /* ---- UpSampling2D() + Dropout  :160-161,:198 (the upsampling_or_transpose != 'transpose' branch) -------------
  * nearest 2x of in [N,H,W,C] (dense) into out [N,2H,2W,C] (pixel stride out_ld), dropout applied to the
- * up-sampled tensor (mask uint8 [N,2H,2W,C] or counter RNG(seed); keep >= 1: none). */
+ * up-sampled tensor (mask uint8 [N,2H,2W,C] or counter RNG(seed); keep >= 1: none).
+ * abound_in / abound_out (nullable pair, float[C]): range-guard bound of the source / of the up-sampled tensor
+ * (= abound_in / keep). */
 int dc_upsample2x_drop_fwd(const float* in, float* out, long out_ld, const uint8_t* mask, float keep, uint64_t seed,
-                           int N, int H, int W, int C, dc_stream_t stream);
+                           const float* abound_in, float* abound_out, int N, int H, int W, int C, dc_stream_t stream);
 /* din[N,H,W,C] (dense) = sum over each 2x2 block of dout (pixel stride dout_ld) * dropout factor */
 int dc_upsample2x_drop_bwd(const float* dout, long dout_ld, const uint8_t* mask, float keep, uint64_t seed, float* din,
                            int N, int H, int W, int C, dc_stream_t stream);

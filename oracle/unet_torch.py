@@ -63,8 +63,9 @@ class UNetTorch(object):
             a = a * m / keep
         return a
 
-    def forward(self, x, training=False, masks=None, stats=None):
-        """x: (N,H,W) -> p: (N,H,W).  Internals are NCHW (torch's native CPU layout)."""
+    def forward(self, x, training=False, masks=None, stats=None, taps=None):
+        """x: (N,H,W) -> p: (N,H,W).  Internals are NCHW (torch's native CPU layout).
+        taps (dict): receives 'skip<lvl>' = the tensor each max-pool reads (detached, NCHW) for pool-index checks."""
         x = torch.as_tensor(np.asarray(x), dtype=self.dtype)[:, None]
         skips = {}
         for lvl in range(5):
@@ -73,6 +74,8 @@ class UNetTorch(object):
             x = self._block(tag + 'b', 'conv', x, training, masks, stats)
             if lvl < 4:
                 skips[lvl] = x
+                if taps is not None:
+                    taps['skip%d' % lvl] = x.detach()
                 x = F.max_pool2d(x, 2, 2)
         for lvl in (3, 2, 1, 0):
             if self.upsampling:
@@ -101,12 +104,12 @@ class UNetTorch(object):
         zero = torch.zeros_like(x)
         return (torch.where(pos, x, zero) - x * y + torch.log1p(torch.exp(torch.where(pos, -x, x)))).mean()
 
-    def loss_and_grads(self, x, y, masks=None):
+    def loss_and_grads(self, x, y, masks=None, taps=None):
         stats = {}
         for pl in self.P.values():
             for t in pl:
                 t.grad = None
-        p = self.forward(x, True, masks, stats)
+        p = self.forward(x, True, masks, stats, taps)
         loss = self.bce(p, torch.as_tensor(np.asarray(y), dtype=self.dtype))
         loss.backward()
         G = {name: [t.grad.numpy() for t in pl[:4] if t.grad is not None] for name, pl in self.P.items()}

@@ -42,7 +42,7 @@ def test_argument_validation_returns_codes(dclib):
     with pytest.raises(DcunetError, match='null pointer'):
         dclib.dc_conv3x3_fwd(None, None, None, None, 32, None, None, None, 0, 1, 8, 8, 8, 8, None)
     with pytest.raises(DcunetError, match='power of two'):
-        dclib.dc_bn_relu_drop_fwd(1, 1, 1, 1, 1, None, 1.0, 0, 16, 24, 10, 24, None)
+        dclib.dc_bn_relu_drop_fwd(1, 1, 1, 1, 1, None, 1.0, 0, 16, 24, 10, 24, 0.0, None, None)
     with pytest.raises(DcunetError, match='even'):
         dclib.dc_maxpool2x2_fwd(16, 8, 16, None, 1, 7, 8, 8, None)
 

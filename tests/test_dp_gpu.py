@@ -68,7 +68,7 @@ def test_shard_dropout_seed_reproduces_single_device_masks():
     def run(zz, s):
         out = torch.empty_like(zz)
         L.dc_bn_relu_drop_fwd(zz.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, keep, s,
-                              out.data_ptr(), C, zz.numel() // C, C, st)
+                              out.data_ptr(), C, zz.numel() // C, C, 0.0, None, st)
         torch.cuda.synchronize()
         return out.cpu().numpy()
 

@@ -95,18 +95,21 @@ def test_fullsize_train_step_is_bit_reproducible(setup):
     assert torch.equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
-def test_fullsize_window_train_step_vs_float64_torch_oracle():
-    """One train-mode forward + backward on FULL 512x512 windows (batch 2, nb_filters_base 32) against the float64 torch
-    oracle (autograd): probabilities and loss within 1e-4, gradients in rel-L2 / cosine (single ReLU-gate flips between
-    fp32 and float64 are legitimate discontinuities)."""
+@pytest.mark.parametrize('n', [2, 16])
+def test_fullsize_window_train_step_vs_float64_torch_oracle(n):
+    """One train-mode forward + backward on FULL 512x512 windows (nb_filters_base 32) against the float64 torch oracle
+    (autograd): batch 2, and batch 16 = BASELINE.json configs[2] verbatim.  Probabilities and BCE loss within 1e-4, pool
+    argmax indices exact wherever the float64 maximum is unambiguous, gradients in rel-L2 / cosine (single ReLU-gate
+    flips between fp32 and float64 are legitimate discontinuities)."""
     from deep_calcium_amd.net import UNetEngine
     from oracle.unet_torch import UNetTorch
-    n = 2
+    torch.cuda.empty_cache()
     Wt = on.init_weights(NFB, seed=77, randomize_bn=True)
     x, y = on.synthetic_batch(n, H, W)
     masks = on.make_drop_masks(NFB, n, H, W)
     ref = UNetTorch(Wt, NFB, dtype=torch.float64)
-    loss_ref, p_ref, G_ref, _ = ref.loss_and_grads(x, y, masks)
+    taps = {}
+    loss_ref, p_ref, G_ref, _ = ref.loss_and_grads(x, y, masks, taps=taps)
     eng = UNetEngine((H, W), nb_filters_base=NFB, prop_dropout_base=0.25)
     eng.set_weights(Wt)
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
@@ -117,6 +120,25 @@ def test_fullsize_window_train_step_vs_float64_torch_oracle():
     G = eng.grads()
     assert np.abs(p - p_ref).max() < 1e-4
     assert abs(loss - loss_ref) < 1e-4
+    # max-pool argmax (0..3, row-major in the 2x2 window, first maximum wins): bit-exact wherever the float64 oracle's
+    # top two window values are further apart than fp32 noise; all-equal windows (post-ReLU zeros) must give index 0
+    for lvl in range(4):
+        t = taps['skip%d' % lvl]                                   # (n, C, h, w) float64
+        nn, C, h, w = t.shape
+        win = t.reshape(nn, C, h // 2, 2, w // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(nn, h // 2, w // 2, C, 4)
+        top2 = win.topk(2, dim=-1).values
+        clear = ((top2[..., 0] - top2[..., 1]) > 1e-4).numpy()
+        ref_idx = win.argmax(dim=-1).numpy()
+        got = eng._acts(n)['idx%d' % lvl].cpu().numpy()
+        assert clear.mean() > 0.3
+        assert np.array_equal(got[clear], ref_idx[clear]), lvl
+        # ties: wherever the kernel's OWN input window is all-equal (post-ReLU / dropped zeros) the index is 0
+        own = eng._acts(n)['cat%d' % lvl][..., eng._cup(lvl):]
+        ow = own.reshape(nn, h // 2, 2, w // 2, 2, C).permute(0, 1, 3, 5, 2, 4).reshape(nn, h // 2, w // 2, C, 4)
+        flat0 = (ow.max(dim=-1).values == ow.min(dim=-1).values).cpu().numpy()
+        assert flat0.mean() > 0.01 and (got[flat0] == 0).all(), lvl
+        del t, win, top2, own, ow
+    taps.clear()
     fg = np.concatenate([g.ravel() for k in G_ref for j, g in enumerate(G[k]) if not (j == 1 and k != 'out')]).astype(np.float64)
     fr = np.concatenate([np.asarray(g).ravel() for k in G_ref for j, g in enumerate(G_ref[k]) if not (j == 1 and k != 'out')])
     assert fg.shape == fr.shape

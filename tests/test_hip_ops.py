@@ -76,7 +76,7 @@ def test_conv3x3_fwd_dgrad_wgrad(dclib, N, H, W, Ci, Co):
     wpd = pack(L, K, 9, Co, Ci, Ci * Co, 1, Co, 1)
     z = torch.full((N, H, W, Co), float('nan'), device='cuda')
     tiles = L.dc_conv3x3_tiles(N, H, W, Co)
-    stats = torch.zeros(tiles * Co * 2, device='cuda')
+    stats = torch.zeros(tiles * Co * 2, device='cuda', dtype=torch.float64)
     L.dc_conv3x3_fwd(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), z.data_ptr(), Co, stats.data_ptr(), None, None, 0,
                      N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
@@ -125,13 +125,14 @@ def test_conv3x3_f16x3_fwd_dgrad(dclib, N, H, W, Ci, Co):
     L.dc_pack_weights_f16x3(Kd.data_ptr(), wpd.data_ptr(), 9, Co, Ci, Ci * Co, 1, Co, 1, None)
     z = torch.full((N, H, W, Co), float('nan'), device='cuda')
     tiles = L.dc_conv3x3_tiles(N, H, W, Co)
-    stats = torch.zeros(tiles * Co * 2, device='cuda')
+    stats = torch.zeros(tiles * Co * 2, device='cuda', dtype=torch.float64)
     L.dc_conv3x3_fwd_f16x3(dev(x).data_ptr(), wp.data_ptr(), dev(b).data_ptr(), z.data_ptr(), Co, stats.data_ptr(),
-                           None, None, 0, None, N, H, W, Ci, Co, None)
+                           None, None, 0, None, None, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert rel_err(z.cpu().numpy(), z_ref) < 2e-5
     st = stats.cpu().numpy().reshape(tiles, Co, 2).astype(np.float64).sum(0)
     assert np.allclose(st[:, 0], z_ref.sum((0, 1, 2)), rtol=1e-4, atol=1e-3 * np.sqrt(N * H * W))
+    assert np.allclose(st[:, 1], (z_ref ** 2).sum((0, 1, 2)), rtol=1e-4)
     amax = dev(np.array([np.abs(dz).max()], np.float32))
     scl = torch.empty(1, device='cuda')
     L.dc_pow2_scale_from_absmax(amax.data_ptr(), 1, 1024.0, scl.data_ptr(), None)
@@ -142,7 +143,7 @@ def test_conv3x3_f16x3_fwd_dgrad(dclib, N, H, W, Ci, Co):
     ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, H, W, Ci, Co), device='cuda')
     dw = torch.full((3, 3, Ci, Co), float('nan'), device='cuda')
     L.dc_conv3x3_wgrad_f16x3(dev(x).data_ptr(), dev(dz).data_ptr(), dw.data_ptr(), ws.data_ptr(), scl.data_ptr(),
-                             N, H, W, Ci, Co, None)
+                             None, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     _, dK_ref, _ = on.conv3x3_bwd(x.astype(np.float64), K.astype(np.float64), dz.astype(np.float64))
     assert rel_err(dw.cpu().numpy(), dK_ref) < 2e-5
@@ -166,15 +167,19 @@ def test_bn_relu_on_load_conv_convT_wgrad_head(dclib, N, H, W, Ci, Co):
     # statistics through the library: partial sums -> finalize_affine (mean, invstd, scale, shift)
     part = np.stack([zin.reshape(-1, Ci).astype(np.float64).sum(0), (zin.reshape(-1, Ci).astype(np.float64) ** 2).sum(0)], -1)
     mean, invstd, sc, sh = (torch.empty(Ci, device='cuda') for _ in range(4))
-    L.dc_bn_stats_finalize_affine(dev(part.astype(np.float32)).data_ptr(), 1, 1, Ci, float(N * H * W), 1e-3, -1.0,
+    ab = torch.empty(Ci, device='cuda')
+    L.dc_bn_stats_finalize_affine(dev(part).data_ptr(), 1, 1, Ci, float(N * H * W), 1e-3, -1.0,
                                   mean.data_ptr(), invstd.data_ptr(), None, None, dev(gamma).data_ptr(),
-                                  dev(beta).data_ptr(), sc.data_ptr(), sh.data_ptr(), None)
+                                  dev(beta).data_ptr(), sc.data_ptr(), sh.data_ptr(), ab.data_ptr(), None)
     # the materialised activation from the library's own BN kernel (same affine, same bits)
     a = torch.empty(N, H, W, Ci, device='cuda')
     L.dc_bn_relu_drop_fwd(dev(zin).data_ptr(), mean.data_ptr(), invstd.data_ptr(), dev(gamma).data_ptr(),
-                          dev(beta).data_ptr(), None, 1.0, 0, a.data_ptr(), Ci, N * H * W, Ci, None)
+                          dev(beta).data_ptr(), None, 1.0, 0, a.data_ptr(), Ci, N * H * W, Ci, 0.0, None, None)
     torch.cuda.synchronize()
     a_np = a.cpu().numpy()
+    # the range-guard bound really bounds the activation, per channel
+    assert np.allclose(ab.cpu().numpy(), np.abs(gamma) * np.sqrt(N * H * W) + np.abs(beta), rtol=1e-6)
+    assert (a_np.reshape(-1, Ci).max(0) <= ab.cpu().numpy()).all()
     mu64 = zin.reshape(-1, Ci).astype(np.float64).mean(0)
     var64 = zin.reshape(-1, Ci).astype(np.float64).var(0)
     a_ref = np.maximum((zin.astype(np.float64) - mu64) / np.sqrt(var64 + 1e-3) * gamma + beta, 0)
@@ -187,10 +192,10 @@ def test_bn_relu_on_load_conv_convT_wgrad_head(dclib, N, H, W, Ci, Co):
     wp = torch.empty(L.dc_pack_weights_f16x3_floats(9, Ci, Co), device='cuda')
     L.dc_pack_weights_f16x3(Kd.data_ptr(), wp.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
     z1 = torch.full((N, H, W, Co), float('nan'), device='cuda'); z2 = torch.full_like(z1, float('nan'))
-    L.dc_conv3x3_fwd_f16x3(a.data_ptr(), wp.data_ptr(), None, z1.data_ptr(), Co, None, None, None, 0, None,
+    L.dc_conv3x3_fwd_f16x3(a.data_ptr(), wp.data_ptr(), None, z1.data_ptr(), Co, None, None, None, 0, ab.data_ptr(), None,
                            N, H, W, Ci, Co, None)
-    L.dc_conv3x3_fwd_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), wp.data_ptr(), None, z2.data_ptr(),
-                                Co, None, None, None, 0, N, H, W, Ci, Co, None)
+    L.dc_conv3x3_fwd_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), ab.data_ptr(), wp.data_ptr(), None,
+                                z2.data_ptr(), Co, None, None, None, 0, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert torch.equal(z1, z2)                       # same operand bits -> same result bits
     z_ref = on.conv3x3_fwd(a_ref, K.astype(np.float64), np.zeros(Co))
@@ -203,9 +208,10 @@ def test_bn_relu_on_load_conv_convT_wgrad_head(dclib, N, H, W, Ci, Co):
     ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, H, W, Ci, Co), device='cuda')
     dw1 = torch.full((3, 3, Ci, Co), float('nan'), device='cuda'); dw2 = torch.full_like(dw1, float('nan'))
     dzd = dev(dz)
-    L.dc_conv3x3_wgrad_f16x3(a.data_ptr(), dzd.data_ptr(), dw1.data_ptr(), ws.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
-    L.dc_conv3x3_wgrad_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), dzd.data_ptr(), dw2.data_ptr(),
-                                  ws.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
+    L.dc_conv3x3_wgrad_f16x3(a.data_ptr(), dzd.data_ptr(), dw1.data_ptr(), ws.data_ptr(), scl.data_ptr(), ab.data_ptr(),
+                             N, H, W, Ci, Co, None)
+    L.dc_conv3x3_wgrad_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), ab.data_ptr(), dzd.data_ptr(),
+                                  dw2.data_ptr(), ws.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert torch.equal(dw1, dw2)
     _, dK_ref, _ = on.conv3x3_bwd(a_ref, K.astype(np.float64), dz.astype(np.float64))
@@ -217,10 +223,10 @@ def test_bn_relu_on_load_conv_convT_wgrad_head(dclib, N, H, W, Ci, Co):
     wpt = torch.empty(L.dc_pack_weights_f16x3_floats(1, Ci, 4 * Co), device='cuda')
     L.dc_pack_weights_f16x3(KTd.data_ptr(), wpt.data_ptr(), 1, Ci, 4 * Co, 0, 1, Ci, 0, None)
     t1 = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device='cuda'); t2 = torch.full_like(t1, float('nan'))
-    L.dc_convT2x2_fwd_f16x3(a.data_ptr(), wpt.data_ptr(), None, t1.data_ptr(), Co, None, None, None, 0, None,
+    L.dc_convT2x2_fwd_f16x3(a.data_ptr(), wpt.data_ptr(), None, t1.data_ptr(), Co, None, None, None, 0, ab.data_ptr(), None,
                             N, H, W, Ci, Co, None)
-    L.dc_convT2x2_fwd_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), wpt.data_ptr(), None, t2.data_ptr(),
-                                 Co, None, None, None, 0, N, H, W, Ci, Co, None)
+    L.dc_convT2x2_fwd_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), ab.data_ptr(), wpt.data_ptr(), None,
+                                 t2.data_ptr(), Co, None, None, None, 0, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert torch.equal(t1, t2)
     assert rel_err(t2.cpu().numpy(), on.convT2x2_fwd(a_ref, KT.astype(np.float64), np.zeros(Co))) < 2e-5
@@ -228,9 +234,10 @@ def test_bn_relu_on_load_conv_convT_wgrad_head(dclib, N, H, W, Ci, Co):
     wst = torch.empty(L.dc_convT2x2_wgrad_ws_floats(N, H, W, Ci, Co), device='cuda')
     g1 = torch.full((2, 2, Co, Ci), float('nan'), device='cuda'); g2 = torch.full_like(g1, float('nan'))
     dztd = dev(dzt)
-    L.dc_convT2x2_wgrad_f16x3(a.data_ptr(), dztd.data_ptr(), g1.data_ptr(), wst.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
-    L.dc_convT2x2_wgrad_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), dztd.data_ptr(), g2.data_ptr(),
-                                   wst.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
+    L.dc_convT2x2_wgrad_f16x3(a.data_ptr(), dztd.data_ptr(), g1.data_ptr(), wst.data_ptr(), scl.data_ptr(), ab.data_ptr(),
+                              N, H, W, Ci, Co, None)
+    L.dc_convT2x2_wgrad_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), ab.data_ptr(), dztd.data_ptr(),
+                                   g2.data_ptr(), wst.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert torch.equal(g1, g2)
 
@@ -287,10 +294,11 @@ def test_conv3x3_c1(dclib, N, H, W, Co):
     z_ref = on.conv3x3_fwd(x[..., None].astype(np.float64), K.astype(np.float64), b.astype(np.float64))
     _, dK_ref, _ = on.conv3x3_bwd(x[..., None].astype(np.float64), K.astype(np.float64), dz.astype(np.float64))
     tiles = L.dc_conv3x3_c1_tiles(N, H, W, Co)
-    stats = torch.zeros(tiles * Co * 2, device='cuda')
+    stats = torch.zeros(tiles * Co * 2, device='cuda', dtype=torch.float64)
     z = torch.empty((N, H, W, Co), device='cuda')
+    amx = torch.zeros(Co, device='cuda')
     L.dc_conv3x3_c1_fwd(dev(x).data_ptr(), dev(K).data_ptr(), dev(b).data_ptr(), z.data_ptr(), Co, stats.data_ptr(),
-                        None, None, 0, N, H, W, Co, None)
+                        None, None, 0, amx.data_ptr(), N, H, W, Co, None)
     ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, H, W, 1, Co), device='cuda')
     dw = torch.empty((3, 3, 1, Co), device='cuda')
     L.dc_conv3x3_wgrad(dev(x).data_ptr(), dev(dz).data_ptr(), dw.data_ptr(), ws.data_ptr(), N, H, W, 1, Co, None)
@@ -298,6 +306,8 @@ def test_conv3x3_c1(dclib, N, H, W, Co):
     assert rel_err(z.cpu().numpy(), z_ref) < 1e-5
     st = stats.cpu().numpy().reshape(tiles, Co, 2).astype(np.float64).sum(0)
     assert np.allclose(st[:, 0], z_ref.sum((0, 1, 2)), rtol=1e-4, atol=1e-2)
+    assert np.allclose(st[:, 1], (z_ref ** 2).sum((0, 1, 2)), rtol=1e-5)
+    assert np.allclose(amx.cpu().numpy(), np.abs(z.cpu().numpy()).max((0, 1, 2)), rtol=0, atol=0)     # measured max |out|
     assert rel_err(dw.cpu().numpy(), dK_ref) < 1e-5
 
 
@@ -317,7 +327,7 @@ def test_convT2x2(dclib, N, H, W, Ci, Co):
     wp = pack(L, K, 1, Ci, 4 * Co, 0, 1, Ci, 0)
     wpd = pack(L, K, 4, Co, Ci, Co * Ci, Ci, 1, 0)
     tiles = L.dc_convT2x2_tiles(N, H, W, Co)
-    stats = torch.zeros(tiles * 4 * Co * 2, device='cuda')
+    stats = torch.zeros(tiles * 4 * Co * 2, device='cuda', dtype=torch.float64)
     z = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device='cuda')
     L.dc_convT2x2_fwd(dev(x).data_ptr(), wp.data_ptr(), dev(b).data_ptr(), z.data_ptr(), Co, stats.data_ptr(),
                       None, None, 0, N, H, W, Ci, Co, None)
@@ -343,19 +353,21 @@ def test_convT2x2(dclib, N, H, W, Ci, Co):
     L.dc_pack_weights_f16x3(Kd.data_ptr(), wp16.data_ptr(), 1, Ci, 4 * Co, 0, 1, Ci, 0, None)
     L.dc_pack_weights_f16x3(Kd.data_ptr(), wpd16.data_ptr(), 4, Co, Ci, Co * Ci, Ci, 1, 0, None)
     z2 = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device='cuda')
-    stats2 = torch.zeros(tiles * 4 * Co * 2, device='cuda')
+    stats2 = torch.zeros(tiles * 4 * Co * 2, device='cuda', dtype=torch.float64)
+    amx = torch.zeros(Co, device='cuda')
     L.dc_convT2x2_fwd_f16x3(dev(x).data_ptr(), wp16.data_ptr(), dev(b).data_ptr(), z2.data_ptr(), Co, stats2.data_ptr(),
-                            None, None, 0, None, N, H, W, Ci, Co, None)
+                            None, None, 0, None, amx.data_ptr(), N, H, W, Ci, Co, None)
     dx2 = torch.full((N, H, W, Ci), float('nan'), device='cuda')
     L.dc_convT2x2_dgrad_f16x3(dev(dzs).data_ptr(), wpd16.data_ptr(), dx2.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert rel_err(z2.cpu().numpy(), z_ref) < 2e-5
+    assert np.array_equal(amx.cpu().numpy(), np.abs(z2.cpu().numpy()).max((0, 1, 2)))
     st2 = stats2.cpu().numpy().reshape(tiles, 4, Co, 2).astype(np.float64).sum((0, 1))
     assert np.allclose(st2[:, 1], (z_ref ** 2).sum((0, 1, 2)), rtol=1e-4)
     assert rel_err(dx2.cpu().numpy(), dx_ref * 1e-7) < 2e-5
     dw2 = torch.full((2, 2, Co, Ci), float('nan'), device='cuda')
     L.dc_convT2x2_wgrad_f16x3(dev(x).data_ptr(), dev(dzs).data_ptr(), dw2.data_ptr(), ws.data_ptr(), scl.data_ptr(),
-                              N, H, W, Ci, Co, None)
+                              None, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert rel_err(dw2.cpu().numpy(), dK_ref * 1e-7) < 2e-5
 
@@ -393,7 +405,7 @@ def test_batchnorm_relu_dropout_fwd_bwd(dclib, pixels_shape, C, keep):
 
     # statistics through the finalize kernel (one "tile" per image row block -> exercises the partial reduction)
     parts = N * H
-    part = np.stack([z64.reshape(parts, W, C).sum(1), (z64 ** 2).reshape(parts, W, C).sum(1)], axis=-1).astype(np.float32)
+    part = np.stack([z64.reshape(parts, W, C).sum(1), (z64 ** 2).reshape(parts, W, C).sum(1)], axis=-1)
     mean, invstd = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
     mm, mv = dev(np.full(C, 0.25, np.float32)), dev(np.full(C, 2.0, np.float32))
     L.dc_bn_stats_finalize(dev(part).data_ptr(), parts, 1, C, float(M), 1e-3, 0.9, mean.data_ptr(), invstd.data_ptr(),
@@ -408,7 +420,7 @@ def test_batchnorm_relu_dropout_fwd_bwd(dclib, pixels_shape, C, keep):
     mptr = md.data_ptr() if keep < 1 else None
     out = torch.zeros((N, H, W, 2 * C), device='cuda')          # strided destination (concat slice)
     L.dc_bn_relu_drop_fwd(zd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(), mptr, keep, 0,
-                          out.data_ptr() + 4 * C, 2 * C, M, C, None)
+                          out.data_ptr() + 4 * C, 2 * C, M, C, 0.0, None, None)
     torch.cuda.synchronize()
     o = out.cpu().numpy()
     assert np.all(o[..., :C] == 0)
@@ -448,13 +460,13 @@ def test_bn_constant_input_kat(dclib):
     L = dclib
     C, M = 32, 512
     z = np.full((M, C), 3.25, np.float32)
-    part = np.stack([z.sum(0), (z.astype(np.float64) ** 2).sum(0)], -1).astype(np.float32)[None]
+    part = np.stack([z.astype(np.float64).sum(0), (z.astype(np.float64) ** 2).sum(0)], -1)[None]
     mean, invstd = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
     L.dc_bn_stats_finalize(dev(part).data_ptr(), 1, 1, C, float(M), 1e-3, -1.0, mean.data_ptr(), invstd.data_ptr(), None, None, None)
     beta = np.linspace(-1, 1, C).astype(np.float32)
     out = torch.empty((M, C), device='cuda')
     L.dc_bn_relu_drop_fwd(dev(z).data_ptr(), mean.data_ptr(), invstd.data_ptr(), dev(np.ones(C, np.float32)).data_ptr(),
-                          dev(beta).data_ptr(), None, 1.0, 0, out.data_ptr(), C, M, C, None)
+                          dev(beta).data_ptr(), None, 1.0, 0, out.data_ptr(), C, M, C, 0.0, None, None)
     torch.cuda.synchronize()
     assert np.allclose(out.cpu().numpy(), np.maximum(beta, 0)[None].repeat(M, 0), atol=5e-6)
 
@@ -469,7 +481,7 @@ def test_dropout_rng_is_reproducible_and_unbiased(dclib):
         out = torch.empty((M, C), device='cuda')
         # mean 0, invstd 1, gamma 1, beta 0 -> y = z = 1
         L.dc_bn_relu_drop_fwd(dev(z).data_ptr(), zero.data_ptr(), one.data_ptr(), one.data_ptr(), zero.data_ptr(), None,
-                              keep, seed, out.data_ptr(), C, M, C, None)
+                              keep, seed, out.data_ptr(), C, M, C, 0.0, None, None)
         torch.cuda.synchronize()
         outs.append(out.cpu().numpy())
     assert np.array_equal(outs[0], outs[1])
@@ -616,9 +628,9 @@ def test_bnred_sums_from_pool_and_head_backward(dclib, N, H, W, C, keep):
         pixels = N * H * W
         sc, sh = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
         part0 = np.stack([z.reshape(-1, C).astype(np.float64).sum(0), (z.reshape(-1, C).astype(np.float64) ** 2).sum(0)], -1)
-        L.dc_bn_stats_finalize_affine(dev(part0.astype(np.float32)).data_ptr(), 1, 1, C, float(pixels), 1e-3, -1.0,
+        L.dc_bn_stats_finalize_affine(dev(part0).data_ptr(), 1, 1, C, float(pixels), 1e-3, -1.0,
                                       md.data_ptr(), isd.data_ptr(), None, None, gd.data_ptr(), bd.data_ptr(),
-                                      sc.data_ptr(), sh.data_ptr(), None)
+                                      sc.data_ptr(), sh.data_ptr(), None, None)
         kh = (rs.standard_normal((C, 2)) * 0.3).astype(np.float32)
         y = (rs.random_sample(pixels) < 0.3).astype(np.uint8)
         p = rs.random_sample(pixels).astype(np.float32)
