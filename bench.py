@@ -162,6 +162,93 @@ def pmc_traffic(kname):
     return t.get('bytes_per_launch'), 'rocprofv3 PMC passes of this kernel source, %s' % t.get('source', '')
 
 
+def bench_infer(args, model, xd, rank, world):
+    """BASELINE configs[1]: forward only (BatchNorm folded into the conv epilogues), batch 8 of 512x512, replicas only."""
+    import torch
+    from deep_calcium_amd import parallel
+    eng, B = model.engine, xd.shape[0]
+    timer = KernelTimer(eng.L)
+    eng.L = timer
+    for _ in range(args.warmup):
+        eng.forward_infer(xd)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.forward_infer(xd)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = True
+    for _ in range(3):
+        eng.forward_infer(xd)
+    torch.cuda.synchronize()
+    n_launch, k_ms, k_flops = timer.summarize()
+    if rank != 0:
+        return
+    achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    kname, peak, mpf = KernelTimer.KERNELS[eng.mfma]
+    print(json.dumps({
+        'metric': '512x512 summary images/sec (forward only)', 'value': round(world * B * args.steps / dt, 2),
+        'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'UNet2DS forward-only, batch=%d 512x512 random fp32, nfb=32 (BASELINE.json configs[1])' % B,
+                   'parallelism': 'replicas x%d' % world},
+        'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': peak, 'unit': 'TFLOP/s',
+                     'frac': round(achieved / peak, 4), 'traffic': None, 'kernel': kname, 'launches': n_launch,
+                     'avg_launch_ms': round(k_ms / max(n_launch, 1), 4),
+                     'algorithmic_flops_per_launch': round(k_flops / max(n_launch, 1)),
+                     'mfma_flops_per_algorithmic_flop': mpf, 'matrix_pipe_frac': round(mpf * achieved / peak, 4)}}))
+
+
+def bench_tta(args, model, rank):
+    """BASELINE configs[4]: UNet2DSummary.predict(augmentation=True) over 19 datasets (synthetic 512x512 summary images;
+    the Neurofinder data is not available offline), end to end through the reference's API: model file load, reflect
+    pad, 8 augmented copies in one batch-8 forward, inverse maps, mean, threshold.  19 x 8 = 152 forwards per step."""
+    import tempfile
+    import torch
+    from deep_calcium_amd import UNet2DSummary
+    if rank != 0:
+        return
+    tmp = tempfile.mkdtemp(prefix='dc_tta_')
+    rs = np.random.RandomState(865)
+    paths = []
+    for k in range(19):
+        p = os.path.join(tmp, 'ds%02d.npz' % k)
+        np.savez(p, series_mean=(rs.random_sample((512, 512)) * 900 + 100).astype(np.float16), name=np.array('neurofinder.%02d' % k))
+        paths.append(p)
+    mpath = os.path.join(tmp, 'model.hdf5')
+    model.save(mpath, include_optimizer=False)
+    api = UNet2DSummary(cpdir=tmp)
+    for _ in range(max(1, args.warmup // 3)):
+        api.predict(paths, mpath, augmentation=True)
+    torch.cuda.synchronize()
+    steps = max(1, args.steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        Mp, _ = api.predict(paths, mpath, augmentation=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        api.predict(paths, mpath, augmentation=False)
+    torch.cuda.synchronize()
+    dt_plain = time.perf_counter() - t1
+    print(json.dumps({
+        'metric': '512x512 forwards/sec through UNet2DSummary.predict with 8x test-time augmentation',
+        'value': round(19 * 8 * steps / dt, 2), 'unit': 'forwards/s', 'n_gpus': 1, 'steps': steps, 'warmup': max(1, args.warmup // 3),
+        'ms_per_step': round(dt / steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'UNet2DSummary.predict(augmentation=True), 19 synthetic 512x512 datasets x 8 TTA variants, '
+                               'nfb=32, model file loaded per call as the reference does (BASELINE.json configs[4])',
+                   'datasets_per_s': round(19 * steps / dt, 2), 'datasets_per_s_without_tta': round(19 * steps / dt_plain, 2),
+                   'positive_fraction': float(np.mean([m.mean() for m in Mp]))}}))
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) from THIS process,
     which has not touched the GPU (no HIP call, only a device count), wait for them and return their exit code.
@@ -213,13 +300,18 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='per-GPU batch (default 16 = BASELINE config)')
+    ap.add_argument('--batch', type=int, default=None,
+                    help='per-GPU batch (default: 16 for train = BASELINE configs[2], 8 for infer = configs[1])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--bn', default='local', choices=['local', 'sync'],
                     help="BatchNorm under data parallelism: per-rank statistics (default) or all-reduced ('sync')")
-    ap.add_argument('--mode', default='train', choices=['train', 'infer'],
-                    help="'infer' times the forward-only path (BASELINE configs[1]) for information; the contract line is 'train'")
+    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'tta'],
+                    help="train (default, the contract line: BASELINE configs[2]/[3]); infer = forward only, batch 8 "
+                         "(configs[1]); tta = UNet2DSummary.predict with 8x test-time augmentation over 19 synthetic "
+                         "512x512 datasets (configs[4]) -- the last two print the same JSON shape for profiles/ and DESIGN.md")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 8 if args.mode == 'infer' else BATCH_PER_GPU
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args.gpus))         # before anything in this process touches the GPU
@@ -248,20 +340,10 @@ def main():
     x, y = on.synthetic_batch(B, H, W, seed_x=865 + 1000 * rank, seed_y=866 + 1000 * rank)
     xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
 
+    if args.mode == 'tta':
+        return bench_tta(args, model, rank)
     if args.mode == 'infer':
-        for _ in range(args.warmup):
-            eng.forward_infer(xd)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.forward_infer(xd)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if rank == 0:
-            print(json.dumps({'metric': '512x512 summary images/sec (forward only, informational)', 'value': round(B * args.steps / dt, 2),
-                              'unit': 'images/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
-                              'ms_per_step': round(dt / args.steps * 1e3, 3), 'config': {'workload': 'UNet2DS forward, batch=%d 512x512' % B}}))
-        return
+        return bench_infer(args, model, xd, rank, world)
 
     timer = KernelTimer(eng.L)
     eng.L = timer

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <mutex>
 #include "../../include/dcunet.h"
 
 #define DC_OK 0
@@ -33,6 +34,24 @@ void dc_set_error(const char* fmt, ...);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel ON ONE DEVICE: set it once per (kernel,
+// device), from whichever host thread launches there first (dcunet.h: concurrent callers on different devices).
+struct DcLdsAttr {
+  std::mutex mu;
+  bool done[64] = {};
+};
+static inline int dc_func_max_lds(DcLdsAttr& st, const void* kern, int bytes, const char* name) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  DC_REQUIRE(e == hipSuccess, DC_EHIP, "%s: hipGetDevice: %s", name, hipGetErrorString(e));
+  std::lock_guard<std::mutex> lock(st.mu);
+  if (dev >= 0 && dev < 64 && st.done[dev]) return DC_OK;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  DC_REQUIRE(e == hipSuccess, DC_EHIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+  if (dev >= 0 && dev < 64) st.done[dev] = true;
+  return DC_OK;
+}
 
 static inline int dc_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool dc_is_pow2(long v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -107,10 +126,19 @@ __device__ __forceinline__ float dc_pow2_guard(float amax) {
   if (amax <= 0.f || e < 14u || e == 0xffu) return 1.f;                     // zero / denormal / inf / nan: leave alone
   return __builtin_bit_cast(float, (268u - e) << 23);                       // 2^(14 - floor(log2 amax))
 }
-__device__ __forceinline__ float dc_block_guard_scale(const float* __restrict__ abound, int n, float* tmp) {
+// In inference the bound is MEASURED: the producing kernel folds max |a| per channel into DC_ABOUND_SLOTS replicas of
+// the array (slot = workgroup id mod 8, `ld` floats apart) -- thousands of workgroups hammering ONE address per channel
+// with atomics cost 10-50 % of the memory-bound kernels, eight replicas make it noise -- and the consumer takes the max
+// over all slots (ld > 0); training writes slot 0 only (ld == 0).
+__device__ __forceinline__ float dc_block_guard_scale(const float* __restrict__ abound, int n, float* tmp, long ld = 0) {
   if (abound == nullptr) return 1.f;
   float m = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(abound[i]));
+  // one flat sweep over (replica, channel): independent loads, all in flight together
+  const int total = (ld > 0 ? DC_ABOUND_SLOTS : 1) * n;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int sl = i / n, c = i - sl * n;
+    m = fmaxf(m, fabsf(abound[sl * ld + c]));
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -121,10 +149,14 @@ __device__ __forceinline__ float dc_block_guard_scale(const float* __restrict__ 
   __syncthreads();
   return dc_pow2_guard(m);
 }
-// running max |v| per channel (inference: the measured bound of a folded-BN activation); order-independent
+// running max |v| per channel (inference: the measured bound of a folded-BN activation); order-independent.
+// Thousands of workgroups fold into the same few addresses: read first and skip the atomic unless it would raise the
+// value (a stale cached read only costs a redundant atomic; after the first workgroups nearly every call is a read).
 __device__ __forceinline__ void dc_atomic_absmax(float* dst, float v) {
-  atomicMax(reinterpret_cast<unsigned*>(dst), __builtin_bit_cast(unsigned, fabsf(v)));
+  const float a = fabsf(v);
+  if (a > __builtin_nontemporal_load(dst)) atomicMax(reinterpret_cast<unsigned*>(dst), __builtin_bit_cast(unsigned, a));
 }
+__device__ __forceinline__ long dc_absmax_slot(long ld) { return (long)(blockIdx.x & (DC_ABOUND_SLOTS - 1)) * ld; }
 
 // Buffer descriptor from provably wave-uniform inputs (readfirstlane), so hipcc does not wrap every buffer op in a
 // waterfall loop.  Out-of-range offsets read zeros / drop stores (hardware bounds check on num_records = bytes).

@@ -14,6 +14,7 @@ struct C1Params {
   const float* scale;
   const float* shift;
   float* absmax;   // nullable: per-channel max |output| (atomic max), the next layer's fp16 range-guard bound
+  long absmaxLd;   // floats between its DC_ABOUND_SLOTS replicas (common.h)
   int N, H, W, Cout, relu;
   long pixels, zLd;
 };
@@ -60,7 +61,7 @@ __device__ __forceinline__ void c1_finish(const C1Params& p, const C1Acc& a, int
       for (int e = 0; e < 4; ++e) {
         float m = a.amax[e];
         for (int k = 1; k < PPB; ++k) m = fmaxf(m, fm[e * 256 + k * C4 + q]);
-        dc_atomic_absmax(p.absmax + 4 * q + e, m);
+        dc_atomic_absmax(p.absmax + dc_absmax_slot(p.absmaxLd) + 4 * q + e, m);
       }
     }
     __syncthreads();
@@ -292,15 +293,15 @@ static int check_c1(const char* fn, int N, int H, int W, int Cout) {
 }
 
 extern "C" int dc_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, float* z, long z_ld, double* stats,
-                                 const float* scale, const float* shift, int relu, float* out_absmax, int N, int H,
-                                 int W, int Cout, dc_stream_t stream) {
+                                 const float* scale, const float* shift, int relu, float* out_absmax, long out_absmax_ld,
+                                 int N, int H, int W, int Cout, dc_stream_t stream) {
   DC_REQUIRE(x && w && z, DC_EINVAL, "dc_conv3x3_c1_fwd: null pointer");
   DC_REQUIRE(dc_aligned16(w) && dc_aligned16(z), DC_EINVAL, "dc_conv3x3_c1_fwd: w and z must be 16-byte aligned");
   DC_REQUIRE((scale == nullptr) == (shift == nullptr), DC_EINVAL, "dc_conv3x3_c1_fwd: scale and shift go together");
   int rc = check_c1("dc_conv3x3_c1_fwd", N, H, W, Cout);
   if (rc) return rc;
   C1Params p;
-  p.x = x; p.w = w; p.bias = bias; p.z = z; p.stats = stats; p.scale = scale; p.shift = shift; p.absmax = out_absmax;
+  p.x = x; p.w = w; p.bias = bias; p.z = z; p.stats = stats; p.scale = scale; p.shift = shift; p.absmax = out_absmax; p.absmaxLd = out_absmax_ld;
   p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.pixels = (long)N * H * W; p.zLd = z_ld;
   DC_REQUIRE(z_ld >= Cout && z_ld % 4 == 0, DC_EINVAL, "dc_conv3x3_c1_fwd: bad z_ld");
   // same grid (= the BN-partial row count dc_conv3x3_c1_tiles reports) for both kernels

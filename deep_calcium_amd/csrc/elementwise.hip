@@ -675,13 +675,15 @@ extern "C" int dc_maxpool2x2_bwd_bnred(const float* dy, const uint8_t* idx, cons
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                           long out_ld, const uint8_t* __restrict__ mask, float keep,
                                                           uint64_t seed, int N, int H, int W, int C,
-                                                          const float* __restrict__ ab_in, float* __restrict__ ab_out) {
+                                                          const float* __restrict__ ab_in, long ab_in_ld,
+                                                          float* __restrict__ ab_out, long ab_out_ld) {
   const int C4 = C >> 2;
   const long total = (long)N * 4 * H * W * C4;
   const bool drop = keep < 1.f;
   const float inv_keep = drop ? 1.f / keep : 1.f;
   if (ab_out && blockIdx.x == 0)       // range-guard bound of the up-sampled tensor = the source's, times 1/keep
-    for (int c = threadIdx.x; c < C; c += 256) ab_out[c] = ab_in[c] * inv_keep;
+    for (int s = 0; s < (ab_in_ld > 0 ? DC_ABOUND_SLOTS : 1); ++s)
+      for (int c = threadIdx.x; c < C; c += 256) ab_out[s * ab_out_ld + c] = ab_in[s * ab_in_ld + c] * inv_keep;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
     const int q = (int)(i % C4);
     long r = i / C4;
@@ -740,15 +742,15 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
 }
 
 extern "C" int dc_upsample2x_drop_fwd(const float* in, float* out, long out_ld, const uint8_t* mask, float keep,
-                                      uint64_t seed, const float* abound_in, float* abound_out, int N, int H, int W, int C,
-                                      dc_stream_t stream) {
+                                      uint64_t seed, const float* abound_in, long abound_in_ld, float* abound_out,
+                                      long abound_out_ld, int N, int H, int W, int C, dc_stream_t stream) {
   DC_REQUIRE((abound_in == nullptr) == (abound_out == nullptr), DC_EINVAL, "dc_upsample2x_drop_fwd: abound_in and abound_out go together");
   DC_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0 && out_ld >= C && out_ld % 4 == 0 && keep > 0.f,
              DC_EINVAL, "dc_upsample2x_drop_fwd: bad arguments");
   const long total = (long)N * 4 * H * W * (C / 4);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(upsample_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, out_ld, mask, keep,
-                     seed, N, H, W, C, abound_in, abound_out);
+                     seed, N, H, W, C, abound_in, abound_in_ld, abound_out, abound_out_ld);
   DC_CHECK_LAUNCH("dc_upsample2x_drop_fwd");
   return DC_OK;
 }
@@ -1145,5 +1147,51 @@ extern "C" int dc_fill(float* p, long n, float value, dc_stream_t stream) {
   const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
   hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, value);
   DC_CHECK_LAUNCH("dc_fill");
+  return DC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Test-time augmentation on the device (UNet2DSummary.predict(augmentation=True),
+// /root/reference/deepcalcium/models/neurons/unet_2d_summary.py:585-595 with the 8-entry table of
+// utils/neurons.py:112-137).  The augmentations are pixel permutations: the host applies the table's own numpy
+// functions to an index image ONCE and uploads the resulting maps, so the device cannot disagree with the table.
+//   dc_gather_maps : out[k][p] = in[maps[k][p]]                         (the K augmented copies of one padded image)
+//   dc_tta_merge   : m[p] = sum_k preds[k][invmaps[k][p]] / K  accumulated in DOUBLE in table order (= numpy's
+//                    float64 `mp += inv(...) / 8`), cropped to hs x ws, mask = m > threshold (uint8), as :588-595.
+__global__ __launch_bounds__(256) void gather_maps_kernel(const float* __restrict__ in, const int* __restrict__ maps,
+                                                         float* __restrict__ out, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) out[i] = in[maps[i]];
+}
+extern "C" int dc_gather_maps(const float* in, const int* maps, float* out, int K, long n, dc_stream_t stream) {
+  DC_REQUIRE(in && maps && out && K > 0 && n > 0, DC_EINVAL, "dc_gather_maps: bad arguments");
+  const long total = (long)K * n;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(gather_maps_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, maps, out, total);
+  DC_CHECK_LAUNCH("dc_gather_maps");
+  return DC_OK;
+}
+__global__ __launch_bounds__(256) void tta_merge_kernel(const float* __restrict__ preds, const int* __restrict__ invmaps,
+                                                       int K, long n, int W, int hs, int ws, double threshold,
+                                                       uint8_t* __restrict__ mask, float* __restrict__ mean_out) {
+  const long total = (long)hs * ws;
+  const double invK = 1.0 / (double)K;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int y = (int)(i / ws), x = (int)(i - (long)y * ws);
+    const long p = (long)y * W + x;
+    double m = 0.0;
+    for (int k = 0; k < K; ++k) m += (double)preds[(long)k * n + invmaps[(long)k * n + p]] * invK;
+    mask[i] = m > threshold ? 1 : 0;
+    if (mean_out) mean_out[i] = (float)m;
+  }
+}
+extern "C" int dc_tta_merge(const float* preds, const int* invmaps, int K, int H, int W, int hs, int ws, double threshold,
+                            uint8_t* mask, float* mean_out, dc_stream_t stream) {
+  DC_REQUIRE(preds && invmaps && mask && K > 0 && H > 0 && W > 0 && hs > 0 && ws > 0 && hs <= H && ws <= W, DC_EINVAL,
+             "dc_tta_merge: bad arguments");
+  const long total = (long)hs * ws;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(tta_merge_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, preds, invmaps, K, (long)H * W, W,
+                     hs, ws, threshold, mask, mean_out);
+  DC_CHECK_LAUNCH("dc_tta_merge");
   return DC_OK;
 }

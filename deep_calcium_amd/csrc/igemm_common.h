@@ -27,6 +27,8 @@ struct IgemmParams {
   // (dc_pack_weights_f16x3).  outAbsmax (nullable, biasMod floats): the epilogue folds max |output| per channel into it
   // (atomic max; the caller zeroes it) -- the bound the NEXT layer's guard reads in inference.
   const float* inAbound;
+  long inAboundLd;   // 0: one slot (training bound); > 0: DC_ABOUND_SLOTS measured replicas, this many floats apart
   float* outAbsmax;
+  long outAbsmaxLd;  // floats between the replicas of the output's array
 };
 

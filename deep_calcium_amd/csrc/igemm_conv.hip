@@ -245,13 +245,8 @@ template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB, i
 static int igemm_launch(IgemmParams p, hipStream_t st, const char* name) {
   using Cfg = IgemmCfg<KH, KW, S, PAD, TW, WAVES_M, MB, NB, CK>;
   auto kern = igemm_kernel<KH, KW, S, PAD, TW, WAVES_M, MB, NB, CK>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    DC_REQUIRE(e == hipSuccess, DC_EHIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
-    attr_set = true;
-  }
+  static DcLdsAttr lds_attr;      // one per template instantiation; per-device inside
+  if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES, name)) return rc;
   p.tilesX = dc_cdiv(p.Wout, TW);
   p.tilesY = dc_cdiv(p.Hout, Cfg::TH);
   dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY * dc_cdiv(p.Ncols, Cfg::BN)));

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   if (bnin)
     for (int i = tid; i < p.Cin; i += 256) { lds_sc[i] = p.inSc[i]; lds_sc[Cinp + i] = p.inSh[i]; }
   const float in_scale = (p.inScale ? *p.inScale : 1.f) *
-                         dc_block_guard_scale(p.inAbound, p.Cin, reinterpret_cast<float*>(smem));
+                         dc_block_guard_scale(p.inAbound, p.Cin, reinterpret_cast<float*>(smem), p.inAboundLd);
   if (bnin && p.inAbound == nullptr) __syncthreads();
   for (int c0 = 0; c0 < p.Cin; c0 += CK) {
     f32x4 csc = {1.f, 1.f, 1.f, 1.f}, csh = {0.f, 0.f, 0.f, 0.f};
@@ -337,14 +337,24 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
         }
         if (h == 0) red[(wave * NB + nb) * 32 + li] = m;
       }
-      if constexpr (TRACK) {
+      if constexpr (TRACK) {      // lanes h = 0 / 1 -> one value per (wave, column); the waves are folded below
         amax = fmaxf(amax, __shfl_xor(amax, 32));
-        if (h == 0 && n_ok) dc_atomic_absmax(p.outAbsmax + n % p.biasMod, amax);
+        if (h == 0) reinterpret_cast<float*>(smem + 4096)[(wave * NB + nb) * 32 + li] = n_ok ? amax : 0.f;   // behind `red`
       }
     }
   };
   if (p.outAbsmax) {
     if (interior) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{});
+    __syncthreads();
+    if (tid < Cfg::WAVES_N * NB * 32) {       // one atomic per output column per workgroup, into this workgroup's slot
+      const int wn = tid / (NB * 32), rem = tid % (NB * 32);
+      const float* fm = reinterpret_cast<const float*>(smem + 4096);
+      float m = fm[(wn * WAVES_M) * NB * 32 + rem];
+#pragma unroll
+      for (int wm = 1; wm < WAVES_M; ++wm) m = fmaxf(m, fm[(wn * WAVES_M + wm) * NB * 32 + rem]);
+      const int n = n0 + wn * NB * 32 + rem;
+      if (n < p.Ncols) dc_atomic_absmax(p.outAbsmax + dc_absmax_slot(p.outAbsmaxLd) + n % p.biasMod, m);
+    }
   } else {
     if (interior) epilogue(std::true_type{}, std::false_type{}); else epilogue(std::false_type{}, std::false_type{});
   }
@@ -367,13 +377,8 @@ template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB, i
 static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name) {
   using Cfg = IgemmH<KH, KW, S, PAD, TW, WAVES_M, MB, NB, CK_>;
   auto kern = igemm_f16x3_kernel<KH, KW, S, PAD, TW, WAVES_M, MB, NB, CK_>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 8 * 1024);
-    DC_REQUIRE(e == hipSuccess, DC_EHIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
-    attr_set = true;
-  }
+  static DcLdsAttr lds_attr;      // one per template instantiation; per-device inside
+  if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES + 8 * 1024, name)) return rc;
   p.tilesX = dc_cdiv(p.Wout, TW);
   p.tilesY = dc_cdiv(p.Hout, Cfg::TH);
   dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY * dc_cdiv(p.Ncols, Cfg::BN)));
@@ -537,7 +542,8 @@ static int check_h(const char* fn, const void* a, const void* b, const void* c, 
 
 extern "C" int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld,
                                     double* stats, const float* scale, const float* shift, int relu,
-                                    const float* in_abound, float* out_absmax, int N, int H, int W, int Cin, int Cout,
+                                    const float* in_abound, long in_abound_ld, float* out_absmax, long out_absmax_ld,
+                                    int N, int H, int W, int Cin, int Cout,
                                     dc_stream_t stream) {
   int rc = check_h("dc_conv3x3_fwd_f16x3", x, wp16, z, N, H, W, Cin, Cout);
   if (rc) return rc;
@@ -545,7 +551,8 @@ extern "C" int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const floa
   DC_REQUIRE(z_ld >= Cout, DC_EINVAL, "dc_conv3x3_fwd_f16x3: z_ld < Cout");
   IgemmParams p{};
   p.in = x; p.wp = reinterpret_cast<const float*>(wp16); p.bias = bias; p.out = z; p.stats = stats;
-  p.scale = scale; p.shift = shift; p.inAbound = in_abound; p.outAbsmax = out_absmax;
+  p.scale = scale; p.shift = shift; p.inAbound = in_abound; p.inAboundLd = in_abound_ld;
+  p.outAbsmax = out_absmax; p.outAbsmaxLd = out_absmax_ld;
   p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = Cout;
   p.relu = relu; p.scatterCo = 0; p.biasMod = Cout; p.outLd = z_ld;
   return conv3x3_h_launch(p, (hipStream_t)stream);
@@ -598,7 +605,8 @@ extern "C" int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* 
 
 extern "C" int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld,
                                      double* stats, const float* scale, const float* shift, int relu,
-                                     const float* in_abound, float* out_absmax, int N, int H, int W, int Cin, int Cout,
+                                     const float* in_abound, long in_abound_ld, float* out_absmax, long out_absmax_ld,
+                                    int N, int H, int W, int Cin, int Cout,
                                      dc_stream_t stream) {
   int rc = check_h("dc_convT2x2_fwd_f16x3", x, wp16, z, N, H, W, Cin, Cout);
   if (rc) return rc;
@@ -606,7 +614,8 @@ extern "C" int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const flo
   DC_REQUIRE(z_ld >= Cout, DC_EINVAL, "dc_convT2x2_fwd_f16x3: z_ld < Cout");
   IgemmParams p{};
   p.in = x; p.wp = reinterpret_cast<const float*>(wp16); p.bias = bias; p.out = z; p.stats = stats;
-  p.scale = scale; p.shift = shift; p.inAbound = in_abound; p.outAbsmax = out_absmax;
+  p.scale = scale; p.shift = shift; p.inAbound = in_abound; p.inAboundLd = in_abound_ld;
+  p.outAbsmax = out_absmax; p.outAbsmaxLd = out_absmax_ld;
   p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = 4 * Cout;
   p.relu = relu; p.scatterCo = Cout; p.biasMod = Cout; p.outLd = z_ld;
   return convT_fwd_h_launch(p, (hipStream_t)stream);

@@ -146,13 +146,8 @@ static int wgrad_launch(const float* A, const float* B, float* dw, float* ws, in
                         int Cm, int Cn, hipStream_t st, const char* name) {
   using Cfg = WgradCfg<KH, KW, S, PAD, TW, RW, WM, WN>;
   auto kern = wgrad_kernel<KH, KW, S, PAD, TW, RW, WM, WN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    DC_REQUIRE(e == hipSuccess, DC_EHIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
-    attr_set = true;
-  }
+  static DcLdsAttr lds_attr;      // one per template instantiation; per-device inside
+  if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES, name)) return rc;
   WgradPlan pl = wgrad_plan<KH, KW, S, PAD, TW, RW, WM, WN>(N, Hb, Wb, Cm, Cn);
   WgradParams p;
   p.A = A; p.B = B; p.slabs = ws;

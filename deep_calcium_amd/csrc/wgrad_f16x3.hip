@@ -341,13 +341,8 @@ static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, 
                           hipStream_t st, const char* name) {
   using Cfg = WgradHCfg<KH, KW, S, PAD, TW, RW, WM, WNW, NBW>;
   auto kern = wgrad_f16x3_kernel<KH, KW, S, PAD, TW, RW, WM, WNW, NBW, A_SCALED>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    DC_REQUIRE(e == hipSuccess, DC_EHIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
-    attr_set = true;
-  }
+  static DcLdsAttr lds_attr;      // one per template instantiation; per-device inside
+  if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES, name)) return rc;
   WgradHPlan pl = wgrad_h_plan<KH, KW, S, PAD, TW, RW, WM, WNW, NBW>(N, Hb, Wb, Cm, Cn);
   WgradHParams hp;
   WgradParams& p = hp.g;

@@ -189,12 +189,11 @@ class ReduceLROnPlateau(Callback):
 class Model(object):
     def __init__(self, window_shape, nb_filters_base=32, conv_kernel_init='he_normal', prop_dropout_base=0.25,
                  upsampling_or_transpose='transpose', device=None, seed=7535):
-        if conv_kernel_init != 'he_normal':
-            raise NotImplementedError("only conv_kernel_init='he_normal' (the reference default) is built")
         self.config = dict(window_shape=tuple(int(v) for v in window_shape), nb_filters_base=int(nb_filters_base),
                            prop_dropout_base=float(prop_dropout_base), upsampling_or_transpose=str(upsampling_or_transpose))
         self.engine = UNetEngine(self.config['window_shape'], nb_filters_base, prop_dropout_base, device=device, seed=seed,
-                                 upsampling=(upsampling_or_transpose != 'transpose'))      # unet_2d_summary.py:155,:160
+                                 upsampling=(upsampling_or_transpose != 'transpose'),      # unet_2d_summary.py:155,:160
+                                 conv_kernel_init=conv_kernel_init)                        # :149,:157,:165
         self.optimizer = None
         self.loss = None
         self.metrics_names = ['loss']
@@ -435,32 +434,106 @@ class Model(object):
                 cb.on_train_end({})
         return self.history
 
-    # -- checkpoint (own .npz container; Keras-HDF5 import/export is SURVEY 8f rank 1) ----------------------
+    # -- checkpoints ------------------------------------------------------------------------------------------------------
+    # '*.hdf5' / '*.h5' (what ModelCheckpoint passes, unet_2d_summary.py:423): the reference's Keras-2.0.x model-file layout,
+    # written in-process (keras_io / hdf5_min); anything else: the build's own .npz container.  Loading sniffs the file.
+    def _optimizer_state(self):
+        eng = self.engine
+        m, v = eng.mflat.cpu().numpy(), eng.vflat.cpu().numpy()
+        ms, vs = [], []
+        for l in eng.layers:
+            for key in ('k', 'b', 'gamma', 'beta'):
+                if key in l.off:
+                    o, shp = l.off[key]
+                    n = int(np.prod(shp))
+                    ms.append(m[o:o + n].reshape(shp).copy())
+                    vs.append(v[o:o + n].reshape(shp).copy())
+        return dict(config=self.optimizer.get_config(), iterations=int(eng.iterations), m=ms, v=vs)
+
+    def _set_optimizer_state(self, st, loss):
+        eng = self.engine
+        m, v = np.zeros(eng.mflat.numel(), np.float32), np.zeros(eng.vflat.numel(), np.float32)
+        i = 0
+        for l in eng.layers:
+            for key in ('k', 'b', 'gamma', 'beta'):
+                if key in l.off:
+                    o, shp = l.off[key]
+                    n = int(np.prod(shp))
+                    if tuple(np.shape(st['m'][i])) != tuple(shp):
+                        raise ValueError('optimizer state %d: shape %r != %r' % (i, np.shape(st['m'][i]), shp))
+                    m[o:o + n] = np.asarray(st['m'][i], np.float32).ravel()
+                    v[o:o + n] = np.asarray(st['v'][i], np.float32).ravel()
+                    i += 1
+        eng.mflat.copy_(torch.from_numpy(m))
+        eng.vflat.copy_(torch.from_numpy(v))
+        eng.iterations = int(st['iterations'])
+        oc = dict((k, st['config'][k]) for k in ('lr', 'beta_1', 'beta_2', 'epsilon') if k in st.get('config', {}))
+        self.compile(Adam(**oc), loss or 'binary_crossentropy')
+
     def save(self, filepath, include_optimizer=True):
         eng = self.engine
+        with_opt = include_optimizer and self.optimizer is not None
+        if str(filepath).lower().endswith(('.hdf5', '.h5')):
+            from . import keras_io
+            keras_io.write_keras_model(filepath, eng.get_weights(), self.config,
+                                       optimizer=self._optimizer_state() if with_opt else None, loss=self.loss,
+                                       metrics=self.metrics_names[1:])
+            return
         arrays = {'w_%03d' % i: w for i, w in enumerate(eng.get_weights())}
         meta = dict(format='dcunet-npz-1', config=self.config, compiled=self.optimizer is not None)
-        if include_optimizer and self.optimizer is not None:
+        if with_opt:
             arrays['opt_m'] = eng.mflat.cpu().numpy()
             arrays['opt_v'] = eng.vflat.cpu().numpy()
             meta['optimizer'] = dict(self.optimizer.get_config(), iterations=int(eng.iterations))
             meta['loss'] = self.loss
         arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-        with open(filepath, 'wb') as fp:         # exact file name (ModelCheckpoint passes '*.hdf5')
+        with open(filepath, 'wb') as fp:
             np.savez(fp, **arrays)
 
     def load_state(self, filepath, with_optimizer):
-        z = np.load(filepath)
-        meta = json.loads(bytes(z['meta']).decode())
-        n = len([k for k in z.files if k.startswith('w_')])
-        self.set_weights([z['w_%03d' % i] for i in range(n)])
-        if with_optimizer and 'optimizer' in meta:
-            oc = dict(meta['optimizer'])
-            self.engine.iterations = int(oc.pop('iterations'))
-            self.engine.mflat.copy_(torch.from_numpy(z['opt_m']))
-            self.engine.vflat.copy_(torch.from_numpy(z['opt_v']))
-            self.compile(Adam(**oc), meta.get('loss', 'binary_crossentropy'))
-        return meta
+        state = read_checkpoint(filepath)
+        self.set_weights(state['weights'])
+        if with_optimizer and state.get('optimizer') is not None:
+            self._set_optimizer_state(state['optimizer'], state.get('loss'))
+        return state
+
+
+def read_checkpoint(path):
+    """Either checkpoint container -> dict(weights, config, optimizer | None, loss): a Keras-2.0.x HDF5 model file (the
+    reference's format: released weights, ModelCheckpoint files, files written by Model.save('*.hdf5')) or the build's
+    own .npz.  The format is sniffed from the file's first bytes, not from its name."""
+    from . import hdf5_min, keras_io
+    if hdf5_min.is_hdf5(path):
+        return keras_io.read_keras_model(path)
+    with open(path, 'rb') as fp:
+        magic = fp.read(4)
+    if magic[:2] != b'PK':
+        raise ValueError('%s is neither a Keras HDF5 model file nor a dcunet .npz checkpoint' % path)
+    z = np.load(path)
+    if 'meta' not in z.files:
+        raise ValueError('%s is not a dcunet checkpoint (no meta record)' % path)
+    meta = json.loads(bytes(z['meta']).decode())
+    if meta.get('format') != 'dcunet-npz-1':
+        raise ValueError('%s is not a dcunet checkpoint' % path)
+    n = len([k for k in z.files if k.startswith('w_')])
+    out = dict(weights=[z['w_%03d' % i] for i in range(n)], config=meta['config'], optimizer=None, loss=meta.get('loss'))
+    if 'optimizer' in meta:
+        oc = dict(meta['optimizer'])
+        it = int(oc.pop('iterations'))
+        m, v = z['opt_m'], z['opt_v']
+        ms, vs, o = [], [], 0
+        from .net import build_layer_table
+        cfg = meta['config']
+        for l in build_layer_table(cfg['nb_filters_base'], cfg.get('prop_dropout_base', 0.25),
+                                   cfg.get('upsampling_or_transpose', 'transpose') != 'transpose'):
+            shapes = [l.kshape, (l.cout,)] + ([(l.cout,), (l.cout,)] if l.kind != 'head' else [])
+            for shp in shapes:
+                k = int(np.prod(shp))
+                ms.append(m[o:o + k].reshape(shp))
+                vs.append(v[o:o + k].reshape(shp))
+                o += k
+        out['optimizer'] = dict(config=oc, iterations=it, m=ms, v=vs)
+    return out
 
 
 def unet_hip(window_shape=(128, 128), nb_filters_base=32, conv_kernel_init='he_normal',
@@ -472,13 +545,15 @@ def unet_hip(window_shape=(128, 128), nb_filters_base=32, conv_kernel_init='he_n
 
 def load_model_with_new_input_shape(model_path, input_shape, **load_model_args):
     """The weight-I/O seam of /root/reference/deepcalcium/utils/keras_helpers.py:24-68: the same weights at a
-    new window size (the net is fully convolutional).  `compile=True` restores the optimizer state."""
-    z = np.load(model_path)
-    meta = json.loads(bytes(z['meta']).decode())
-    if meta.get('format') != 'dcunet-npz-1':
-        raise ValueError('%s is not a dcunet checkpoint' % model_path)
-    cfg = meta['config']
-    model = Model(tuple(input_shape), cfg['nb_filters_base'], prop_dropout_base=cfg['prop_dropout_base'],
+    new window size (the net is fully convolutional).  `compile=True` restores the optimizer state.  model_path may be
+    a Keras-2.0.x HDF5 model file (the reference's own format, e.g. the released unet2ds_model.hdf5 or a
+    ModelCheckpoint file -- read in-process, optimizer_weights included) or the build's .npz."""
+    state = read_checkpoint(model_path)
+    cfg = state['config']
+    model = Model(tuple(input_shape), cfg['nb_filters_base'], conv_kernel_init=None,      # weights come from the file
+                  prop_dropout_base=cfg['prop_dropout_base'],
                   upsampling_or_transpose=cfg.get('upsampling_or_transpose', 'transpose'))
-    model.load_state(model_path, with_optimizer=bool(load_model_args.get('compile', True)))
+    model.set_weights(state['weights'])
+    if bool(load_model_args.get('compile', True)) and state.get('optimizer') is not None:
+        model._set_optimizer_state(state['optimizer'], state.get('loss'))
     return model

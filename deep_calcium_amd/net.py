@@ -84,7 +84,7 @@ def build_layer_table(nfb=32, drp=0.25, upsampling=False):
 
 class UNetEngine(object):
     def __init__(self, window_shape, nb_filters_base=32, prop_dropout_base=0.25, device=None, seed=7535, mfma=None,
-                 upsampling=False, bn_mode=None):
+                 upsampling=False, bn_mode=None, conv_kernel_init='he_normal'):
         # mfma: 'f16x3' (default; fp32-grade split-fp16 products on the fp16 matrix cores) or 'f32' (fp32 MFMA)
         self.mfma = mfma or os.environ.get('DC_MFMA', 'f16x3')
         if self.mfma not in ('f16x3', 'f32'):
@@ -97,6 +97,8 @@ class UNetEngine(object):
         self.bnin = self.mfma == 'f16x3' and os.environ.get('DC_BNIN', '1') == '1'
         # BatchNorm-backward pass-1 sums emitted by the kernel that produces da (head / max-pool backward)
         self.bnred = os.environ.get('DC_BNRED', '1') == '1'
+        # fp16 range guard of the activation operands (A/B knob; the weights' pack-time scale is unconditional)
+        self.range_guard = os.environ.get('DC_RANGE_GUARD', '1') == '1'
         # BatchNorm under batch-sharded data parallelism: 'local' = each rank normalises over its own shard
         # (standard DP semantics); 'sync' = the per-channel sums are all-reduced in forward and backward, so G ranks x B
         # images reproduce ONE device's step on the G*B batch
@@ -178,26 +180,33 @@ class UNetEngine(object):
         # bound per activation tensor, written by the layer that produces it (training: |gamma|*sqrt(count)+|beta| from
         # the BatchNorm finalize / apply kernels; inference: the measured max |a| from the conv epilogues) and read by
         # the consumers, in THEIR input-channel order: the two producers of a skip-concat buffer share one array.
-        self._ab_off = {}
+        # Every array has DC_ABOUND_SLOTS = 8 replicas `ld` floats apart: training writes / reads replica 0 only, the
+        # inference epilogues spread their atomic max over the replicas (one hot address per channel otherwise).
+        self._ab_off, self._ab_ld = {}, {}
         o = 0
         for lvl in range(4):
-            self._ab_off['cat%d' % lvl] = o
-            o += self._cup(lvl) + (nfb << lvl)
+            self._ab_off['cat%d' % lvl], self._ab_ld['cat%d' % lvl] = o, self._cup(lvl) + (nfb << lvl)
+            o += 8 * self._ab_ld['cat%d' % lvl]
         for l in self.layers:
             if l.kind != 'head':
-                self._ab_off[l.name] = o
-                o += l.cout
+                self._ab_off[l.name], self._ab_ld[l.name] = o, l.cout
+                o += 8 * l.cout
         self.abound = torch.zeros(o, dtype=torch.float32, device=dev)
         self._bufs = {}
         self._packed_dirty = True
         self._fold_dirty = True
         self.iterations = 0
         self.drop_seed = 0x5eed0000 + seed
-        self.set_weights(self.initial_weights(seed))
+        if conv_kernel_init is not None:         # None: the caller sets the weights (checkpoint load): skip the RNG work
+            self.set_weights(self.initial_weights(seed, conv_kernel_init))
 
     # ---- parameters ---------------------------------------------------------------------------------
-    def initial_weights(self, seed=7535):
-        """he_normal (truncated, fan_in) conv kernels, glorot-uniform head, BN identity."""
+    def initial_weights(self, seed=7535, conv_kernel_init='he_normal'):
+        """Keras-2.0.6 initialisers: `conv_kernel_init` (the reference's `cki`, default he_normal) for
+        the 3x3 convolutions and the conv-transposes (unet_2d_summary.py:157,:165), glorot_uniform (Keras' Conv2D
+        default) for the head (:221), zero biases, identity BatchNorm.  VarianceScaling family: fans from the kernel
+        shape (kh,kw,in,out) -- for Conv2DTranspose's (kh,kw,out,in) kernel Keras therefore takes fan_in = 4*out;
+        'normal' = truncated at 2 sigma."""
         rs = np.random.RandomState(seed)
 
         def tn(shape, std):
@@ -208,15 +217,39 @@ class UNetEngine(object):
                 bad = np.abs(out) > 2
             return (out * std).astype(np.float32)
 
+        vs = {'he_normal': (2.0, 'fan_in', 'normal'), 'he_uniform': (2.0, 'fan_in', 'uniform'),
+              'glorot_normal': (1.0, 'fan_avg', 'normal'), 'glorot_uniform': (1.0, 'fan_avg', 'uniform'),
+              'lecun_normal': (1.0, 'fan_in', 'normal'), 'lecun_uniform': (1.0, 'fan_in', 'uniform')}
+
+        def init(name, shape):
+            if callable(name):
+                return np.asarray(name(shape), np.float32).reshape(shape)
+            rf = shape[0] * shape[1]
+            fan_in, fan_out = shape[2] * rf, shape[3] * rf
+            if name in vs:
+                scale, mode, dist = vs[name]
+                scale /= max(1.0, {'fan_in': fan_in, 'fan_out': fan_out, 'fan_avg': (fan_in + fan_out) / 2.0}[mode])
+                if dist == 'normal':
+                    return tn(shape, np.sqrt(scale))
+                lim = np.sqrt(3.0 * scale)
+                return rs.uniform(-lim, lim, shape).astype(np.float32)
+            if name in ('random_normal', 'normal'):
+                return (rs.standard_normal(shape) * 0.05).astype(np.float32)
+            if name == 'truncated_normal':
+                return tn(shape, 0.05)
+            if name in ('random_uniform', 'uniform'):
+                return rs.uniform(-0.05, 0.05, shape).astype(np.float32)
+            if name in ('zeros', 'zero'):
+                return np.zeros(shape, np.float32)
+            if name in ('ones', 'one'):
+                return np.ones(shape, np.float32)
+            raise ValueError('conv_kernel_init %r: not a Keras-2.0.6 initializer this build restates (%s, random_normal, '
+                             'random_uniform, truncated_normal, zeros, ones, or a callable shape -> array)'
+                             % (name, ', '.join(sorted(vs))))
+
         W = []
         for l in self.layers:
-            if l.kind == 'conv':
-                W.append(tn(l.kshape, np.sqrt(2.0 / (9 * l.cin))))
-            elif l.kind == 'convT':
-                W.append(tn(l.kshape, np.sqrt(2.0 / (4 * l.cout))))   # Keras fan_in quirk for (2,2,Cout,Cin)
-            else:
-                lim = np.sqrt(6.0 / (l.cin + l.cout))
-                W.append(rs.uniform(-lim, lim, l.kshape).astype(np.float32))
+            W.append(init('glorot_uniform' if l.kind == 'head' else conv_kernel_init, l.kshape))
             W.append(np.zeros(l.cout, np.float32))
             if l.kind != 'head':
                 W += [np.ones(l.cout, np.float32), np.zeros(l.cout, np.float32),
@@ -339,61 +372,79 @@ class UNetEngine(object):
                          BN_EPS, self.stat_ptr(l, 2), self.stat_ptr(l, 3), l.cout, st)
         self._fold_dirty = False
 
-    def _conv_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None, absmax=None):
+    def _conv_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None, measured=False):
         """bnin = (scale_ptr, shift_ptr): x is the producer's pre-BN tensor, BN + ReLU are applied on load.
-        absmax: inference only, where the epilogue folds max |output| per channel (the next layer's range-guard bound)."""
+        measured: inference -- the input bound is a measured one (8 replicas) and the epilogue folds max |output| per
+        channel into the output's replicas (the next layer's range-guard bound)."""
+        (ab_in, ab_in_ld), (ab_out, ab_out_ld) = self._ab_in(l, True), self._ab_out(l, True)
+        if not measured:
+            ab_in_ld, ab_out, ab_out_ld = 0, None, 0
         if bnin is not None:
             self.L.dc_conv3x3_fwd_bnin_f16x3(x, bnin[0], bnin[1], self._ab_in(l), _ptr(self.wp_fwd[l.name]), bias, z, z_ld,
                                              stats, sc, sh, relu, N, h, w, l.cin, l.cout, st)
         elif self.mfma == 'f16x3':
-            self.L.dc_conv3x3_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu, self._ab_in(l),
-                                        absmax, N, h, w, l.cin, l.cout, st)
+            self.L.dc_conv3x3_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu, ab_in, ab_in_ld,
+                                        ab_out, ab_out_ld, N, h, w, l.cin, l.cout, st)
         else:
             self.L.dc_conv3x3_fwd(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu,
                                   N, h, w, l.cin, l.cout, st)
 
-    def _convT_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None, absmax=None):
+    def _convT_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None, measured=False):
+        (ab_in, ab_in_ld), (ab_out, ab_out_ld) = self._ab_in(l, True), self._ab_out(l, True)
+        if not measured:
+            ab_in_ld, ab_out, ab_out_ld = 0, None, 0
         if bnin is not None:
             self.L.dc_convT2x2_fwd_bnin_f16x3(x, bnin[0], bnin[1], self._ab_in(l), _ptr(self.wp_fwd[l.name]), bias, z, z_ld,
                                               stats, sc, sh, relu, N, h, w, l.cin, l.cout, st)
         elif self.mfma == 'f16x3':
-            self.L.dc_convT2x2_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu, self._ab_in(l),
-                                         absmax, N, h, w, l.cin, l.cout, st)
+            self.L.dc_convT2x2_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu, ab_in, ab_in_ld,
+                                         ab_out, ab_out_ld, N, h, w, l.cin, l.cout, st)
         else:
             self.L.dc_convT2x2_fwd(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu,
                                    N, h, w, l.cin, l.cout, st)
 
-    def _ab_out(self, l):
-        """Where layer l's activation bound goes (None for the fp32-MFMA engine: no fp16 operands)."""
-        if self.mfma != 'f16x3':
-            return None
+    def _ab_key(self, l, out):
+        """(array name, channel offset) of layer l's output (out=True) or input (out=False) bound."""
         n = l.name
+        if out:
+            if l.kind == 'convT':
+                return 'cat%d' % l.lvl, 0                                 # up half of the concat
+            if n[0] == 'e' and n[-1] == 'b':
+                return 'cat%d' % l.lvl, self._cup(l.lvl)                  # skip half
+            return n, 0
         if l.kind == 'convT':
-            return _ptr(self.abound, self._ab_off['cat%d' % l.lvl])                            # up half of the concat
-        if n[0] == 'e' and n[-1] == 'b':
-            return _ptr(self.abound, self._ab_off['cat%d' % l.lvl] + self._cup(l.lvl))         # skip half
-        return _ptr(self.abound, self._ab_off[n])
-
-    def _ab_up(self, lvl):
-        """UpSampling2D branch: (bound of the up-sampled layer, up half of level lvl's concat bound) or (None, None)."""
-        if self.mfma != 'f16x3':
-            return None, None
-        return (_ptr(self.abound, self._ab_off['bb' if lvl == 3 else 'd%db' % (lvl + 1)]),
-                _ptr(self.abound, self._ab_off['cat%d' % lvl]))
-
-    def _ab_in(self, l):
-        """Bound array of layer l's INPUT tensor, in l's input-channel order (None: the image / fp32-MFMA engine)."""
-        if self.mfma != 'f16x3' or (l.kind == 'conv' and l.cin == 1):
-            return None
-        n = l.name
-        if l.kind == 'convT':
-            return _ptr(self.abound, self._ab_off['bb' if l.lvl == 3 else 'd%db' % (l.lvl + 1)])
+            return ('bb' if l.lvl == 3 else 'd%db' % (l.lvl + 1)), 0
         if n[0] == 'd' and n[-1] == 'a':
-            return _ptr(self.abound, self._ab_off['cat%d' % l.lvl])
+            return 'cat%d' % l.lvl, 0
         if n[-1] == 'b':
-            return _ptr(self.abound, self._ab_off[n[:-1] + 'a'])
-        lvl = l.lvl - 1                                                                        # e<lvl>a / ba: the pooled skip
-        return _ptr(self.abound, self._ab_off['cat%d' % lvl] + self._cup(lvl))
+            return n[:-1] + 'a', 0
+        return 'cat%d' % (l.lvl - 1), self._cup(l.lvl - 1)                # e<lvl>a / ba: the pooled skip
+
+    def _ab_out(self, l, measured=False):
+        """Where layer l's activation bound goes: pointer, or (pointer, replica stride) for a measured (inference)
+        bound.  None for the fp32-MFMA engine (no fp16 operands) / DC_RANGE_GUARD=0."""
+        if self.mfma != 'f16x3' or not self.range_guard:
+            return (None, 0) if measured else None
+        key, off = self._ab_key(l, True)
+        ptr = _ptr(self.abound, self._ab_off[key] + off)
+        return (ptr, self._ab_ld[key]) if measured else ptr
+
+    def _ab_in(self, l, measured=False):
+        """Bound array of layer l's INPUT tensor, in l's input-channel order (None: the image / fp32-MFMA engine)."""
+        if self.mfma != 'f16x3' or not self.range_guard or (l.kind == 'conv' and l.cin == 1):
+            return (None, 0) if measured else None
+        key, off = self._ab_key(l, False)
+        ptr = _ptr(self.abound, self._ab_off[key] + off)
+        return (ptr, self._ab_ld[key]) if measured else ptr
+
+    def _ab_up(self, lvl, measured=False):
+        """UpSampling2D branch: (bound of the up-sampled layer, its replica stride, up half of level lvl's concat bound,
+        its replica stride); strides 0 in training (replica 0 only)."""
+        if self.mfma != 'f16x3' or not self.range_guard:
+            return None, 0, None, 0
+        src, dst = 'bb' if lvl == 3 else 'd%db' % (lvl + 1), 'cat%d' % lvl
+        return (_ptr(self.abound, self._ab_off[src]), self._ab_ld[src] if measured else 0,
+                _ptr(self.abound, self._ab_off[dst]), self._ab_ld[dst] if measured else 0)
 
     def _bnin_src(self, prod, T):
         """(pre-BN tensor ptr, (scale_ptr, shift_ptr)) if the producer's activation is not materialised, else None."""
@@ -518,23 +569,56 @@ class UNetEngine(object):
                 continue
             if step[0] == 'up':
                 _, lvl, src, dst, ld, h, w = step
-                L.dc_upsample2x_drop_fwd(_ptr(src), _ptr(dst), ld, None, 1.0, 0, *self._ab_up(lvl), N, h // 2, w // 2,
+                L.dc_upsample2x_drop_fwd(_ptr(src), _ptr(dst), ld, None, 1.0, 0, *self._ab_up(lvl, True), N, h // 2, w // 2,
                                          self._cup(lvl), st)
                 continue
             _, l, src, dst, coff, ld, h, w, _prod = step
             sc, sh = self.stat_ptr(l, 2), self.stat_ptr(l, 3)
             if l.kind == 'conv' and l.cin == 1:
                 L.dc_conv3x3_c1_fwd(_ptr(x_dev), self.pview(self.pflat, l, 'k'), None, _ptr(dst, coff), ld, None,
-                                    sc, sh, 1, self._ab_out(l), N, h, w, l.cout, st)
+                                    sc, sh, 1, *self._ab_out(l, True), N, h, w, l.cout, st)
             elif l.kind == 'conv':
-                self._conv_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h, w, st, absmax=self._ab_out(l))
+                self._conv_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h, w, st, measured=True)
             else:
-                self._convT_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h // 2, w // 2, st,
-                                absmax=self._ab_out(l))
+                self._convT_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h // 2, w // 2, st, measured=True)
         lo = self.by_name['out']
         L.dc_head_fwd(_ptr(A['d0b']), self.pview(self.pflat, lo, 'k'), self.pview(self.pflat, lo, 'b'), None,
                       _ptr(A['p']), None, N * self.H * self.W, self.nfb, st)
         return A['p']
+
+    @_on_device
+    def predict_tta(self, img, augmentations, hs, ws, threshold):
+        """predict(augmentation=True) for ONE padded (H,W) float32 numpy image, on the device: the K augmented copies are
+        gathered by dc_gather_maps, go through one batch-K forward, and dc_tta_merge inverse-maps, averages (double,
+        table order), crops to (hs, ws) and thresholds.  augmentations = [(name, fwd, inv)] on (N,H,W) arrays.
+        Returns the uint8 mask (hs, ws).  Host traffic: 4*H*W bytes in, hs*ws bytes out (vs 8x both ways)."""
+        K, H, W = len(augmentations), self.H, self.W
+        n = H * W
+        key = ('tta', K, id(augmentations))
+        m = self._bufs.get(key)
+        if m is None:
+            idx = np.arange(n, dtype=np.int32).reshape(1, H, W)
+            fwd = np.stack([np.ascontiguousarray(f(idx)).reshape(-1) for _, f, _ in augmentations])
+            inv = np.stack([np.ascontiguousarray(g(idx)).reshape(-1) for _, _, g in augmentations])
+            if fwd.shape != (K, n) or inv.shape != (K, n):
+                raise ValueError('test-time augmentations must map (N,H,W) to (N,H,W) on a square window')
+            # out_k[p] = in[fwd_k[p]];  inv_k(pred_k)[p] = pred_k[inv_k[p]]
+            m = dict(fwd=torch.from_numpy(fwd).to(self.device), inv=torch.from_numpy(inv).to(self.device),
+                     src=torch.empty(n, dtype=torch.float32, device=self.device),
+                     x=torch.empty((K, H, W), dtype=torch.float32, device=self.device),
+                     mask=torch.empty(n, dtype=torch.uint8, device=self.device),
+                     host=torch.empty((H, W), dtype=torch.float32).pin_memory(),
+                     mask_host=torch.empty(n, dtype=torch.uint8).pin_memory())
+            self._bufs[key] = m
+        L, st = self.L, self._stream()
+        m['host'].numpy()[...] = img
+        m['src'].copy_(m['host'].view(-1), non_blocking=True)
+        L.dc_gather_maps(_ptr(m['src']), m['fwd'].data_ptr(), _ptr(m['x']), K, n, st)
+        p = self.forward_infer(m['x'])
+        L.dc_tta_merge(_ptr(p), m['inv'].data_ptr(), K, H, W, int(hs), int(ws), float(threshold), m['mask'].data_ptr(), None, st)
+        m['mask_host'][:hs * ws].copy_(m['mask'][:hs * ws], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return m['mask_host'][:hs * ws].numpy().reshape(hs, ws).copy()
 
     # ---- training ----------------------------------------------------------------------------------------
     def _train_bufs(self, N):
@@ -658,7 +742,7 @@ class UNetEngine(object):
             if l.kind == 'conv' and l.cin == 1:
                 tiles = L.dc_conv3x3_c1_tiles(N, h, w, l.cout)
                 L.dc_conv3x3_c1_fwd(_ptr(x_dev), self.pview(self.pflat, l, 'k'), bias, _ptr(z), l.cout, stats,
-                                    None, None, 0, None, N, h, w, l.cout, st)
+                                    None, None, 0, None, 0, N, h, w, l.cout, st)
             elif l.kind == 'conv':
                 tiles = L.dc_conv3x3_tiles(N, h, w, l.cout)
                 self._conv_fwd(xin, l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h, w, st, bnin=bn)

@@ -1,11 +1,17 @@
-"""Neurofinder mask scoring used by the validation callback and predict(print_scores=True).
+"""Neurofinder mask scoring and submission files, used by the validation callback, predict(print_scores=True) and the
+evaluate script.
 
-Restates `nf_mask_metrics` / `_mask_to_regional` of /root/reference/deepcalcium/datasets/nf.py:153-174,
-:221-229.  The scoring itself lives in third-party packages absent from the reference tree and from this
-image -- `neurofinder==1.1.1` (centers/shapes/match) and `regional` (region centre / overlap), plus
-`skimage.measure.label` -- so this file restates their published algorithms: PARITY UNPINNED
-(SURVEY 8f rank 2).  Host-side numpy/scipy: it is the caller of the GPU path, not part of it.
+Restates `nf_mask_metrics`, `nf_submit` and `_mask_to_regional` of /root/reference/deepcalcium/datasets/nf.py:153-229.
+Pinned by fixtures made from the reference's own code run under this image's conda interpreter (real scikit-image;
+tests/golden/make_nf_goldens.py): the connected-component labelling (skimage.measure.label, full connectivity, raster
+label order), the region coordinate lists, and nf_submit's output byte for byte, quirks included.  NOT pinned: the
+centre-matching scores -- `neurofinder==1.1.1` (centers / shapes / match) and `regional` are absent from the reference
+tree and from this image, their published algorithms are restated here.
+Host-side numpy/scipy: the caller of the GPU path, not part of it.
 """
+import json
+import logging
+
 import numpy as np
 from scipy import ndimage
 
@@ -86,3 +92,24 @@ def nf_mask_metrics(m, mp):
     i, e = shapes(ra, rb)
     f1 = 2. * (r * p) / (r + p) if (r + p) > 0 else 0.
     return p, r, i, e, f1
+
+
+def nf_submit(Mp, names, json_path):
+    """Neurofinder submission file for predicted masks, datasets/nf.py:177-218 -- reproduced as it is, quirks included:
+    the 'neurofinder.' prefix is stripped from dataset names; coordinates are [row, col] pairs in raster order per
+    region; an empty mask yields ONE dummy region [[0, 0]] (:201-202); `range(1, max)` (:205) drops the LAST labelled
+    component (so a mask with a single component yields no region at all)."""
+    logger = logging.getLogger('nf_submit')
+    submission = []
+    for mp, name in zip(Mp, names):
+        if name.startswith('neurofinder.'):
+            name = '.'.join(name.split('.')[1:])
+        regions_all = mask_to_regions(mp)
+        if not regions_all:
+            regions = [{'coordinates': [[[0, 0]]]}]
+        else:
+            regions = [{'coordinates': [[int(y), int(x)] for y, x in r]} for r in regions_all[:-1]]
+        submission.append({'dataset': name, 'regions': regions})
+    with open(json_path, 'w') as fp:
+        json.dump(submission, fp)
+    logger.info('Saved submission to %s.' % json_path)

@@ -60,15 +60,18 @@ _SIX = [
 
 
 def _open_dataset(dspath):
-    """A dataset is the reference's HDF5 file (needs h5py) or an .npz with the same members, '/' -> '_'."""
+    """A dataset is the reference's HDF5 file (datasets/nf.py:37-150: attrs['name'], series/{raw,mean,max},
+    masks/{raw,max}; read with h5py when importable, else with the built-in reader hdf5_min) or an .npz with the same
+    members, '/' -> '_'."""
     if str(dspath).endswith('.npz'):
         z = np.load(dspath, allow_pickle=False)
         return {k.replace('_', '/', 1): z[k] for k in z.files}, None
     try:
         import h5py
+        return None, h5py.File(dspath, 'r')
     except ImportError:
-        raise ImportError('h5py is required to read %s (or pass .npz datasets / custom summary functions)' % dspath)
-    return None, h5py.File(dspath, 'r')
+        from . import hdf5_min
+        return None, hdf5_min.File(dspath)
 
 
 def _get(dspath, key):
@@ -76,7 +79,10 @@ def _get(dspath, key):
     if d is not None:
         return d[key]
     try:
-        return fp.attrs[key] if key == 'name' else fp.get(key)[...]
+        if key == 'name':
+            return fp.attrs[key]
+        node = fp[key]
+        return node.read() if hasattr(node, 'read') else node[...]
     finally:
         fp.close()
 
@@ -346,16 +352,14 @@ class UNet2DSummary(object):
             hs, ws = s.shape
             s_batch = np.pad(s, ((0, hw - hs), (0, ww - ws)), mode='reflect')[np.newaxis, :, :]
             if augmentation:
-                # the 8 augmented copies go through ONE batch-8 forward (inference BN is per-image)
-                stack = np.concatenate([aug(s_batch) for _, aug, _ in INVERTIBLE_2D_AUGMENTATIONS])
-                out = model.predict(stack, batch_size=len(INVERTIBLE_2D_AUGMENTATIONS))
-                mp = np.zeros(s.shape)
-                for k, (_, _, inv) in enumerate(INVERTIBLE_2D_AUGMENTATIONS):
-                    mp += inv(out[k:k + 1])[0, :hs, :ws] / len(INVERTIBLE_2D_AUGMENTATIONS)
+                # the 8 augmented copies are made on the device, go through ONE batch-8 forward (inference BatchNorm is
+                # per-image), and are inverse-mapped, averaged (float64, table order), cropped and thresholded there
+                mp = model.engine.predict_tta(s_batch[0].astype(np.float32), INVERTIBLE_2D_AUGMENTATIONS, hs, ws, threshold)
+                Mp.append(mp)
             else:
                 mp = model.predict(s_batch)[0, :hs, :ws]
-            mp = (mp > threshold).astype(np.uint8)
-            Mp.append(mp)
+                Mp.append((mp > threshold).astype(np.uint8))
+            mp = Mp[-1]
             names.append(name)
             if print_scores:
                 m = self.mask_summary_func(dsp)

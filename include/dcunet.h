@@ -59,7 +59,7 @@ int dc_conv3x3_fwd(const float* x, const float* wp, const float* bias, float* z,
  * per channel is folded in (atomic max) -- the range-guard bound of the next f16x3 layer in inference. */
 int dc_conv3x3_c1_tiles(int N, int H, int W, int Cout);
 int dc_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, float* z, long z_ld, double* stats,
-                      const float* scale, const float* shift, int relu, float* out_absmax,
+                      const float* scale, const float* shift, int relu, float* out_absmax, long out_absmax_ld,
                       int N, int H, int W, int Cout, dc_stream_t stream);
 /* dx = conv3x3_transpose(dz): wp = dc_pack_weights(conv3x3 dgrad form). dz: [N,H,W,Cout], dx: [N,H,W,Cin]. */
 int dc_conv3x3_dgrad(const float* dz, const float* wp, float* dx,
@@ -81,7 +81,12 @@ int dc_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* ws,
  *     layer that produced the tensor -- dc_bn_stats_finalize_affine / dc_bn_relu_drop_fwd in training
  *     (|gamma|*sqrt(count)+|beta|, valid for ANY data), the out_absmax of the producing kernel in inference; the
  *     consumer scales so that the largest bound lands in [2^14, 2^15): no activation can reach fp16 inf, tiny
- *     ones keep their low bits.  NULL = scale 1. */
+ *     ones keep their low bits.  NULL = scale 1.
+ *   Measured bounds (inference) live in DC_ABOUND_SLOTS = 8 replicas of the per-channel array, `*_ld` floats apart: a
+ *   producer folds max |output| into replica (workgroup id mod 8) with an atomic max (out_absmax, out_absmax_ld; the
+ *   caller zeroes all replicas first), the consumer takes the max over the replicas (in_abound_ld > 0).
+ *   in_abound_ld == 0: a single array (the training-mode bound). */
+#define DC_ABOUND_SLOTS 8
 long dc_pack_weights_f16x3_floats(int taps, int K, int Ncols);
 int dc_pack_weights_f16x3(const float* src, void* dst, int taps, int K, int Ncols,
                           long s_tap, long s_k, long s_n, int flip, dc_stream_t stream);
@@ -90,13 +95,13 @@ int dc_pack_weights_f16x3(const float* src, void* dst, int taps, int K, int Ncol
  * the trailing sentinel entry only carries the grid size (= total_blocks) in its last field. */
 int dc_pack_weights_f16x3_batch(const long* jobs_dev, int njobs, int total_blocks, dc_stream_t stream);
 int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, double* stats,
-                         const float* scale, const float* shift, int relu, const float* in_abound, float* out_absmax,
-                         int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+                         const float* scale, const float* shift, int relu, const float* in_abound, long in_abound_ld,
+                         float* out_absmax, long out_absmax_ld, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
                            int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, double* stats,
-                          const float* scale, const float* shift, int relu, const float* in_abound, float* out_absmax,
-                          int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+                          const float* scale, const float* shift, int relu, const float* in_abound, long in_abound_ld,
+                          float* out_absmax, long out_absmax_ld, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 int dc_convT2x2_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
                             int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 /* weight gradients: same workspace (dc_*_wgrad_ws_floats) and fixed-order slab reduction as the fp32 entry points;
@@ -233,9 +238,10 @@ int dc_maxpool2x2_bwd(const float* dy, const uint8_t* idx, const float* skip, lo
  * nearest 2x of in [N,H,W,C] (dense) into out [N,2H,2W,C] (pixel stride out_ld), dropout applied to the
  * up-sampled tensor (mask uint8 [N,2H,2W,C] or counter RNG(seed); keep >= 1: none).
  * abound_in / abound_out (nullable pair, float[C]): range-guard bound of the source / of the up-sampled tensor
- * (= abound_in / keep). */
+ * (= abound_in / keep); abound_in_ld > 0: all DC_ABOUND_SLOTS replicas (inference), *_ld floats apart. */
 int dc_upsample2x_drop_fwd(const float* in, float* out, long out_ld, const uint8_t* mask, float keep, uint64_t seed,
-                           const float* abound_in, float* abound_out, int N, int H, int W, int C, dc_stream_t stream);
+                           const float* abound_in, long abound_in_ld, float* abound_out, long abound_out_ld,
+                           int N, int H, int W, int C, dc_stream_t stream);
 /* din[N,H,W,C] (dense) = sum over each 2x2 block of dout (pixel stride dout_ld) * dropout factor */
 int dc_upsample2x_drop_bwd(const float* dout, long dout_ld, const uint8_t* mask, float keep, uint64_t seed, float* din,
                            int N, int H, int W, int C, dc_stream_t stream);
@@ -268,6 +274,15 @@ int dc_bn_bwd_finalize(const float* partial, int P, int C, float* dgamma, float*
  * g' = g*gscale; m = b1*m+(1-b1)*g'; v = b2*v+(1-b2)*g'^2; p -= lr_t*m/(sqrt(v)+eps), flat over n floats. */
 int dc_adam_step_flat(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
                       float eps, float gscale, dc_stream_t stream);
+
+/* ---- 8x test-time augmentation of predict()  unet_2d_summary.py:585-595, utils/neurons.py:112-137 ---------------
+ * The augmentations are pixel permutations; maps / invmaps (int32 [K][H*W]) are made on the host by applying the table's
+ * own functions to an index image.  dc_gather_maps: out[k][p] = in[maps[k][p]] (n = H*W elements per copy).
+ * dc_tta_merge: m = sum_k preds[k][invmaps[k][p]] / K in double, table order (numpy's float64 accumulation), cropped to
+ * hs x ws; mask (uint8 [hs][ws]) = m > threshold; mean_out (nullable float [hs][ws]) = m. */
+int dc_gather_maps(const float* in, const int* maps, float* out, int K, long n, dc_stream_t stream);
+int dc_tta_merge(const float* preds, const int* invmaps, int K, int H, int W, int hs, int ws, double threshold,
+                 uint8_t* mask, float* mean_out, dc_stream_t stream);
 
 /* misc */
 int dc_fill(float* p, long n, float value, dc_stream_t stream);

@@ -92,3 +92,101 @@ def test_fit_and_predict_end_to_end(tmp_path):
     assert np.array_equal((mp > 0.5).astype(np.uint8), MpT[0])
     with pytest.raises(AssertionError):
         model.predict(paths, ck, window_shape=(256, 256))
+
+
+def test_keras_model_file_written_by_libhdf5_loads_and_predicts(golden_dir):
+    """A Keras-2.0.6-layout model file written by real h5py (tests/golden/make_keras_fixture.py) handed straight to
+    load_model_with_new_input_shape -- what predict(model_path='unet2ds_model.hdf5') does with the released weights
+    (unet_2d_summary.py:560-561): weights, window size, Adam moments and iteration count arrive in the engine."""
+    from deep_calcium_amd import load_model_with_new_input_shape
+    path = os.path.join(golden_dir, 'keras_unet_nfb4.hdf5')
+    z = np.load(os.path.join(golden_dir, 'keras_unet_nfb4.npz'))
+    W = [z['w_%03d' % i] for i in range(134)]
+    m = load_model_with_new_input_shape(path, (64, 64), compile=True)
+    assert m.input_shape == (None, 64, 64) and m.engine.nfb == 4 and m.engine.iterations == 2000
+    assert abs(m.optimizer.lr - 0.001) < 1e-9 and m.loss == 'binary_crossentropy'
+    assert all(np.array_equal(a, b) for a, b in zip(m.get_weights(), W))
+    x, _ = on.synthetic_batch(2, 64, 64)
+    assert np.abs(m.predict(x) - on.UNetOracle(W, 4).forward(x)).max() < 1e-4
+    eng = m.engine
+    mflat, vflat = eng.mflat.cpu().numpy(), eng.vflat.cpu().numpy()
+    k = 0
+    for l in eng.layers:
+        for key in ('k', 'b', 'gamma', 'beta'):
+            if key in l.off:
+                o, shp = l.off[key]
+                n = int(np.prod(shp))
+                assert np.array_equal(mflat[o:o + n].reshape(shp), z['opt_m_%03d' % k])
+                assert np.array_equal(vflat[o:o + n].reshape(shp), z['opt_v_%03d' % k])
+                k += 1
+    assert k == 90
+    # compile=False (predict / the validation model): weights only
+    m2 = load_model_with_new_input_shape(path, (32, 32), compile=False)
+    assert m2.optimizer is None and m2.engine.iterations == 0
+
+
+def test_hdf5_checkpoint_resumes_training_bit_for_bit(tmp_path):
+    """fit(model_path=..., proceed=True) semantics: a '*.hdf5' checkpoint (Keras layout, written in-process) restores
+    weights + Adam state so that the next optimizer step equals the uninterrupted run's, bit for bit."""
+    from deep_calcium_amd import unet_hip, Adam, load_model_with_new_input_shape
+    x, y = on.synthetic_batch(2, 32, 32)
+    masks = on.make_drop_masks(8, 2, 32, 32)
+    a = unet_hip((32, 32), nb_filters_base=8)
+    a.compile(Adam(0.002), 'binary_crossentropy')
+    for _ in range(3):
+        a.train_on_batch(x, y, drop_masks=masks)
+    path = str(tmp_path / '7_model_02_0.123.hdf5')
+    a.save(path)
+    from deep_calcium_amd import hdf5_min
+    assert hdf5_min.is_hdf5(path)
+    b = load_model_with_new_input_shape(path, (32, 32), compile=True)
+    va = a.train_on_batch(x, y, drop_masks=masks)
+    vb = b.train_on_batch(x, y, drop_masks=masks)
+    assert va == vb
+    assert all(np.array_equal(p, q) for p, q in zip(a.get_weights(), b.get_weights()))
+    # the build's own container still works and is sniffed by content, whatever the file is called
+    npz = str(tmp_path / 'own_format.ckpt')
+    a.save(npz)
+    c = load_model_with_new_input_shape(npz, (32, 32), compile=True)
+    assert c.engine.iterations == 4 and all(np.array_equal(p, q) for p, q in zip(a.get_weights(), c.get_weights()))
+
+
+def test_example_script_evaluate_and_predict(tmp_path):
+    """examples/neurons/unet2ds_nf.py (the reference's example, same CLI): `evaluate` and `predict` on dataset files in
+    the reference's HDF5 schema with a Keras-layout model file; `predict` leaves the Neurofinder submission files."""
+    import json
+    import subprocess
+    import sys
+    from deep_calcium_amd import hdf5_min, unet_hip
+    rs = np.random.RandomState(3)
+    paths = []
+    for k in range(2):
+        hw = (72, 80)
+        mean = (rs.random_sample(hw) * 500 + 50).astype(np.float16)
+        masks = np.zeros((6,) + hw, np.int8)
+        for zz in range(6):
+            cy, cx = rs.randint(6, hw[0] - 6), rs.randint(6, hw[1] - 6)
+            masks[zz, cy - 3:cy + 4, cx - 3:cx + 4] = 1
+        w = hdf5_min.Writer()
+        w.attrs['name'] = 'neurofinder.0%d.00' % k
+        w.create_dataset('series/mean', mean)
+        w.create_dataset('masks/raw', masks)
+        p = str(tmp_path / ('ds%d.hdf5' % k))
+        w.save(p)
+        paths.append(p)
+    model_path = str(tmp_path / 'model.hdf5')
+    unet_hip((512, 512), nb_filters_base=4).save(model_path)
+    cp = str(tmp_path / 'cp')
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'neurons', 'unet2ds_nf.py')
+    for action in ('evaluate', 'predict'):
+        r = subprocess.run([sys.executable, script, action, ','.join(paths), '-m', model_path, '-c', cp],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        if action == 'evaluate':
+            assert 'Evaluation with TTA.' in r.stderr and 'Evaluation without TTA.' in r.stderr
+            assert r.stderr.count('Mean prec=') == 2 and 'neurofinder.00.00: prec=' in r.stderr
+    subs = sorted(f for f in os.listdir(cp) if f.startswith('submission_'))
+    assert 'submission_latest.json' in subs and 'submission_latest_TTA.json' in subs and len(subs) == 4
+    sub = json.load(open(os.path.join(cp, 'submission_latest.json')))
+    # (an untrained model predicts next to nothing: an empty mask gives the dummy region, a single component gives [])
+    assert [s['dataset'] for s in sub] == ['00.00', '01.00'] and all(isinstance(s['regions'], list) for s in sub)

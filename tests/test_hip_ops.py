@@ -127,7 +127,7 @@ def test_conv3x3_f16x3_fwd_dgrad(dclib, N, H, W, Ci, Co):
     tiles = L.dc_conv3x3_tiles(N, H, W, Co)
     stats = torch.zeros(tiles * Co * 2, device='cuda', dtype=torch.float64)
     L.dc_conv3x3_fwd_f16x3(dev(x).data_ptr(), wp.data_ptr(), dev(b).data_ptr(), z.data_ptr(), Co, stats.data_ptr(),
-                           None, None, 0, None, None, N, H, W, Ci, Co, None)
+                           None, None, 0, None, 0, None, 0, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert rel_err(z.cpu().numpy(), z_ref) < 2e-5
     st = stats.cpu().numpy().reshape(tiles, Co, 2).astype(np.float64).sum(0)
@@ -192,7 +192,7 @@ def test_bn_relu_on_load_conv_convT_wgrad_head(dclib, N, H, W, Ci, Co):
     wp = torch.empty(L.dc_pack_weights_f16x3_floats(9, Ci, Co), device='cuda')
     L.dc_pack_weights_f16x3(Kd.data_ptr(), wp.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
     z1 = torch.full((N, H, W, Co), float('nan'), device='cuda'); z2 = torch.full_like(z1, float('nan'))
-    L.dc_conv3x3_fwd_f16x3(a.data_ptr(), wp.data_ptr(), None, z1.data_ptr(), Co, None, None, None, 0, ab.data_ptr(), None,
+    L.dc_conv3x3_fwd_f16x3(a.data_ptr(), wp.data_ptr(), None, z1.data_ptr(), Co, None, None, None, 0, ab.data_ptr(), 0, None, 0,
                            N, H, W, Ci, Co, None)
     L.dc_conv3x3_fwd_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), ab.data_ptr(), wp.data_ptr(), None,
                                 z2.data_ptr(), Co, None, None, None, 0, N, H, W, Ci, Co, None)
@@ -223,7 +223,7 @@ def test_bn_relu_on_load_conv_convT_wgrad_head(dclib, N, H, W, Ci, Co):
     wpt = torch.empty(L.dc_pack_weights_f16x3_floats(1, Ci, 4 * Co), device='cuda')
     L.dc_pack_weights_f16x3(KTd.data_ptr(), wpt.data_ptr(), 1, Ci, 4 * Co, 0, 1, Ci, 0, None)
     t1 = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device='cuda'); t2 = torch.full_like(t1, float('nan'))
-    L.dc_convT2x2_fwd_f16x3(a.data_ptr(), wpt.data_ptr(), None, t1.data_ptr(), Co, None, None, None, 0, ab.data_ptr(), None,
+    L.dc_convT2x2_fwd_f16x3(a.data_ptr(), wpt.data_ptr(), None, t1.data_ptr(), Co, None, None, None, 0, ab.data_ptr(), 0, None, 0,
                             N, H, W, Ci, Co, None)
     L.dc_convT2x2_fwd_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), ab.data_ptr(), wpt.data_ptr(), None,
                                  t2.data_ptr(), Co, None, None, None, 0, N, H, W, Ci, Co, None)
@@ -298,7 +298,7 @@ def test_conv3x3_c1(dclib, N, H, W, Co):
     z = torch.empty((N, H, W, Co), device='cuda')
     amx = torch.zeros(Co, device='cuda')
     L.dc_conv3x3_c1_fwd(dev(x).data_ptr(), dev(K).data_ptr(), dev(b).data_ptr(), z.data_ptr(), Co, stats.data_ptr(),
-                        None, None, 0, amx.data_ptr(), N, H, W, Co, None)
+                        None, None, 0, amx.data_ptr(), 0, N, H, W, Co, None)
     ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, H, W, 1, Co), device='cuda')
     dw = torch.empty((3, 3, 1, Co), device='cuda')
     L.dc_conv3x3_wgrad(dev(x).data_ptr(), dev(dz).data_ptr(), dw.data_ptr(), ws.data_ptr(), N, H, W, 1, Co, None)
@@ -356,7 +356,7 @@ def test_convT2x2(dclib, N, H, W, Ci, Co):
     stats2 = torch.zeros(tiles * 4 * Co * 2, device='cuda', dtype=torch.float64)
     amx = torch.zeros(Co, device='cuda')
     L.dc_convT2x2_fwd_f16x3(dev(x).data_ptr(), wp16.data_ptr(), dev(b).data_ptr(), z2.data_ptr(), Co, stats2.data_ptr(),
-                            None, None, 0, None, amx.data_ptr(), N, H, W, Ci, Co, None)
+                            None, None, 0, None, 0, amx.data_ptr(), 0, N, H, W, Ci, Co, None)
     dx2 = torch.full((N, H, W, Ci), float('nan'), device='cuda')
     L.dc_convT2x2_dgrad_f16x3(dev(dzs).data_ptr(), wpd16.data_ptr(), dx2.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
