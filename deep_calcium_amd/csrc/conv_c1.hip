@@ -50,7 +50,10 @@ struct C1Acc {
 };
 __device__ __forceinline__ void c1_finish(const C1Params& p, const C1Acc& a, int tid, int q, int pl, int C4, int PPB) {
   __shared__ DcMoments sm[4][256];
-  if (p.absmax) {
+  if (p.absmax && p.absmaxLd < 0) {      // optimistic inference: flag an output beyond fp16's range, nothing else
+    const float m = fmaxf(fmaxf(a.amax[0], a.amax[1]), fmaxf(a.amax[2], a.amax[3]));
+    if (!(m <= DC_F16_SAFE_MAX)) p.absmax[0] = 1.f;
+  } else if (p.absmax) {
     // pixel lanes of one channel quad sit C4 threads apart: fold them through LDS, one atomic per channel per block
     float* fm = reinterpret_cast<float*>(&sm[0][0]);
 #pragma unroll

@@ -346,7 +346,16 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   if (p.outAbsmax) {
     if (interior) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{});
     __syncthreads();
-    if (tid < Cfg::WAVES_N * NB * 32) {       // one atomic per output column per workgroup, into this workgroup's slot
+    if (p.outAbsmaxLd < 0) {                  // optimistic inference: only flag an output beyond fp16's range
+      if (tid < Cfg::WAVES_N * NB * 32) {
+        const int wn = tid / (NB * 32), rem = tid % (NB * 32);
+        const float* fm = reinterpret_cast<const float*>(smem + 4096);
+        float m = fm[(wn * WAVES_M) * NB * 32 + rem];
+#pragma unroll
+        for (int wm = 1; wm < WAVES_M; ++wm) m = fmaxf(m, fm[(wn * WAVES_M + wm) * NB * 32 + rem]);
+        if (!(m <= DC_F16_SAFE_MAX)) p.outAbsmax[0] = 1.f;        // (also catches NaN)
+      }
+    } else if (tid < Cfg::WAVES_N * NB * 32) {       // one atomic per output column per workgroup, into this workgroup's slot
       const int wn = tid / (NB * 32), rem = tid % (NB * 32);
       const float* fm = reinterpret_cast<const float*>(smem + 4096);
       float m = fm[(wn * WAVES_M) * NB * 32 + rem];

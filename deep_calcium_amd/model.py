@@ -241,7 +241,7 @@ class Model(object):
         out = np.empty(x.shape, np.float32)
         for i in range(0, x.shape[0], batch_size):
             xb = torch.from_numpy(x[i:i + batch_size]).to(self.engine.device)
-            out[i:i + batch_size] = self.engine.forward_infer(xb).cpu().numpy()[:xb.shape[0]]
+            out[i:i + batch_size] = self.engine.forward_infer_checked(xb).cpu().numpy()[:xb.shape[0]]
         return out
 
     def train_on_batch(self, x, y, drop_masks=None, presharded=False):

@@ -99,6 +99,11 @@ class UNetEngine(object):
         self.bnred = os.environ.get('DC_BNRED', '1') == '1'
         # fp16 range guard of the activation operands (A/B knob; the weights' pack-time scale is unconditional)
         self.range_guard = os.environ.get('DC_RANGE_GUARD', '1') == '1'
+        # Inference starts OPTIMISTIC: no activation scale (a BatchNorm network's activations are O(1)), the kernels only
+        # flag an output beyond fp16's range; forward_infer_checked() then repeats the pass with MEASURED per-channel
+        # bounds and keeps doing so for this engine (un-normalised inputs, exotic weights).  DC_INFER_GUARD=1: measured
+        # bounds from the first call.
+        self.infer_measured = os.environ.get('DC_INFER_GUARD', '0') == '1'
         # BatchNorm under batch-sharded data parallelism: 'local' = each rank normalises over its own shard
         # (standard DP semantics); 'sync' = the per-channel sums are all-reduced in forward and backward, so G ranks x B
         # images reproduce ONE device's step on the G*B batch
@@ -192,6 +197,7 @@ class UNetEngine(object):
                 self._ab_off[l.name], self._ab_ld[l.name] = o, l.cout
                 o += 8 * l.cout
         self.abound = torch.zeros(o, dtype=torch.float32, device=dev)
+        self._ovf = torch.zeros(4, dtype=torch.float32, device=dev)
         self._bufs = {}
         self._packed_dirty = True
         self._fold_dirty = True
@@ -372,13 +378,22 @@ class UNetEngine(object):
                          BN_EPS, self.stat_ptr(l, 2), self.stat_ptr(l, 3), l.cout, st)
         self._fold_dirty = False
 
+    def _ab_infer(self, l):
+        """(in_abound, in_abound_ld, out_absmax, out_absmax_ld) of layer l for the current inference mode."""
+        if self.mfma != 'f16x3' or not self.range_guard:
+            return None, 0, None, 0
+        if self.infer_measured:
+            return self._ab_in(l, True) + self._ab_out(l, True)
+        return None, 0, self._ovf.data_ptr(), -1
+
     def _conv_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None, measured=False):
         """bnin = (scale_ptr, shift_ptr): x is the producer's pre-BN tensor, BN + ReLU are applied on load.
         measured: inference -- the input bound is a measured one (8 replicas) and the epilogue folds max |output| per
         channel into the output's replicas (the next layer's range-guard bound)."""
-        (ab_in, ab_in_ld), (ab_out, ab_out_ld) = self._ab_in(l, True), self._ab_out(l, True)
-        if not measured:
-            ab_in_ld, ab_out, ab_out_ld = 0, None, 0
+        if measured:
+            ab_in, ab_in_ld, ab_out, ab_out_ld = self._ab_infer(l)
+        else:
+            ab_in, ab_in_ld, ab_out, ab_out_ld = self._ab_in(l), 0, None, 0
         if bnin is not None:
             self.L.dc_conv3x3_fwd_bnin_f16x3(x, bnin[0], bnin[1], self._ab_in(l), _ptr(self.wp_fwd[l.name]), bias, z, z_ld,
                                              stats, sc, sh, relu, N, h, w, l.cin, l.cout, st)
@@ -390,9 +405,10 @@ class UNetEngine(object):
                                   N, h, w, l.cin, l.cout, st)
 
     def _convT_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None, measured=False):
-        (ab_in, ab_in_ld), (ab_out, ab_out_ld) = self._ab_in(l, True), self._ab_out(l, True)
-        if not measured:
-            ab_in_ld, ab_out, ab_out_ld = 0, None, 0
+        if measured:
+            ab_in, ab_in_ld, ab_out, ab_out_ld = self._ab_infer(l)
+        else:
+            ab_in, ab_in_ld, ab_out, ab_out_ld = self._ab_in(l), 0, None, 0
         if bnin is not None:
             self.L.dc_convT2x2_fwd_bnin_f16x3(x, bnin[0], bnin[1], self._ab_in(l), _ptr(self.wp_fwd[l.name]), bias, z, z_ld,
                                               stats, sc, sh, relu, N, h, w, l.cin, l.cout, st)
@@ -560,8 +576,11 @@ class UNetEngine(object):
         self.repack()
         self.refold()
         A = self._acts(N)
-        if self.mfma == 'f16x3':
-            self.abound.zero_()           # inference: the conv epilogues fold the measured max |a| per channel into it
+        if self.mfma == 'f16x3' and self.range_guard:
+            if self.infer_measured:
+                self.abound.zero_()       # the conv epilogues fold the measured max |a| per channel into it
+            else:
+                self._ovf.zero_()         # optimistic: they only raise this flag (forward_infer_checked looks at it)
         for step in self._plan(A):
             if step[0] == 'pool':
                 _, lvl, src, coff, ld, h, w = step
@@ -569,14 +588,15 @@ class UNetEngine(object):
                 continue
             if step[0] == 'up':
                 _, lvl, src, dst, ld, h, w = step
-                L.dc_upsample2x_drop_fwd(_ptr(src), _ptr(dst), ld, None, 1.0, 0, *self._ab_up(lvl, True), N, h // 2, w // 2,
-                                         self._cup(lvl), st)
+                L.dc_upsample2x_drop_fwd(_ptr(src), _ptr(dst), ld, None, 1.0, 0,
+                                         *(self._ab_up(lvl, True) if self.infer_measured else (None, 0, None, 0)),
+                                         N, h // 2, w // 2, self._cup(lvl), st)
                 continue
             _, l, src, dst, coff, ld, h, w, _prod = step
             sc, sh = self.stat_ptr(l, 2), self.stat_ptr(l, 3)
             if l.kind == 'conv' and l.cin == 1:
                 L.dc_conv3x3_c1_fwd(_ptr(x_dev), self.pview(self.pflat, l, 'k'), None, _ptr(dst, coff), ld, None,
-                                    sc, sh, 1, *self._ab_out(l, True), N, h, w, l.cout, st)
+                                    sc, sh, 1, *self._ab_infer(l)[2:], N, h, w, l.cout, st)
             elif l.kind == 'conv':
                 self._conv_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h, w, st, measured=True)
             else:
@@ -585,6 +605,15 @@ class UNetEngine(object):
         L.dc_head_fwd(_ptr(A['d0b']), self.pview(self.pflat, lo, 'k'), self.pview(self.pflat, lo, 'b'), None,
                       _ptr(A['p']), None, N * self.H * self.W, self.nfb, st)
         return A['p']
+
+    def forward_infer_checked(self, x_dev):
+        """forward_infer + the range check of the optimistic mode: if an activation left fp16's range the pass is
+        repeated with measured per-channel bounds (and the engine stays in that mode).  Synchronises the stream."""
+        p = self.forward_infer(x_dev)
+        if self.mfma == 'f16x3' and self.range_guard and not self.infer_measured and float(self._ovf[0].item()) != 0.0:
+            self.infer_measured = True
+            p = self.forward_infer(x_dev)
+        return p
 
     @_on_device
     def predict_tta(self, img, augmentations, hs, ws, threshold):
@@ -614,7 +643,7 @@ class UNetEngine(object):
         m['host'].numpy()[...] = img
         m['src'].copy_(m['host'].view(-1), non_blocking=True)
         L.dc_gather_maps(_ptr(m['src']), m['fwd'].data_ptr(), _ptr(m['x']), K, n, st)
-        p = self.forward_infer(m['x'])
+        p = self.forward_infer_checked(m['x'])
         L.dc_tta_merge(_ptr(p), m['inv'].data_ptr(), K, H, W, int(hs), int(ws), float(threshold), m['mask'].data_ptr(), None, st)
         m['mask_host'][:hs * ws].copy_(m['mask'][:hs * ws], non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()

@@ -85,7 +85,10 @@ int dc_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* ws,
  *   Measured bounds (inference) live in DC_ABOUND_SLOTS = 8 replicas of the per-channel array, `*_ld` floats apart: a
  *   producer folds max |output| into replica (workgroup id mod 8) with an atomic max (out_absmax, out_absmax_ld; the
  *   caller zeroes all replicas first), the consumer takes the max over the replicas (in_abound_ld > 0).
- *   in_abound_ld == 0: a single array (the training-mode bound). */
+ *   in_abound_ld == 0: a single array (the training-mode bound).
+ *   out_absmax_ld == -1 (optimistic inference): nothing is measured; out_absmax[0] is set to 1 if any output exceeds
+ *   32768 (or is NaN) -- the caller then repeats the forward pass with measured bounds.  A BatchNorm network's
+ *   activations are O(1), so this path normally runs with no guard traffic at all. */
 #define DC_ABOUND_SLOTS 8
 long dc_pack_weights_f16x3_floats(int taps, int K, int Ncols);
 int dc_pack_weights_f16x3(const float* src, void* dst, int taps, int K, int Ncols,

@@ -265,7 +265,16 @@ def test_inference_on_unnormalised_input(xscale):
     for mode in ('f16x3', 'f32'):
         eng = UNetEngine((H, W), nb_filters_base=nfb, mfma=mode)
         eng.set_weights(Wt)
-        p = eng.forward_infer(torch.from_numpy(x).cuda()).cpu().numpy()
+        xd = torch.from_numpy(x).cuda()
+        if mode == 'f16x3' and xscale > 1:
+            # the optimistic pass (no activation scale) overflows fp16 and says so ...
+            assert not eng.infer_measured
+            eng.forward_infer(xd)
+            torch.cuda.synchronize()
+            assert float(eng._ovf[0].item()) == 1.0
+        # ... and the checked entry point (what Model.predict / predict_tta call) repeats it with measured bounds
+        p = eng.forward_infer_checked(xd).cpu().numpy()
+        assert eng.infer_measured == (mode == 'f16x3' and xscale > 1)
         A = eng._acts(N)
         assert np.isfinite(p).all()
         errs = {}
