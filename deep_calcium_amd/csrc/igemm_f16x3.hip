@@ -22,6 +22,23 @@
 #include "igemm_common.h"
 #include <type_traits>
 
+// Phase timestamps of sampled workgroups (scripts/igemm_phases.py builds the library with -DDC_IGEMM_TRACE and reads
+// them back): wave 0 / lane 0 of every 37th workgroup stores s_memtime at each DC_TRACE point.  Compiled out otherwise.
+#ifdef DC_IGEMM_TRACE
+__device__ unsigned long long* g_dc_trace = nullptr;
+extern "C" int dc_debug_set_trace(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_dc_trace), &p, sizeof(p)) == hipSuccess ? 0 : -2;
+}
+#define DC_TRACE_INIT()                                                                                     \
+  unsigned long long* trc_ = (g_dc_trace && blockIdx.x % 37 == 0 && threadIdx.x == 0)                       \
+                                 ? g_dc_trace + (blockIdx.x / 37) * 64 : nullptr;                           \
+  int trn_ = 0
+#define DC_TRACE() do { if (trc_ && trn_ < 63) trc_[++trn_] = __builtin_readcyclecounter(); if (trc_) trc_[0] = trn_; } while (0)
+#else
+#define DC_TRACE_INIT() do {} while (0)
+#define DC_TRACE() do {} while (0)
+#endif
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -50,17 +67,25 @@ struct IgemmH {
   static_assert(CK % 16 == 0 && 256 % G4 == 0, "CK must be a multiple of the MFMA k (16)");
 };
 
+// hi = fp16(x*s), lo = fp16(x*s - hi) for 4 elements in EIGHT vector instructions: v_fma_mix{lo,hi}_f16 multiplies in
+// fp32, adds an fp16 (or zero) and rounds once to fp16 into one half of the destination.  (s is a power of two and
+// x*s - hi is exactly representable, so the bits equal the two-step form (half)(x*s - (float)hi).)  hipcc's own lowering
+// of the C expression spent 13 instructions per 4 elements, part of them packed-fp32 ops that issue at half rate next to
+// MFMAs -- and this split runs in the matrix waves' own instruction stream, once per staged element.
 __device__ __forceinline__ void split_f16(const f32x4 v, float s, u32x2& hi, u32x2& lo) {
-  f16x4 h, l;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float x = v[e] * s;
-    const _Float16 hh = (_Float16)x;
-    h[e] = hh;
-    l[e] = (_Float16)(x - (float)hh);
-  }
-  hi = __builtin_bit_cast(u32x2, h);
-  lo = __builtin_bit_cast(u32x2, l);
+  unsigned h01, h23, l01, l23;
+  asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+      "v_fma_mixlo_f16 %1, %6, %8, 0\n\t"
+      "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+      "v_fma_mixhi_f16 %1, %7, %8, 0\n\t"
+      "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(s));
+  hi = u32x2{h01, h23};
+  lo = u32x2{l01, l23};
 }
 
 template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB, int CK_>
@@ -77,6 +102,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: tile math goes to the SALU
+  DC_TRACE_INIT();
   const int li = lane & 31, h = lane >> 5;
   const int wave_m = wave % WAVES_M, wave_n = wave / WAVES_M;
 
@@ -173,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
+  DC_TRACE();            // 1: entry + address setup
   load_chunk(0);
   // Per-channel tables and the operand scale AFTER the first chunk's loads are in flight (their latency is the same
   // L2 round trip): the BN-on-load (scale, shift) pairs, and the powers of two -- device scalar of a gradient tensor x
@@ -182,7 +209,13 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   const float in_scale = (p.inScale ? *p.inScale : 1.f) *
                          dc_block_guard_scale(p.inAbound, p.Cin, reinterpret_cast<float*>(smem), p.inAboundLd);
   if (bnin && p.inAbound == nullptr) __syncthreads();
+  DC_TRACE();            // 2: first loads issued, tables / guard done
   for (int c0 = 0; c0 < p.Cin; c0 += CK) {
+    DC_TRACE();          // per chunk a: top
+#ifdef DC_IGEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DC_TRACE();          // a2: this chunk's global loads have landed (trace build only: separates waiting from splitting)
+#endif
     f32x4 csc = {1.f, 1.f, 1.f, 1.f}, csh = {0.f, 0.f, 0.f, 0.f};
     const bool ch_ok = c0 + 4 * a_g < p.Cin;
     if (bnin && ch_ok) {
@@ -213,7 +246,9 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
       const int row = b_row0 + it * B_STEP;
       if (row < BROWS) ldsB[row * BN + b_j] = rb[it];
     }
+    DC_TRACE();          // b: operands split and written to LDS (includes the wait for this chunk's global loads)
     __syncthreads();
+    DC_TRACE();          // c: barrier passed
     if (c0 + CK < p.Cin) load_chunk(c0 + CK);
 
     // Software-pipelined operand fetch: the fragments of step tk+1 are requested from LDS before the 3*MB*NB
@@ -252,8 +287,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
         }
       __builtin_amdgcn_sched_barrier(0);
     }
+    DC_TRACE();          // d: MFMA block done
     __syncthreads();
   }
+  DC_TRACE();            // e: main loop left
 
   // ---- epilogue: C/D col = lane&31 -> output column n, row m = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel --------
   // Stores go through a buffer descriptor of this image's output; pixels outside the image / columns beyond
@@ -269,9 +306,13 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   // Interior items (every pixel and column of the tile exists: all but the ragged border) take a lean epilogue: no
   // per-element validity selects, and the per-element address term rides in the scalar soffset operand.
   const bool interior = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (n0 + BN <= p.Ncols);   // wave-uniform
-  auto epilogue = [&](auto interior_tag, auto track_tag) {
+  // (A variant with the MFMA operands swapped -- 4 consecutive channels per lane, 16-byte stores -- was measured and
+  // dropped: its stores touch 32 cache lines of 32 bytes each per instruction and the epilogue took 1.7x LONGER.)
+  auto epilogue = [&](auto interior_tag, auto mode_tag) {
     constexpr bool INT = decltype(interior_tag)::value;
-    constexpr bool TRACK = decltype(track_tag)::value;     // inference: fold max |output| per channel into outAbsmax
+    constexpr int MODE = decltype(mode_tag)::value;        // 0 plain (data gradients), 1 BatchNorm partials, 2 inference
+    constexpr bool STATS = MODE == 1;
+    constexpr bool TRACK = MODE == 2;                      // fold max |output| per channel into outAbsmax
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const int n = n0 + (wave_n * NB + nb) * 32 + li;
@@ -299,8 +340,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
           float v = __builtin_fmaf(acc[mb][nb][r], out_scale, bv);
           const float d = v - K;
           if constexpr (INT) {
-            s1 += d;
-            s2 = __builtin_fmaf(d, d, s2);
+            if constexpr (STATS) {
+              s1 += d;
+              s2 = __builtin_fmaf(d, d, s2);
+            }
             if (p.scale) v = v * sc + sh;
             if (p.relu) v = fmaxf(v, 0.f);
             if constexpr (TRACK) amax = fmaxf(amax, fabsf(v));
@@ -308,9 +351,11 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
                                                   (rowc * sy + colc * sx) * 4, 0);      // scalar addend
           } else {
             const bool ok = n_ok && (oyb + rowc) < p.Hout && (oxb + colc) < p.Wout;
-            s1 += ok ? d : 0.f;
-            s2 += ok ? d * d : 0.f;
-            cnt += ok ? 1.f : 0.f;
+            if constexpr (STATS) {
+              s1 += ok ? d : 0.f;
+              s2 += ok ? d * d : 0.f;
+              cnt += ok ? 1.f : 0.f;
+            }
             if (p.scale) v = v * sc + sh;
             if (p.relu) v = fmaxf(v, 0.f);
             if constexpr (TRACK) amax = fmaxf(amax, ok ? fabsf(v) : 0.f);
@@ -319,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
           }
         }
       }
-      if (p.stats) {
+      if constexpr (STATS) {
         DcMoments m;
         if constexpr (INT) {      // every lane holds 16*MB values: no divisions
           constexpr float NL = (float)(16 * MB);
@@ -343,8 +388,11 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
       }
     }
   };
+  using Plain = std::integral_constant<int, 0>;
+  using Stats = std::integral_constant<int, 1>;
+  using Track = std::integral_constant<int, 2>;
   if (p.outAbsmax) {
-    if (interior) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{});
+    if (interior) epilogue(std::true_type{}, Track{}); else epilogue(std::false_type{}, Track{});
     __syncthreads();
     if (p.outAbsmaxLd < 0) {                  // optimistic inference: only flag an output beyond fp16's range
       if (tid < Cfg::WAVES_N * NB * 32) {
@@ -364,9 +412,12 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
       const int n = n0 + wn * NB * 32 + rem;
       if (n < p.Ncols) dc_atomic_absmax(p.outAbsmax + dc_absmax_slot(p.outAbsmaxLd) + n % p.biasMod, m);
     }
+  } else if (p.stats) {
+    if (interior) epilogue(std::true_type{}, Stats{}); else epilogue(std::false_type{}, Stats{});
   } else {
-    if (interior) epilogue(std::true_type{}, std::false_type{}); else epilogue(std::false_type{}, std::false_type{});
+    if (interior) epilogue(std::true_type{}, Plain{}); else epilogue(std::false_type{}, Plain{});
   }
+  DC_TRACE();            // f: epilogue stores issued
   if (p.stats) {
     __syncthreads();
     if (tid < Cfg::WAVES_N * NB * 32) {
@@ -557,6 +608,7 @@ extern "C" int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const floa
   int rc = check_h("dc_conv3x3_fwd_f16x3", x, wp16, z, N, H, W, Cin, Cout);
   if (rc) return rc;
   DC_REQUIRE((scale == nullptr) == (shift == nullptr), DC_EINVAL, "dc_conv3x3_fwd_f16x3: scale and shift go together");
+  DC_REQUIRE(!(stats && out_absmax), DC_EINVAL, "dc_conv3x3_fwd_f16x3: stats (training) and out_absmax (inference) are exclusive");
   DC_REQUIRE(z_ld >= Cout, DC_EINVAL, "dc_conv3x3_fwd_f16x3: z_ld < Cout");
   IgemmParams p{};
   p.in = x; p.wp = reinterpret_cast<const float*>(wp16); p.bias = bias; p.out = z; p.stats = stats;
@@ -620,6 +672,7 @@ extern "C" int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const flo
   int rc = check_h("dc_convT2x2_fwd_f16x3", x, wp16, z, N, H, W, Cin, Cout);
   if (rc) return rc;
   DC_REQUIRE((scale == nullptr) == (shift == nullptr), DC_EINVAL, "dc_convT2x2_fwd_f16x3: scale and shift go together");
+  DC_REQUIRE(!(stats && out_absmax), DC_EINVAL, "dc_convT2x2_fwd_f16x3: stats (training) and out_absmax (inference) are exclusive");
   DC_REQUIRE(z_ld >= Cout, DC_EINVAL, "dc_convT2x2_fwd_f16x3: z_ld < Cout");
   IgemmParams p{};
   p.in = x; p.wp = reinterpret_cast<const float*>(wp16); p.bias = bias; p.out = z; p.stats = stats;

@@ -71,18 +71,22 @@ __device__ __forceinline__ f16x8 tr_frag(const char* base, int off1, int off2) {
   return __builtin_bit_cast(f16x8, v);
 }
 
+// hi = fp16(x*s), lo = fp16(x*s - hi): two v_fma_mix per element (see split_f16 in igemm_f16x3.hip)
 template <bool SCALED>
 __device__ __forceinline__ void split4_f16(const f32x4 v, float s, u32x2& hi, u32x2& lo) {
-  f16x4 h, l;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float x = SCALED ? v[e] * s : v[e];
-    const _Float16 hh = (_Float16)x;
-    h[e] = hh;
-    l[e] = (_Float16)(x - (float)hh);
-  }
-  hi = __builtin_bit_cast(u32x2, h);
-  lo = __builtin_bit_cast(u32x2, l);
+  unsigned h01, h23, l01, l23;
+  asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+      "v_fma_mixlo_f16 %1, %6, %8, 0\n\t"
+      "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+      "v_fma_mixhi_f16 %1, %7, %8, 0\n\t"
+      "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(s));
+  hi = u32x2{h01, h23};
+  lo = u32x2{l01, l23};
 }
 
 template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW, bool A_SCALED>

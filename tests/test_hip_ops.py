@@ -355,8 +355,14 @@ def test_convT2x2(dclib, N, H, W, Ci, Co):
     z2 = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device='cuda')
     stats2 = torch.zeros(tiles * 4 * Co * 2, device='cuda', dtype=torch.float64)
     amx = torch.zeros(Co, device='cuda')
+    L.dc_convT2x2_fwd_f16x3(dev(x).data_ptr(), wp16.data_ptr(), dev(b).data_ptr(), z2.data_ptr(), Co, None,
+                            None, None, 0, None, 0, amx.data_ptr(), 0, N, H, W, Ci, Co, None)       # inference: measured max
+    torch.cuda.synchronize()
+    zi = z2.clone()
     L.dc_convT2x2_fwd_f16x3(dev(x).data_ptr(), wp16.data_ptr(), dev(b).data_ptr(), z2.data_ptr(), Co, stats2.data_ptr(),
-                            None, None, 0, None, 0, amx.data_ptr(), 0, N, H, W, Ci, Co, None)
+                            None, None, 0, None, 0, None, 0, N, H, W, Ci, Co, None)                  # training: partials
+    torch.cuda.synchronize()
+    assert torch.equal(zi, z2)
     dx2 = torch.full((N, H, W, Ci), float('nan'), device='cuda')
     L.dc_convT2x2_dgrad_f16x3(dev(dzs).data_ptr(), wpd16.data_ptr(), dx2.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
