@@ -21,20 +21,22 @@ stats_csv = os.path.join(src, 'stats', 'p_kernel_stats.csv')
 shutil.copy(stats_csv, os.path.join(P, tag + '_bench_train_b16_kernel_stats.csv'))
 rows = list(csv.DictReader(open(stats_csv)))
 pmc_json = os.path.join(P, tag + '_pmc_per_kernel.json')
-table = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'pmc_table.py'), os.path.join(src, 'pmc'), '--json', pmc_json],
-                       capture_output=True, text=True, check=True).stdout
-per_kernel = json.load(open(pmc_json))
-dom = bench['roofline']['kernel'].replace(' ', '')
-d = [r for r in per_kernel if r['kernel'] == dom][0]
-old = {}
-tp = os.path.join(P, 'pmc_traffic.json')
-if os.path.exists(tp):
-    old = json.load(open(tp))
-traffic = dict(old)
-traffic.update(kernel=bench['roofline']['kernel'], bytes_per_launch=int(round((d['fetch_MB'] + d['write_MB']) * 1e6)),
-               fetch_bytes_per_launch=int(round(d['fetch_MB'] * 1e6)), write_bytes_per_launch=int(round(d['write_MB'] * 1e6)),
-               mfma_busy_frac=d['mfma_util'], source=tag + '_pmc_per_kernel.json')
-json.dump(traffic, open(tp, 'w'), indent=1)
+# pmc_traffic.json = what bench.py's roofline.traffic reports, stamped with the kernel-source fingerprint it was measured on
+table = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'pmc_table.py'), os.path.join(src, 'pmc'), '--json', pmc_json,
+                        '--traffic', os.path.join(P, 'pmc_traffic.json')], capture_output=True, text=True, check=True).stdout
+traffic = json.load(open(os.path.join(P, 'pmc_traffic.json')))
+traffic['source'] = tag + '_pmc_per_kernel.json'
+json.dump(traffic, open(os.path.join(P, 'pmc_traffic.json'), 'w'), indent=1)
+for name, dst in (('FETCH_SIZE', 'pmc_fetch_size'), ('WRITE_SIZE', 'pmc_write_size'), ('SQ_VALU_MFMA_BUSY_CYCLES', 'pmc_mfma_busy')):
+    f = os.path.join(src, 'pmc', name, 'p_counter_collection.csv')
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(P, '%s_%s.csv' % (tag, dst)))
+for name in ('bench.json', 'bench_infer.json', 'bench_tta.json'):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(P, '%s_%s' % (tag, name)))
+si = os.path.join(src, 'stats_infer', 'p_kernel_stats.csv')
+if os.path.exists(si):
+    shutil.copy(si, os.path.join(P, tag + '_bench_infer_b8_kernel_stats.csv'))
 
 steps = 11   # bench.py --steps 5 --warmup 2 + 4 instrumented steps (2 with, 2 without the side stream)
 out = io.StringIO()
