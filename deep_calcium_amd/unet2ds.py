@@ -59,6 +59,22 @@ _SIX = [
 ]
 
 
+_PROBE = np.arange(4).reshape(2, 2)
+_D4 = [lambda a: a, lambda a: a[:, ::-1], lambda a: a[::-1, :], lambda a: np.rot90(a, 1), lambda a: np.rot90(a, 2),
+       lambda a: np.rot90(a, 3), lambda a: np.rot90(a, 1)[:, ::-1], lambda a: np.rot90(a, 1)[::-1, :]]
+_D4_KEYS = {tuple(f(_PROBE).ravel()): f for f in _D4}
+_D4[0] = _SIX[0]
+_D4_KEYS[tuple(_PROBE.ravel())] = _SIX[0]
+
+
+def _compose_six(indices):
+    """The single dihedral transform equal to applying _SIX[j] for j in `indices` in order (square arrays)."""
+    probe = _PROBE
+    for j in indices:
+        probe = _SIX[j](probe)
+    return _D4_KEYS[tuple(np.asarray(probe).ravel())]
+
+
 def _open_dataset(dspath):
     """A dataset is the reference's HDF5 file (datasets/nf.py:37-150: attrs['name'], series/{raw,mean,max},
     masks/{raw,max}; read with h5py when importable, else with the built-in reader hdf5_min) or an .npz with the same
@@ -305,18 +321,32 @@ class UNet2DSummary(object):
             ys, xs = np.where(m[ymin:ymax, :] == 1)          # NB relative to ymin, used as absolute (:474, :510)
             locs.append(np.stack([ys, xs], axis=1))
         probs = np.ones(n_ds) / n_ds
+        # crop sources in the batch dtypes (the reference's assignment into the float32 / uint8 batch arrays converts
+        # per item; the values are the same)
+        S_src = [np.ascontiguousarray(v, dtype=np.float32) for v in S_summ]
+        M_src = [np.ascontiguousarray(v).astype(np.uint8) for v in M_summ]
+        pool = None
+        if (b1 - b0) * hw * ww >= 8 * 256 * 256:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=min(4, b1 - b0))
         while True:
             if scores_path and os.path.exists(scores_path) and (nb_yields - 1) % nb_steps == 0:
                 with open(scores_path, 'rb') as fp:
                     scores = pickle.load(fp)
                 probs = np.array([1 - np.mean(scores[n]) for n in names])
                 probs /= probs.sum()
-            s_batch = np.zeros((b1 - b0, hw, ww), dtype=np.float32)
-            m_batch = np.zeros((b1 - b0, hw, ww), dtype=np.uint8)
+            # Phase 1 (sequential: it IS the reference's random stream): every draw of the global batch, in order; items of
+            # other ranks only advance the stream.  Phase 2: the array work of this rank's items -- on a few threads for
+            # big windows (numpy's copies release the GIL), so that the one producer thread keeps up with the GPU step.
+            specs = []
+            # rng.choice(np.arange(n), p=probs) == searchsorted(cumsum(p) / cumsum(p)[-1], random_sample(), 'right') and
+            # rng.choice(6, n) == randint(0, 6, size=n): numpy's own (legacy RandomState) implementation, minus its
+            # per-call argument checking -- same draws, same values (pinned by the reference-generated goldens)
+            cdf = probs.cumsum()
+            cdf /= cdf[-1]
             for b in range(batch_size):
-                k = rng.choice(np.arange(n_ds), p=probs)
-                s, m = S_summ[k], M_summ[k]
-                hs, ws = s.shape
+                k = int(cdf.searchsorted(rng.random_sample(), side='right'))
+                hs, ws = S_summ[k].shape
                 ymin, ymax = y_coords[k]
                 cy, cx = locs[k][rng.randint(0, len(locs[k]))]
                 cy = min(max(ymin, cy + rng.randint(-5, 5)), ymax)
@@ -325,14 +355,35 @@ class UNet2DSummary(object):
                 y1 = min(y0 + hw, ymax)
                 x0 = max(0, int(cx - (ww / 2)))
                 x1 = min(x0 + ww, ws)
-                augs = rng.choice(len(_SIX), rng.randint(0, nb_max_augment + 1))
-                if not b0 <= b < b1:
-                    continue                                          # another rank's item: draws made, no array work
-                i = b - b0
-                m_batch[i, :y1 - y0, :x1 - x0] = m[y0:y1, x0:x1]      # short crops stay zero-filled
-                s_batch[i, :y1 - y0, :x1 - x0] = s[y0:y1, x0:x1]
-                for j in augs:
-                    s_batch[i], m_batch[i] = _SIX[j](s_batch[i]), _SIX[j](m_batch[i])
+                augs = rng.randint(0, len(_SIX), size=rng.randint(0, nb_max_augment + 1))
+                if b0 <= b < b1:
+                    specs.append((b - b0, k, y0, y1, x0, x1, augs))
+            s_batch = np.empty((b1 - b0, hw, ww), dtype=np.float32)
+            m_batch = np.empty((b1 - b0, hw, ww), dtype=np.uint8)
+
+            def materialise(spec):
+                i, k, y0, y1, x0, x1, augs = spec
+                # the drawn flips / rot90s are elements of the dihedral group: their composition is ONE of 8 pixel
+                # permutations, found on a 2x2 probe and applied once (same bits, ~1/8 of the array traffic of
+                # applying up to 15 of them one after the other as the reference does, :524-527)
+                f = _compose_six(augs) if hw == ww else None
+                if f is not None and y1 - y0 == hw and x1 - x0 == ww:  # full window: transform the crop view, one copy
+                    s_batch[i], m_batch[i] = f(S_src[k][y0:y1, x0:x1]), f(M_src[k][y0:y1, x0:x1])
+                    return
+                s_batch[i], m_batch[i] = 0, 0                         # short crops are zero-filled (:520-521)
+                m_batch[i, :y1 - y0, :x1 - x0] = M_src[k][y0:y1, x0:x1]
+                s_batch[i, :y1 - y0, :x1 - x0] = S_src[k][y0:y1, x0:x1]
+                if f is None:
+                    for j in augs:
+                        s_batch[i], m_batch[i] = _SIX[j](s_batch[i]), _SIX[j](m_batch[i])
+                elif f is not _SIX[0]:
+                    s_batch[i], m_batch[i] = f(s_batch[i]), f(m_batch[i])
+
+            if pool is not None:
+                list(pool.map(materialise, specs))
+            else:
+                for spec in specs:
+                    materialise(spec)
             nb_yields += 1
             yield s_batch, m_batch
 
