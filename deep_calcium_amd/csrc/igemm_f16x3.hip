@@ -450,7 +450,10 @@ static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name) {
 }
 
 // Same tile-shape choice (and therefore the same `tiles` count for the BN partials) as the fp32 kernel.
+bool dc_igemm_pp_serves(const IgemmParams& p);                         // igemm_pp.hip: persistent role-split variant
+int dc_igemm_pp_launch(IgemmParams p, hipStream_t st, const char* name);
 static int conv3x3_h_launch(IgemmParams p, hipStream_t st) {
+  if (dc_igemm_pp_serves(p)) return dc_igemm_pp_launch(p, st, "conv3x3_f16x3_pp");
   if (p.Wout > 16) {
     if (p.Ncols <= 32) return igemm_h_launch<3, 3, 1, 1, 32, 4, 4, 1>(p, st, "conv3x3_f16x3");
     return igemm_h_launch<3, 3, 1, 1, 32, 4, 2, 2>(p, st, "conv3x3_f16x3");

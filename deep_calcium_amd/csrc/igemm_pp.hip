@@ -1,0 +1,515 @@
+// Persistent, role-split conv3x3 implicit GEMM on the fp16 matrix cores (split-fp16 operands, numerics and data layouts of
+// igemm_f16x3.hip: same packed weights, same LDS operand images, same accumulation order => bit-identical results).
+//
+// Why: scripts/igemm_phases.py shows a workgroup of the 256-thread kernel spending ~1.9x as long
+// OUTSIDE its MFMA blocks (fp16 split + LDS writes, barriers, tile decode, epilogue) as inside them, so two such
+// workgroups per CU keep the matrix pipe busy only ~53 %.  Here ONE 768-thread workgroup per CU runs for the whole launch:
+//   waves 8-11  producers : request chunk k+2's global rows, split chunk k+1 into the OTHER LDS stage (BN + ReLU on load,
+//                           range-guard scale) -- always one step ahead, across tile boundaries (no prologue bubble);
+//   waves 0-3   consumers A, waves 4-7 consumers B: alternate output tiles.  While one set runs the 108 MFMAs of a step on
+//                           the stage that is ready, the other runs one SLICE of the epilogue of its previous tile (bias,
+//                           BatchNorm partials, stores): the matrix pipe of every SIMD always has exactly one wave feeding it.
+// One s_barrier per step (a 16-channel chunk).  Every SIMD hosts one wave of each role.
+// Served launches: conv3x3 forward (training, BN-on-load, inference) and data gradient with W > 16, > 32 output columns,
+// Cin a multiple of 16 and >= 64 (>= 4 steps per tile for the sliced epilogue); everything else stays on igemm_f16x3.hip.
+#include "igemm_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Step timestamps of sampled workgroups (scripts/igemm_pp_phases.py; compiled out unless -DDC_IGEMM_TRACE): per role the
+// first wave stores s_memtime when its work of a step is done and again when the step's barrier has released it.
+#ifdef DC_IGEMM_TRACE
+__device__ unsigned long long* g_pp_trace = nullptr;
+extern "C" int dc_debug_set_pp_trace(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_pp_trace), &p, sizeof(p)) == hipSuccess ? 0 : -2;
+}
+#define PP_TRACE_INIT()                                                                                          \
+  unsigned long long* trc_ = (g_pp_trace && blockIdx.x % 37 == 0 && (threadIdx.x & 255) == 0)                    \
+                                 ? g_pp_trace + ((blockIdx.x / 37) * 3 + (threadIdx.x >> 8)) * 512 : nullptr;    \
+  int trn_ = 0
+#define PP_TRACE() do { if (trc_ && trn_ < 510) trc_[++trn_] = __builtin_readcyclecounter(); if (trc_) trc_[0] = trn_; } while (0)
+#else
+#define PP_TRACE_INIT() do {} while (0)
+#define PP_TRACE() do {} while (0)
+#endif
+
+namespace pp {
+constexpr int KW = 3, TAPS = 9, TW = 32, WAVES_M = 4, MB = 2, NB = 2, CK = 16;
+constexpr int RPM = 32 / TW, TH = WAVES_M * MB * RPM, BN = NB * 32;
+constexpr int THI = TH + 2, TWI = TW + 2, NPIXH = THI * TWI;
+constexpr int PS = ((NPIXH + 5) / 8) * 8 + 2;
+constexpr int G4 = CK / 4, G8 = CK / 8;
+constexpr int NA = (NPIXH * G4 + 255) / 256;
+constexpr int BROWS = TAPS * G8 * 2;
+constexpr int NBV = (BROWS * BN + 255) / 256;
+constexpr int A_SLOTS = 2 * G8 * PS;
+constexpr int STAGE_SLOTS = A_SLOTS + BROWS * BN;
+constexpr int STAGE_BYTES = STAGE_SLOTS * 16;
+constexpr int RED_ENTRIES = WAVES_M * NB * 32;                      // per consumer set
+constexpr int RED_BYTES = 2 * RED_ENTRIES * (int)sizeof(DcMoments);
+constexpr int TMP_BYTES = 64;
+constexpr int FIXED_LDS = 2 * STAGE_BYTES + RED_BYTES + TMP_BYTES;
+constexpr int TABLE_BYTES = 8 * 1024;          // BN-on-load table: 2 x Cin floats, Cin <= 1024
+constexpr int EP_COLS = 512;                   // epilogue parameter table: 3 x Ncols floats, Ncols <= 512
+constexpr int THREADS = 768;
+constexpr unsigned OOB = 0x80000000u;
+static_assert(256 % BN == 0 && NB == 2 && MB == 2, "staging / epilogue slicing assume 64 columns in two 32-column blocks");
+
+// hi = fp16(x*s), lo = fp16(x*s - hi): two v_fma_mix per element (igemm_f16x3.hip split_f16)
+__device__ __forceinline__ void split(const f32x4 v, float s, u32x2& hi, u32x2& lo) {
+  unsigned h01, h23, l01, l23;
+  asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+      "v_fma_mixlo_f16 %1, %6, %8, 0\n\t"
+      "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+      "v_fma_mixhi_f16 %1, %7, %8, 0\n\t"
+      "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(s));
+  hi = u32x2{h01, h23};
+  lo = u32x2{l01, l23};
+}
+
+struct Item {          // one output tile x column block (wave-uniform)
+  int tile_id, img, n0, oy0, ox0;
+};
+}  // namespace pp
+
+__global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p) {
+  using namespace pp;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DcMoments* red_all = reinterpret_cast<DcMoments*>(smem + 2 * STAGE_BYTES);
+  float* tmp = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES + RED_BYTES);
+  float* lds_sc = reinterpret_cast<float*>(smem + FIXED_LDS);                 // BN-on-load (scale, shift) per input channel
+  float* lds_ep = reinterpret_cast<float*>(smem + FIXED_LDS + TABLE_BYTES);   // epilogue bias | scale | shift per column
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..11
+  const int role = wave >> 2, wr = wave & 3;                      // 0, 1: consumer sets; 2: producers
+  PP_TRACE_INIT();
+
+  // ---- this workgroup's items: each XCD walks a contiguous range of (tile, column block) pairs, its workgroups
+  // striding through it (ids b and b+8 share an L2: the workgroups that read one input patch for different columns, and
+  // neighbouring patches, stay on one L2 -- speed only)
+  const int nblk = (p.Ncols + BN - 1) / BN;
+  const int total = p.N * p.tilesX * p.tilesY * nblk;
+  const int G = (int)gridDim.x, xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int nx = (G + 7 - xcd) >> 3;                               // workgroups on this XCD
+  const int qq = total >> 3, rr = total & 7;
+  const int xstart = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq;
+  const int xcount = qq + (xcd < rr ? 1 : 0);
+  const int n_items = seq < xcount ? (xcount - seq + nx - 1) / nx : 0;
+  const int nch = p.Cin / CK;
+  const int K = n_items * nch;                                     // steps of this workgroup
+  auto decode = [&](int j) __attribute__((always_inline)) {
+    Item it;
+    const int work = xstart + seq + j * nx;
+    it.tile_id = work / nblk;
+    it.n0 = (work - it.tile_id * nblk) * BN;
+    int t = it.tile_id;
+    const int tx = t % p.tilesX; t /= p.tilesX;
+    const int ty = t % p.tilesY;
+    it.img = t / p.tilesY;
+    it.oy0 = ty * TH; it.ox0 = tx * TW;
+    return it;
+  };
+
+  const int Cin8 = p.Cin >> 3;
+  const float w_scale = p.wp[(long)TAPS * Cin8 * 2 * p.Ncols * 4];     // trailer of the packed weights
+  const bool bnin = p.inSc != nullptr;
+  const int Cinp = (p.Cin + 3) & ~3;
+  if (bnin)
+    for (int i = tid; i < p.Cin; i += THREADS) { lds_sc[i] = p.inSc[i]; lds_sc[Cinp + i] = p.inSh[i]; }
+  // per-column epilogue parameters live in LDS for the whole launch: a global load inside an epilogue slice would make the
+  // slice wait (vmcnt counts stores too) for the previous slice's stores to drain
+  for (int i = tid; i < p.Ncols; i += THREADS) {
+    lds_ep[i] = p.bias ? p.bias[i] : 0.f;
+    lds_ep[EP_COLS + i] = p.scale ? p.scale[i] : 1.f;
+    lds_ep[2 * EP_COLS + i] = p.shift ? p.shift[i] : 0.f;
+  }
+  const float in_scale = (p.inScale ? *p.inScale : 1.f) * dc_block_guard_scale(p.inAbound, p.Cin, tmp, p.inAboundLd);
+  if (p.inAbound == nullptr) __syncthreads();                 // (the guard's own barriers publish the tables otherwise)
+
+  if (role == 2) {
+    // =========================== producers: HBM -> registers -> fp16 hi/lo operand images ==========================
+    const int t = tid & 255;
+    const __amdgpu_buffer_rsrc_t rsrcB = dc_make_rsrc(p.wp, (unsigned)(TAPS * Cin8 * 2 * p.Ncols) * 16u);
+    constexpr int A_STEP = 256 / G4, B_STEP = 256 / BN;
+    const int a_g = t % G4, a_pix0 = t / G4;
+    const int b_j = t % BN, b_row0 = t / BN;
+    int a_rel[NA], b_rel[NBV];                 // tile-independent parts of the byte offsets
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int pix = a_pix0 + it * A_STEP;
+      const int r = pix / TWI, c = pix - r * TWI;
+      a_rel[it] = ((r * p.Win + c) * p.Cin + 4 * a_g) * 4;
+    }
+#pragma unroll
+    for (int it = 0; it < NBV; ++it) {
+      const int row = b_row0 + it * B_STEP;    // (tap, g8, hl)
+      const int tap = row / (2 * G8), g8 = (row >> 1) % G8, hl = row & 1;
+      b_rel[it] = row < BROWS ? (((tap * Cin8 + g8) * 2 + hl) * p.Ncols + b_j) * 16 : -1;
+    }
+    unsigned a_voff[NA], b_voff[NBV];
+    __amdgpu_buffer_rsrc_t rsrcA = rsrcB;
+    auto setup_item = [&](int j) __attribute__((always_inline)) {
+      const Item it = decode(j);
+      rsrcA = dc_make_rsrc(p.in + (long)it.img * p.Hin * p.Win * p.Cin, (unsigned)(p.Hin * p.Win * p.Cin) * 4u);
+      const int iy0 = it.oy0 - 1, ix0 = it.ox0 - 1;
+      const int base = (iy0 * p.Win + ix0) * p.Cin * 4;
+      const bool inside = iy0 >= 0 && ix0 >= 0 && iy0 + THI <= p.Hin && ix0 + TWI <= p.Win;     // wave-uniform
+#pragma unroll
+      for (int k = 0; k < NA; ++k) {
+        const int pix = a_pix0 + k * A_STEP;
+        bool ok = pix < NPIXH;
+        if (!inside) {
+          const int r = pix / TWI, c = pix - r * TWI;
+          const int y = iy0 + r, x = ix0 + c;
+          ok = ok && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+        }
+        a_voff[k] = ok ? (unsigned)(base + a_rel[k]) : OOB;
+      }
+      const bool col_ok = (it.n0 + b_j) < p.Ncols;
+#pragma unroll
+      for (int k = 0; k < NBV; ++k) b_voff[k] = (b_rel[k] >= 0 && col_ok) ? (unsigned)(b_rel[k] + it.n0 * 16) : OOB;
+    };
+    f32x4 ra[NA];
+    u32x4 rb[NBV];
+    auto load_chunk = [&](int c0) __attribute__((always_inline)) {
+      const unsigned a_add = (unsigned)c0 * 4u, b_add = (unsigned)(c0 >> 3) * 2u * (unsigned)p.Ncols * 16u;
+#pragma unroll
+      for (int k = 0; k < NA; ++k)
+        ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, a_voff[k], (int)a_add, 0));
+#pragma unroll
+      for (int k = 0; k < NBV; ++k) rb[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, b_voff[k], (int)b_add, 0);
+    };
+    auto stage = [&](char* st, int c0) __attribute__((always_inline)) {
+      u32x4* ldsB = reinterpret_cast<u32x4*>(st) + A_SLOTS;
+      f32x4 csc = {1.f, 1.f, 1.f, 1.f}, csh = {0.f, 0.f, 0.f, 0.f};
+      if (bnin) {
+        csc = *reinterpret_cast<const f32x4*>(lds_sc + c0 + 4 * a_g);
+        csh = *reinterpret_cast<const f32x4*>(lds_sc + Cinp + c0 + 4 * a_g);
+      }
+#pragma unroll
+      for (int k = 0; k < NA; ++k) {
+        const int pix = a_pix0 + k * A_STEP;
+        if (pix < NPIXH) {
+          f32x4 v = ra[k];
+          if (bnin) {
+            const bool live = !(a_voff[k] >> 31);              // zero padding stays zero
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y = fmaxf(__builtin_fmaf(v[e], csc[e], csh[e]), 0.f);
+              v[e] = live ? y : 0.f;
+            }
+          }
+          u32x2 hi, lo;
+          split(v, in_scale, hi, lo);
+          char* base = st + ((a_g >> 1) * PS + pix) * 16 + (a_g & 1) * 8;
+          *reinterpret_cast<u32x2*>(base) = hi;
+          *reinterpret_cast<u32x2*>(base + G8 * PS * 16) = lo;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NBV; ++k) {
+        const int row = b_row0 + k * B_STEP;
+        if (row < BROWS) ldsB[row * BN + b_j] = rb[k];
+      }
+    };
+    // (item, chunk) of the next load
+    int jl = 0, cl = 0;
+    auto advance = [&]() __attribute__((always_inline)) { if (++cl == nch) { cl = 0; ++jl; } };
+    if (K > 0) {
+      setup_item(0);
+      load_chunk(0);
+      advance();
+      stage(smem, 0);                                           // step 0 -> stage 0
+      if (K > 1) {
+        if (cl == 0) setup_item(jl);
+        load_chunk(cl * CK);
+      }
+    }
+    PP_TRACE();
+    __syncthreads();                                            // barrier 0: stage 0 is ready
+    PP_TRACE();
+    int cs = cl;                                                // chunk of the step held in the registers (step k+1)
+    for (int k = 0; k < K; ++k) {
+      if (k + 1 < K) {
+        stage(smem + ((k + 1) & 1) * STAGE_BYTES, cs * CK);     // uses the a_voff of that step's item (padding mask)
+        advance();
+        if (k + 2 < K) {
+          if (cl == 0) setup_item(jl);
+          load_chunk(cl * CK);
+        }
+        cs = cl;
+      }
+      PP_TRACE();
+      __syncthreads();
+      PP_TRACE();
+    }
+#pragma unroll 1
+    for (int c = 0; c < 5; ++c) __syncthreads();                // the consumers' tail: 4 epilogue slices + the merge
+    return;
+  }
+
+  // ================================ consumers: LDS fragments -> MFMA, sliced epilogue ================================
+  const int li = lane & 31, h = lane >> 5;
+  const int wave_m = wr;
+  DcMoments* red = red_all + role * RED_ENTRIES;
+  int a_base[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int mblk = wave_m * MB + mb;
+    const int row = mblk * RPM + li / TW, col = li % TW;
+    a_base[mb] = h * PS + row * TWI + col;                      // g8 = 2*ks + h for k-step ks
+  }
+  const int b_base = (h * 2) * BN + li;
+
+  f32x16 acc[MB][NB];
+  const float out_scale = 1.f / (in_scale * w_scale);
+  const int ld = (int)p.outLd;
+  const int sy = p.Wout * ld, sx = ld;
+  Item cur = {0, 0, 0, 0, 0}, pend = {0, 0, 0, 0, 0};
+  bool pending = false;
+
+  auto mfma_block = [&](const char* st) __attribute__((always_inline)) {
+    const u32x4* ldsA = reinterpret_cast<const u32x4*>(st);
+    const u32x4* ldsB = ldsA + A_SLOTS;
+    f16x8 ah[2][MB], al[2][MB], bh[2][NB], bl[2][NB];
+    auto fetch = [&](int tap, int buf) __attribute__((always_inline)) {
+      const int toff = (tap / KW) * TWI + (tap % KW);
+      const int boff = (tap * G8) * 2 * BN;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        ah[buf][mb] = __builtin_bit_cast(f16x8, ldsA[a_base[mb] + toff]);
+        al[buf][mb] = __builtin_bit_cast(f16x8, ldsA[a_base[mb] + toff + G8 * PS]);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        bh[buf][nb] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + nb * 32]);
+        bl[buf][nb] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + BN + nb * 32]);
+      }
+    };
+    fetch(0, 0);
+    // Hand-ordered schedule (every statement pinned by sched_barrier): the 8 fragment reads of tap t+1 go one per gap
+    // between the first 8 MFMAs of tap t, in the order tap t+1 will use them -- a burst of 8 b128 reads in front of the
+    // group kept the wave from issuing MFMAs for ~50 cycles per tap and the pipe ran dry.
+#define PP_SB() __builtin_amdgcn_sched_barrier(0)
+#define PP_MFMA(mb, nb, A, B) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[b][mb], B[b][nb], acc[mb][nb], 0, 0, 0); PP_SB()
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int b = tap & 1, nx = b ^ 1;
+      const bool more = tap + 1 < TAPS;
+      const int toff = ((tap + 1) / KW) * TWI + ((tap + 1) % KW);
+      const int boff = ((tap + 1) * G8) * 2 * BN;
+      PP_SB();
+      PP_MFMA(0, 0, al, bh);
+      if (more) { al[nx][0] = __builtin_bit_cast(f16x8, ldsA[a_base[0] + toff + G8 * PS]); PP_SB(); }
+      PP_MFMA(0, 0, ah, bl);
+      if (more) { bh[nx][0] = __builtin_bit_cast(f16x8, ldsB[b_base + boff]); PP_SB(); }
+      PP_MFMA(0, 0, ah, bh);
+      if (more) { ah[nx][0] = __builtin_bit_cast(f16x8, ldsA[a_base[0] + toff]); PP_SB(); }
+      PP_MFMA(0, 1, al, bh);
+      if (more) { bl[nx][0] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + BN]); PP_SB(); }
+      PP_MFMA(0, 1, ah, bl);
+      if (more) { bh[nx][1] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + 32]); PP_SB(); }
+      PP_MFMA(0, 1, ah, bh);
+      if (more) { bl[nx][1] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + BN + 32]); PP_SB(); }
+      PP_MFMA(1, 0, al, bh);
+      if (more) { al[nx][1] = __builtin_bit_cast(f16x8, ldsA[a_base[1] + toff + G8 * PS]); PP_SB(); }
+      PP_MFMA(1, 0, ah, bl);
+      if (more) { ah[nx][1] = __builtin_bit_cast(f16x8, ldsA[a_base[1] + toff]); PP_SB(); }
+      PP_MFMA(1, 0, ah, bh);
+      PP_MFMA(1, 1, al, bh);
+      PP_MFMA(1, 1, ah, bl);
+      PP_MFMA(1, 1, ah, bh);
+    }
+#undef PP_MFMA
+#undef PP_SB
+  };
+
+  // One 32x32 accumulator block (mb, nb) of the pending tile per slice: bias, BatchNorm partials (mode 1), inference flag
+  // (mode 2), stores.  Slices run in the order (nb 0: mb 0, 1), (nb 1: mb 0, 1); the per-column shifted sums of a column
+  // block live in four registers across its two slices and go to LDS after the second; the cross-wave merge of the tile's
+  // partials happens one step later (merge_pending), whatever that step is for this set.
+  const int mode = p.outAbsmax ? 2 : (p.stats ? 1 : 0);          // wave-uniform
+  float e_s1 = 0.f, e_s2 = 0.f, e_cnt = 0.f, e_K = 0.f;
+  auto epi_values = [&](auto nb_tag, auto mb_tag, auto interior_tag, auto mode_tag) __attribute__((always_inline)) {
+    constexpr int nb = decltype(nb_tag)::value;
+    constexpr int mb = decltype(mb_tag)::value;
+    constexpr bool INT = decltype(interior_tag)::value;
+    constexpr int MODE = decltype(mode_tag)::value;                 // border tiles (!INT): MODE == 3, resolved at run time
+    const bool m_stats = MODE == 1 || (MODE == 3 && mode == 1), m_track = MODE == 2 || (MODE == 3 && mode == 2);
+    const long out_img_floats = (long)p.Hout * p.Wout * p.outLd;
+    const __amdgpu_buffer_rsrc_t rsrcO = dc_make_rsrc(p.out + (long)pend.img * out_img_floats, (unsigned)(out_img_floats * 4));
+    const int n = pend.n0 + nb * 32 + li;
+    const bool n_ok = INT || n < p.Ncols;
+    const int nl = n_ok ? n : 0;
+    const float bv = lds_ep[nl], sc = lds_ep[EP_COLS + nl], sh = lds_ep[2 * EP_COLS + nl];
+    if constexpr (mb == 0) {
+      e_K = __builtin_fmaf(acc[0][nb][0], out_scale, bv);      // shift of this lane's sums: its first value
+      e_s1 = 0.f; e_s2 = 0.f; e_cnt = 0.f;
+    }
+    float amax = 0.f;
+    const int mblk = wave_m * MB + mb;
+    const int oyb = pend.oy0 + mblk * RPM, oxb = pend.ox0 + 4 * h;
+    const unsigned base = (unsigned)((oyb * sy + oxb * sx + n) * 4);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mr = (r & 3) + 8 * (r >> 2);
+      const int rowc = mr / TW, colc = mr % TW;
+      float v = __builtin_fmaf(acc[mb][nb][r], out_scale, bv);
+      const float d = v - e_K;
+      if constexpr (INT) {
+        if constexpr (MODE == 1) { e_s1 += d; e_s2 = __builtin_fmaf(d, d, e_s2); }
+        if (p.scale) v = v * sc + sh;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if constexpr (MODE == 2) amax = fmaxf(amax, fabsf(v));
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, base, (rowc * sy + colc * sx) * 4, 0);
+      } else {
+        const bool ok = n_ok && (oyb + rowc) < p.Hout && (oxb + colc) < p.Wout;
+        if (m_stats) { e_s1 += ok ? d : 0.f; e_s2 += ok ? d * d : 0.f; e_cnt += ok ? 1.f : 0.f; }
+        if (p.scale) v = v * sc + sh;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (m_track) amax = fmaxf(amax, ok ? fabsf(v) : 0.f);
+        const unsigned off = ok ? base + (unsigned)((rowc * sy + colc * sx) * 4) : OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, off, 0, 0);
+      }
+    }
+    if (m_stats && mb == MB - 1) {
+      DcMoments m;
+      if constexpr (INT) {
+        constexpr float NL = (float)(16 * MB);
+        const float ms = e_s1 * (1.f / NL);
+        m.n = NL; m.mean = e_K + ms; m.m2 = fmaxf(__builtin_fmaf(-e_s1, ms, e_s2), 0.f);
+        const float om = __shfl_xor(m.mean, 32), o2 = __shfl_xor(m.m2, 32), dd = om - m.mean;
+        m.m2 = m.m2 + o2 + dd * dd * (0.5f * NL);
+        m.mean = __builtin_fmaf(dd, 0.5f, m.mean);
+        m.n = 2.f * NL;
+      } else {
+        m = dc_moments_from_shifted(e_cnt, e_K, e_s1, e_s2);
+        DcMoments o;
+        o.n = __shfl_xor(m.n, 32); o.mean = __shfl_xor(m.mean, 32); o.m2 = __shfl_xor(m.m2, 32);
+        m = dc_moments_merge(m, o);
+      }
+      if (h == 0) red[(wave_m * NB + nb) * 32 + li] = m;
+    }
+    if (m_track) {
+      if (!(amax <= DC_F16_SAFE_MAX)) p.outAbsmax[0] = 1.f;
+    }
+  };
+  bool merge_pending = false;
+  Item mitem = {0, 0, 0, 0, 0};
+  auto epi_merge = [&]() __attribute__((always_inline)) {      // the red[] entries of both column blocks are complete
+    if (mode == 1) {
+      const int ts = tid & 255;                                 // thread within the consumer set
+      if (ts < NB * 32) {
+        const int nb = ts / 32, l = ts % 32;
+        DcMoments m = red[nb * 32 + l];
+#pragma unroll
+        for (int wm = 1; wm < WAVES_M; ++wm) m = dc_moments_merge(m, red[(wm * NB + nb) * 32 + l]);
+        const int n = mitem.n0 + nb * 32 + l;
+        if (n < p.Ncols) dc_moments_store(p.stats + ((long)mitem.tile_id * p.Ncols + n) * 2, m);
+      }
+    }
+    merge_pending = false;
+  };
+  auto epi_slice = [&](int c) __attribute__((always_inline)) {
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    using T2 = std::integral_constant<int, 2>;
+    using T3 = std::integral_constant<int, 3>;
+    if (c >= 4) return;
+    const bool interior = (pend.oy0 + TH <= p.Hout) && (pend.ox0 + TW <= p.Wout) && (pend.n0 + BN <= p.Ncols);
+    auto run = [&](auto nb_tag, auto mb_tag) __attribute__((always_inline)) {
+      if (interior) {
+        if (mode == 0) epi_values(nb_tag, mb_tag, std::true_type{}, T0{});
+        else if (mode == 1) epi_values(nb_tag, mb_tag, std::true_type{}, T1{});
+        else epi_values(nb_tag, mb_tag, std::true_type{}, T2{});
+      } else {
+        epi_values(nb_tag, mb_tag, std::false_type{}, T3{});
+      }
+    };
+    if (c == 0) run(T0{}, T0{});
+    else if (c == 1) run(T0{}, T1{});
+    else if (c == 2) run(T1{}, T0{});
+    else {
+      run(T1{}, T1{});
+      pending = false;
+      merge_pending = true;
+      mitem = pend;
+    }
+  };
+
+  PP_TRACE();
+  __syncthreads();                                              // barrier 0
+  PP_TRACE();
+  int j = 0, c = 0;
+  for (int k = 0; k < K + 5; ++k) {                             // + 5: the last tile's 4 epilogue slices and its merge
+    if (merge_pending) epi_merge();                             // partials written one step ago (a barrier in between)
+    if (k < K && (j & 1) == role) {
+      if (c == 0) {
+        cur = decode(j);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+      }
+      __builtin_amdgcn_s_setprio(3);                            // the wave that feeds the matrix pipe goes first
+      mfma_block(smem + (k & 1) * STAGE_BYTES);
+      __builtin_amdgcn_s_setprio(0);
+      if (c == nch - 1) { pend = cur; pending = true; }
+    } else if (pending) {
+      epi_slice(c);
+    }
+    if (++c == nch) { c = 0; ++j; }
+    PP_TRACE();
+    __syncthreads();
+    PP_TRACE();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host side: the shape test and the launch (called from igemm_f16x3.hip's conv3x3 dispatch).
+bool dc_igemm_pp_serves(const IgemmParams& p) {
+  // DC_IGEMM_PP: 0 off, 1 (default) every served launch, 2 forward launches only (a data-gradient launch runs beside the
+  // weight-gradient kernel of the side stream, and this kernel's 138 KB of LDS cannot share a CU with that one's 87 KB:
+  // measured, serving the data gradients too is still the faster setting: 788 vs 780 vs 774 images/s for 1 / 2 / 0)
+  static const int knob = getenv("DC_IGEMM_PP") ? atoi(getenv("DC_IGEMM_PP")) : 1;
+  const bool enabled = knob == 1 || (knob == 2 && p.inScale == nullptr);
+  const long total = (long)p.N * dc_cdiv(p.Wout, pp::TW) * dc_cdiv(p.Hout, pp::TH) * dc_cdiv(p.Ncols, pp::BN);
+  return enabled && p.Wout > 16 && p.Ncols > 32 && p.Cin % pp::CK == 0 && p.Cin >= 4 * pp::CK && p.scatterCo == 0 &&
+         !(p.outAbsmax && p.outAbsmaxLd >= 0) && p.Cin <= 1024 && p.Ncols <= pp::EP_COLS && total >= 8;
+}
+
+int dc_igemm_pp_launch(IgemmParams p, hipStream_t st, const char* name) {
+  static DcLdsAttr lds_attr;
+  const int lds_max = pp::FIXED_LDS + pp::TABLE_BYTES + 3 * pp::EP_COLS * 4;
+  if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(igemm_pp_kernel), lds_max, name)) return rc;
+  p.tilesX = dc_cdiv(p.Wout, pp::TW);
+  p.tilesY = dc_cdiv(p.Hout, pp::TH);
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    hipError_t e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    DC_REQUIRE(e == hipSuccess && n > 0, DC_EHIP, "%s: hipDeviceGetAttribute: %s", name, hipGetErrorString(e));
+    cus[dev] = n;
+  }
+  const int total = p.N * p.tilesX * p.tilesY * dc_cdiv(p.Ncols, pp::BN);
+  const int grid = total < cus[dev] ? total : cus[dev];
+  const int lds = lds_max;
+  hipLaunchKernelGGL(igemm_pp_kernel, dim3((unsigned)grid), dim3(pp::THREADS), lds, st, p);
+  DC_CHECK_LAUNCH(name);
+  return DC_OK;
+}

@@ -14,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, 'deep_calcium_amd', 'csrc')
 LIB = os.path.join(ROOT, 'deep_calcium_amd', 'lib', 'libdcunet_trace.so')
-srcs = ['common.cpp', 'igemm_conv.hip', 'igemm_f16x3.hip', 'wgrad.hip', 'wgrad_f16x3.hip', 'conv_c1.hip', 'elementwise.hip']
+os.environ['DC_LIB_PATH'] = LIB
+os.environ.setdefault('DC_IGEMM_PP', '0')              # this script traces the 256-thread kernel
+from deep_calcium_amd._build import SOURCES as srcs    # noqa: E402
 if not os.path.exists(LIB) or any(os.path.getmtime(os.path.join(CSRC, f)) > os.path.getmtime(LIB) for f in os.listdir(CSRC)):
     cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DDC_IGEMM_TRACE', '-o', LIB]
     for f in srcs:
