@@ -38,26 +38,33 @@ extern "C" int dc_debug_set_pp_trace(unsigned long long* p) {
 #endif
 
 namespace pp {
-constexpr int KW = 3, TAPS = 9, TW = 32, WAVES_M = 4, MB = 2, NB = 2, CK = 16;
-constexpr int RPM = 32 / TW, TH = WAVES_M * MB * RPM, BN = NB * 32;
-constexpr int THI = TH + 2, TWI = TW + 2, NPIXH = THI * TWI;
-constexpr int PS = ((NPIXH + 5) / 8) * 8 + 2;
+constexpr int KW = 3, TAPS = 9, TW = 32, WAVES_M = 4, CK = 16;
 constexpr int G4 = CK / 4, G8 = CK / 8;
-constexpr int NA = (NPIXH * G4 + 255) / 256;
-constexpr int BROWS = TAPS * G8 * 2;
-constexpr int NBV = (BROWS * BN + 255) / 256;
-constexpr int A_SLOTS = 2 * G8 * PS;
-constexpr int STAGE_SLOTS = A_SLOTS + BROWS * BN;
-constexpr int STAGE_BYTES = STAGE_SLOTS * 16;
-constexpr int RED_ENTRIES = WAVES_M * NB * 32;                      // per consumer set
-constexpr int RED_BYTES = 2 * RED_ENTRIES * (int)sizeof(DcMoments);
 constexpr int TMP_BYTES = 64;
-constexpr int FIXED_LDS = 2 * STAGE_BYTES + RED_BYTES + TMP_BYTES;
 constexpr int TABLE_BYTES = 8 * 1024;          // BN-on-load table: 2 x Cin floats, Cin <= 1024
 constexpr int EP_COLS = 512;                   // epilogue parameter table: 3 x Ncols floats, Ncols <= 512
 constexpr int THREADS = 768;
 constexpr unsigned OOB = 0x80000000u;
-static_assert(256 % BN == 0 && NB == 2 && MB == 2, "staging / epilogue slicing assume 64 columns in two 32-column blocks");
+// The two tile shapes of the 256-thread kernel (same BatchNorm-partial tile counts): <MB 2, NB 2> = 8 x 32 pixels x 64
+// columns, <MB 4, NB 1> = 16 x 32 pixels x 32 columns (layers with <= 32 output columns: the 512^2 layers).
+template <int MB_, int NB_>
+struct Cfg {
+  static constexpr int MB = MB_, NB = NB_;
+  static constexpr int RPM = 32 / TW, TH = WAVES_M * MB * RPM, BN = NB * 32;
+  static constexpr int THI = TH + 2, TWI = TW + 2, NPIXH = THI * TWI;
+  static constexpr int PS = ((NPIXH + 5) / 8) * 8 + 2;
+  static constexpr int NA = (NPIXH * G4 + 255) / 256;
+  static constexpr int BROWS = TAPS * G8 * 2;
+  static constexpr int NBV = (BROWS * BN + 255) / 256;
+  static constexpr int A_SLOTS = 2 * G8 * PS;
+  static constexpr int STAGE_SLOTS = A_SLOTS + BROWS * BN;
+  static constexpr int STAGE_BYTES = STAGE_SLOTS * 16;
+  static constexpr int RED_ENTRIES = WAVES_M * NB * 32;                      // per consumer set
+  static constexpr int RED_BYTES = 2 * RED_ENTRIES * (int)sizeof(DcMoments);
+  static constexpr int FIXED_LDS = 2 * STAGE_BYTES + RED_BYTES + TMP_BYTES;
+  static constexpr int NBLK = MB * NB;                                       // 32x32 accumulator blocks per wave
+  static_assert(256 % BN == 0 && NBLK == 4 && (MB == 2 || MB == 4), "two shapes: 2x2 and 4x1 blocks per wave");
+};
 
 // hi = fp16(x*s), lo = fp16(x*s - hi): two v_fma_mix per element (igemm_f16x3.hip split_f16)
 __device__ __forceinline__ void split(const f32x4 v, float s, u32x2& hi, u32x2& lo) {
@@ -81,8 +88,13 @@ struct Item {          // one output tile x column block (wave-uniform)
 };
 }  // namespace pp
 
+template <int MB_, int NB_>
 __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p) {
   using namespace pp;
+  using C = Cfg<MB_, NB_>;
+  constexpr int MB = C::MB, NB = C::NB, RPM = C::RPM, TH = C::TH, BN = C::BN, THI = C::THI, TWI = C::TWI, NPIXH = C::NPIXH;
+  constexpr int PS = C::PS, NA = C::NA, BROWS = C::BROWS, NBV = C::NBV, A_SLOTS = C::A_SLOTS, STAGE_BYTES = C::STAGE_BYTES;
+  constexpr int RED_ENTRIES = C::RED_ENTRIES, RED_BYTES = C::RED_BYTES, FIXED_LDS = C::FIXED_LDS, NBLK = C::NBLK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   DcMoments* red_all = reinterpret_cast<DcMoments*>(smem + 2 * STAGE_BYTES);
   float* tmp = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES + RED_BYTES);
@@ -302,6 +314,8 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
     // group kept the wave from issuing MFMAs for ~50 cycles per tap and the pipe ran dry.
 #define PP_SB() __builtin_amdgcn_sched_barrier(0)
 #define PP_MFMA(mb, nb, A, B) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[b][mb], B[b][nb], acc[mb][nb], 0, 0, 0); PP_SB()
+#define PP_RA(X, mb, off) if (more) { X[nx][mb] = __builtin_bit_cast(f16x8, ldsA[a_base[mb] + toff + (off)]); PP_SB(); }
+#define PP_RB(X, nb, off) if (more) { X[nx][nb] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + (off)]); PP_SB(); }
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int b = tap & 1, nx = b ^ 1;
@@ -309,27 +323,36 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
       const int toff = ((tap + 1) / KW) * TWI + ((tap + 1) % KW);
       const int boff = ((tap + 1) * G8) * 2 * BN;
       PP_SB();
-      PP_MFMA(0, 0, al, bh);
-      if (more) { al[nx][0] = __builtin_bit_cast(f16x8, ldsA[a_base[0] + toff + G8 * PS]); PP_SB(); }
-      PP_MFMA(0, 0, ah, bl);
-      if (more) { bh[nx][0] = __builtin_bit_cast(f16x8, ldsB[b_base + boff]); PP_SB(); }
-      PP_MFMA(0, 0, ah, bh);
-      if (more) { ah[nx][0] = __builtin_bit_cast(f16x8, ldsA[a_base[0] + toff]); PP_SB(); }
-      PP_MFMA(0, 1, al, bh);
-      if (more) { bl[nx][0] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + BN]); PP_SB(); }
-      PP_MFMA(0, 1, ah, bl);
-      if (more) { bh[nx][1] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + 32]); PP_SB(); }
-      PP_MFMA(0, 1, ah, bh);
-      if (more) { bl[nx][1] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + BN + 32]); PP_SB(); }
-      PP_MFMA(1, 0, al, bh);
-      if (more) { al[nx][1] = __builtin_bit_cast(f16x8, ldsA[a_base[1] + toff + G8 * PS]); PP_SB(); }
-      PP_MFMA(1, 0, ah, bl);
-      if (more) { ah[nx][1] = __builtin_bit_cast(f16x8, ldsA[a_base[1] + toff]); PP_SB(); }
-      PP_MFMA(1, 0, ah, bh);
-      PP_MFMA(1, 1, al, bh);
-      PP_MFMA(1, 1, ah, bl);
-      PP_MFMA(1, 1, ah, bh);
+      if constexpr (MB == 2) {          // 2 x 2 blocks: 8 reads in the first 8 gaps
+        PP_MFMA(0, 0, al, bh); PP_RA(al, 0, G8 * PS);
+        PP_MFMA(0, 0, ah, bl); PP_RB(bh, 0, 0);
+        PP_MFMA(0, 0, ah, bh); PP_RA(ah, 0, 0);
+        PP_MFMA(0, 1, al, bh); PP_RB(bl, 0, BN);
+        PP_MFMA(0, 1, ah, bl); PP_RB(bh, 1, 32);
+        PP_MFMA(0, 1, ah, bh); PP_RB(bl, 1, BN + 32);
+        PP_MFMA(1, 0, al, bh); PP_RA(al, 1, G8 * PS);
+        PP_MFMA(1, 0, ah, bl); PP_RA(ah, 1, 0);
+        PP_MFMA(1, 0, ah, bh);
+        PP_MFMA(1, 1, al, bh);
+        PP_MFMA(1, 1, ah, bl);
+        PP_MFMA(1, 1, ah, bh);
+      } else {                          // 4 x 1 blocks: 10 reads in the first 10 gaps
+        PP_MFMA(0, 0, al, bh); PP_RA(al, 0, G8 * PS);
+        PP_MFMA(0, 0, ah, bl); PP_RB(bh, 0, 0);
+        PP_MFMA(0, 0, ah, bh); PP_RA(ah, 0, 0);
+        PP_MFMA(1, 0, al, bh); PP_RB(bl, 0, BN);
+        PP_MFMA(1, 0, ah, bl); PP_RA(al, 1, G8 * PS);
+        PP_MFMA(1, 0, ah, bh); PP_RA(ah, 1, 0);
+        PP_MFMA(2, 0, al, bh); PP_RA(al, 2, G8 * PS);
+        PP_MFMA(2, 0, ah, bl); PP_RA(ah, 2, 0);
+        PP_MFMA(2, 0, ah, bh); PP_RA(al, 3, G8 * PS);
+        PP_MFMA(3, 0, al, bh); PP_RA(ah, 3, 0);
+        PP_MFMA(3, 0, ah, bl);
+        PP_MFMA(3, 0, ah, bh);
+      }
     }
+#undef PP_RA
+#undef PP_RB
 #undef PP_MFMA
 #undef PP_SB
   };
@@ -420,12 +443,11 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
     }
     merge_pending = false;
   };
-  auto epi_slice = [&](int c) __attribute__((always_inline)) {
+  auto epi_block = [&](int blk) __attribute__((always_inline)) {
     using T0 = std::integral_constant<int, 0>;
     using T1 = std::integral_constant<int, 1>;
     using T2 = std::integral_constant<int, 2>;
     using T3 = std::integral_constant<int, 3>;
-    if (c >= 4) return;
     const bool interior = (pend.oy0 + TH <= p.Hout) && (pend.ox0 + TW <= p.Wout) && (pend.n0 + BN <= p.Ncols);
     auto run = [&](auto nb_tag, auto mb_tag) __attribute__((always_inline)) {
       if (interior) {
@@ -436,15 +458,30 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
         epi_values(nb_tag, mb_tag, std::false_type{}, T3{});
       }
     };
-    if (c == 0) run(T0{}, T0{});
-    else if (c == 1) run(T0{}, T1{});
-    else if (c == 2) run(T1{}, T0{});
-    else {
-      run(T1{}, T1{});
+    // block order: column block major (the shifted sums of a column block live across its MB blocks)
+    if constexpr (MB == 2) {
+      if (blk == 0) run(T0{}, T0{});
+      else if (blk == 1) run(T0{}, T1{});
+      else if (blk == 2) run(T1{}, T0{});
+      else run(T1{}, T1{});
+    } else {
+      if (blk == 0) run(T0{}, T0{});
+      else if (blk == 1) run(T0{}, T1{});
+      else if (blk == 2) run(T0{}, T2{});
+      else run(T0{}, T3{});
+    }
+    if (blk == NBLK - 1) {
       pending = false;
       merge_pending = true;
       mitem = pend;
     }
+  };
+  // the NBLK blocks are spread over the partner's steps: one per step for >= 4 steps per tile, two for 2 or 3
+  const int bps = nch >= NBLK ? 1 : (NBLK + nch - 1) / nch;
+  auto epi_slice = [&](int c) __attribute__((always_inline)) {
+    const int b0 = c * bps;
+    if (b0 < NBLK) epi_block(b0);
+    if (bps > 1 && b0 + 1 < NBLK) epi_block(b0 + 1);
   };
 
   PP_TRACE();
@@ -485,17 +522,24 @@ bool dc_igemm_pp_serves(const IgemmParams& p) {
   // measured, serving the data gradients too is still the faster setting: 788 vs 780 vs 774 images/s for 1 / 2 / 0)
   static const int knob = getenv("DC_IGEMM_PP") ? atoi(getenv("DC_IGEMM_PP")) : 1;
   const bool enabled = knob == 1 || (knob == 2 && p.inScale == nullptr);
-  const long total = (long)p.N * dc_cdiv(p.Wout, pp::TW) * dc_cdiv(p.Hout, pp::TH) * dc_cdiv(p.Ncols, pp::BN);
-  return enabled && p.Wout > 16 && p.Ncols > 32 && p.Cin % pp::CK == 0 && p.Cin >= 4 * pp::CK && p.scatterCo == 0 &&
+  const int th = p.Ncols <= 32 ? 16 : 8, bn = p.Ncols <= 32 ? 32 : 64;
+  const long total = (long)p.N * dc_cdiv(p.Wout, pp::TW) * dc_cdiv(p.Hout, th) * dc_cdiv(p.Ncols, bn);
+  // 2- and 3-step tiles (Cin 32 / 48) take two epilogue blocks per step: with BatchNorm partials that slice is longer than
+  // the partner's MFMA step and the 256-thread kernel stays ahead (309 vs 292 us on 512^2 x 32 -> 32); without them it wins
+  if (p.Cin < 4 * pp::CK && p.stats) return false;
+  return enabled && p.Wout > 16 && p.Cin % pp::CK == 0 && p.Cin >= 2 * pp::CK && p.scatterCo == 0 &&
          !(p.outAbsmax && p.outAbsmaxLd >= 0) && p.Cin <= 1024 && p.Ncols <= pp::EP_COLS && total >= 8;
 }
 
-int dc_igemm_pp_launch(IgemmParams p, hipStream_t st, const char* name) {
+template <int MB_, int NB_>
+static int pp_launch(IgemmParams p, hipStream_t st, const char* name) {
+  using C = pp::Cfg<MB_, NB_>;
+  auto kern = igemm_pp_kernel<MB_, NB_>;
   static DcLdsAttr lds_attr;
-  const int lds_max = pp::FIXED_LDS + pp::TABLE_BYTES + 3 * pp::EP_COLS * 4;
-  if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(igemm_pp_kernel), lds_max, name)) return rc;
+  const int lds = C::FIXED_LDS + pp::TABLE_BYTES + 3 * pp::EP_COLS * 4;
+  if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), lds, name)) return rc;
   p.tilesX = dc_cdiv(p.Wout, pp::TW);
-  p.tilesY = dc_cdiv(p.Hout, pp::TH);
+  p.tilesY = dc_cdiv(p.Hout, C::TH);
   static int cus[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -506,10 +550,14 @@ int dc_igemm_pp_launch(IgemmParams p, hipStream_t st, const char* name) {
     DC_REQUIRE(e == hipSuccess && n > 0, DC_EHIP, "%s: hipDeviceGetAttribute: %s", name, hipGetErrorString(e));
     cus[dev] = n;
   }
-  const int total = p.N * p.tilesX * p.tilesY * dc_cdiv(p.Ncols, pp::BN);
+  const int total = p.N * p.tilesX * p.tilesY * dc_cdiv(p.Ncols, C::BN);
   const int grid = total < cus[dev] ? total : cus[dev];
-  const int lds = lds_max;
-  hipLaunchKernelGGL(igemm_pp_kernel, dim3((unsigned)grid), dim3(pp::THREADS), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(pp::THREADS), lds, st, p);
   DC_CHECK_LAUNCH(name);
   return DC_OK;
+}
+
+// same tile-shape choice as igemm_f16x3.hip's conv3x3 dispatch (and therefore the same BatchNorm-partial tile count)
+int dc_igemm_pp_launch(IgemmParams p, hipStream_t st, const char* name) {
+  return p.Ncols <= 32 ? pp_launch<4, 1>(p, st, name) : pp_launch<2, 2>(p, st, name);
 }

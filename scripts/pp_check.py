@@ -9,7 +9,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SHAPES = [(2, 32, 32, 64, 64), (1, 64, 64, 128, 128), (2, 40, 40, 144, 96), (16, 256, 256, 64, 64), (16, 128, 128, 128, 128),
-          (16, 64, 64, 256, 256), (16, 32, 32, 512, 512), (16, 256, 256, 128, 64), (3, 50, 70, 80, 72)]
+          (16, 64, 64, 256, 256), (16, 32, 32, 512, 512), (16, 256, 256, 128, 64), (3, 50, 70, 80, 72),
+          (16, 512, 512, 32, 32), (16, 512, 512, 64, 32), (16, 256, 256, 32, 64), (2, 40, 40, 32, 32), (1, 64, 64, 48, 24),
+          (2, 72, 40, 48, 96)]
 
 
 def worker(out):
