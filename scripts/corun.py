@@ -40,5 +40,22 @@ for HW, Ci, Co in [(512, 32, 32), (512, 64, 32), (256, 64, 64), (256, 128, 64), 
     fb = lambda: L.dc_bn_bwd_apply(da.data_ptr(), C, z.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(),
                                    None, 1.0, 0, v[4].data_ptr(), v[5].data_ptr(), dzo.data_ptr(), p2.data_ptr(), am.data_ptr(), pixels, C, s2.cuda_stream)
     tw, tb, tt = wall([fw]), wall([fb]), wall([fw, fb])
+    each = {}
+    for order in ('wb', 'bw'):          # one launch each, both dispatch orders: who is starved?
+        rec = []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            ev[0].record(torch.cuda.current_stream()); s1.wait_event(ev[0]); s2.wait_event(ev[0])
+            def one(f, s, a, b):
+                ev[a].record(s); f(); ev[b].record(s)
+            if order == 'wb': one(fw, s1, 1, 2); one(fb, s2, 3, 4)
+            else: one(fb, s2, 3, 4); one(fw, s1, 1, 2)
+            torch.cuda.synchronize()
+            rec.append((ev[1].elapsed_time(ev[2]) * 1e3, ev[3].elapsed_time(ev[4]) * 1e3, max(ev[0].elapsed_time(ev[2]), ev[0].elapsed_time(ev[4])) * 1e3))
+        rec.sort(key=lambda r: r[2])
+        each[order] = rec[len(rec) // 2]
     print('%4d^2 %3d->%3d  wgrad %6.1f us  bn_apply(C=%d) %6.1f us  together %6.1f us  (sum %6.1f, max %6.1f)  hidden %.0f %%' % (
         HW, Ci, Co, tw, C, tb, tt, tw + tb, max(tw, tb), 100 * (tw + tb - tt) / min(tw, tb)))
+    for order in ('wb', 'bw'):
+        print('        launched %s: wgrad %6.1f us, bn_apply %6.1f us, both done after %6.1f us' % ((('wgrad first', 'bn first')[order == 'bw'],) + each[order]))
