@@ -90,7 +90,10 @@ class UNetEngine(object):
         if self.mfma not in ('f16x3', 'f32'):
             raise ValueError("mfma must be 'f16x3' or 'f32', got %r" % self.mfma)
         self.streams = 1 if os.environ.get('DC_STREAMS', '2') == '1' else 2     # 2: weight gradients on a side stream
-        self.wgrad_after_dgrad = os.environ.get('DC_WGRAD_AFTER_DGRAD', '0') == '1'
+        # the weight gradient of a block starts when its data gradient has FINISHED: the role-split conv kernel owns a CU's
+        # whole LDS, so the two cannot share a CU anyway -- ordered this way the data gradient (critical path) never waits
+        # behind 256 persistent weight-gradient workgroups, and those overlap with the next block's BatchNorm passes
+        self.wgrad_after_dgrad = os.environ.get('DC_WGRAD_AFTER_DGRAD', '1') == '1'
         self.dz_bufs = int(os.environ.get('DC_DZ_BUFS', '3'))
         # BN + ReLU on load: activations that only feed a conv / conv-transpose / the head (no dropout, pool or
         # skip) are never written; their consumers take (z, scale, shift) instead.  f16x3 kernels only.
