@@ -457,24 +457,40 @@ class _WGroup(_WNode):
             node = nxt
         return node
 
-    def create_dataset(self, path, data):
+    def create_dataset(self, path, data=None, shape=None, dtype=None):
+        """data given: written with the file.  shape + dtype instead: a DEFERRED dataset -- save() only reserves its
+        (zero-filled) extent behind the metadata and Writer.open_deferred(d) maps it for writing afterwards, so a series
+        of thousands of frames never has to sit in memory."""
         parts = [p for p in path.split('/') if p]
         g = self.create_group('/'.join(parts[:-1])) if len(parts) > 1 else self
-        d = _WDataset(np.asarray(data).copy(order='C'))        # (ascontiguousarray would turn a scalar into shape (1,))
+        if data is None:
+            if shape is None or dtype is None:
+                raise Hdf5Error('create_dataset needs data, or shape and dtype')
+            d = _WDataset(None, tuple(int(x) for x in shape), np.dtype(dtype))
+        else:
+            d = _WDataset(np.asarray(data).copy(order='C'))    # (ascontiguousarray would turn a scalar into shape (1,))
         g.children[parts[-1]] = d
         return d
 
 
 class _WDataset(_WNode):
-    def __init__(self, data):
+    def __init__(self, data, shape=None, dtype=None):
         _WNode.__init__(self)
-        if data.dtype.kind == 'f':
-            data = data.astype('<f%d' % data.dtype.itemsize)
-        elif data.dtype.kind in 'iu':
-            data = data.astype('<%s%d' % (data.dtype.kind, data.dtype.itemsize))
+        dt = data.dtype if data is not None else dtype
+        if dt.kind == 'f':
+            dt = np.dtype('<f%d' % dt.itemsize)
+        elif dt.kind in 'iu':
+            dt = np.dtype('<%s%d' % (dt.kind, dt.itemsize))
         else:
-            raise Hdf5Error('cannot write a dataset of dtype %r' % data.dtype)
-        self.data = data
+            raise Hdf5Error('cannot write a dataset of dtype %r' % dt)
+        self.data = data.astype(dt) if data is not None else None
+        self.shape = self.data.shape if data is not None else shape
+        self.dtype = dt
+        self.file_offset = None         # deferred datasets: byte offset of the extent, known after save()
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
 
 
 class Writer(_WGroup):
@@ -485,17 +501,40 @@ class Writer(_WGroup):
 
     def save(self, path):
         self._buf = bytearray(b'\0' * 96)                  # superblock (v0) is patched in at the end
+        self._deferred = []
         root_ohdr, root_btree, root_heap = self._write_group(self)
+        # deferred extents follow the metadata; their layout messages carried a sentinel address until now
+        self._buf += b'\0' * (-len(self._buf) % 8)
+        eof = len(self._buf)
+        for i, d in enumerate(self._deferred):
+            sentinel = struct.pack('<Q', self._SENTINEL + i)
+            at = bytes(self._buf).find(sentinel)
+            if at < 0 or bytes(self._buf).find(sentinel, at + 1) >= 0:
+                raise Hdf5Error('internal: deferred dataset address not found exactly once')
+            d.file_offset = eof
+            self._buf[at:at + 8] = struct.pack('<Q', eof)
+            eof += d.nbytes + (-d.nbytes % 8)
+        self._path = path
         sb = bytearray()
         sb += SIGNATURE
         sb += struct.pack('<BBBBBBBB', 0, 0, 0, 0, 0, 8, 8, 0)      # versions, sizes of offsets / lengths
         sb += struct.pack('<HHI', self.LEAF_K, self.INTERNAL_K, 0)
-        sb += struct.pack('<QQQQ', 0, UNDEF, len(self._buf), UNDEF)  # base, free-space, end of file, driver info
+        sb += struct.pack('<QQQQ', 0, UNDEF, eof, UNDEF)  # base, free-space, end of file, driver info
         sb += struct.pack('<QQII', 0, root_ohdr, 1, 0) + struct.pack('<QQ', root_btree, root_heap)
         assert len(sb) == 96
         self._buf[:96] = sb
         with open(path, 'wb') as fp:
             fp.write(bytes(self._buf))
+            if eof > len(self._buf):
+                fp.truncate(eof)                            # zero-filled (sparse where the filesystem allows)
+
+    _SENTINEL = 0x5EED5EED00000000
+
+    def open_deferred(self, d):
+        """Writable memory map of a deferred dataset of the file save() just wrote (flush / delete it when done)."""
+        if d.file_offset is None:
+            raise Hdf5Error('open_deferred: save() first')
+        return np.memmap(self._path, dtype=d.dtype, mode='r+', offset=d.file_offset, shape=d.shape)
 
     def _alloc(self, data):
         self._buf += b'\0' * (-len(self._buf) % 8)
@@ -561,11 +600,18 @@ class Writer(_WGroup):
         return self._object_header(msgs), btree_addr, heap_addr
 
     def _write_dataset(self, d):
-        raw = d.data.tobytes()
-        addr = self._alloc(raw) if raw else UNDEF
-        msgs = [(0x0001, _space_msg(d.data.shape)),
-                (0x0003, _dt_msg(d.data.dtype)),
+        if d.data is None:
+            nbytes = d.nbytes
+            addr = self._SENTINEL + len(self._deferred) if nbytes else UNDEF
+            if nbytes:
+                self._deferred.append(d)
+        else:
+            raw = d.data.tobytes()
+            nbytes = len(raw)
+            addr = self._alloc(raw) if raw else UNDEF
+        msgs = [(0x0001, _space_msg(d.shape)),
+                (0x0003, _dt_msg(d.dtype)),
                 (0x0005, struct.pack('<BBBB', 2, 2, 0, 0)),                       # fill value v2: late alloc, never write, undefined
-                (0x0008, struct.pack('<BBQQ', 3, 1, addr, len(raw)))]
+                (0x0008, struct.pack('<BBQQ', 3, 1, addr, nbytes))]
         msgs += [(0x000C, _attr_msg(k, v)) for k, v in d.attrs.items()]
         return self._object_header(msgs)

@@ -1,0 +1,166 @@
+"""Neurofinder directories -> the HDF5 dataset files `UNet2DSummary.fit()/predict()` read.
+
+Restates `nf_load_hdf5` of /root/reference/deepcalcium/datasets/nf.py:37-150 (the data format on the INPUT side of the
+hot path): per dataset `<datasets_dir>/<name>/dataset.hdf5` with
+    attrs['name'], series/raw (n,h,w) int16, series/mean (h,w) float16, series/max (h,w) int16,
+    masks/raw (neurons,h,w) int8, masks/max (h,w) int8           (no masks for '.test' datasets)
+from `<name>/images/*.tiff` (sorted) and `<name>/regions/regions.json`.  What the reference's h5py calls do to the
+values is reproduced, quirks included:
+  * 16-bit frames are stored as int16 through libhdf5's SATURATING conversion (65535 -> 32767), nf.py:113,:121;
+  * series/mean is accumulated IN its float16 storage, one rounding per frame (`ds_mean[...] += img * 1. / n`,
+    nf.py:122), so it is not the float64 mean rounded once -- and overflows to inf above 65504;
+  * series/max starts at zero (nf.py:119), so an all-negative pixel reads 0.
+Pinned by tests/golden/nf_dataset.npz: the reference's own function run on synthetic directories with real h5py.
+The file is written by `hdf5_min.Writer` (h5py is not a dependency); series/raw is streamed frame by frame into a
+reserved extent, as the reference streams it into its dataset.
+Host-side numpy; not part of the GPU path.
+"""
+import json
+import logging
+import os
+from glob import glob
+
+import numpy as np
+
+from . import hdf5_min
+
+NEUROFINDER_NAMES = sorted(
+    ['neurofinder.00.%02d' % i for i in range(12)] +
+    ['neurofinder.01.00', 'neurofinder.01.01', 'neurofinder.02.00', 'neurofinder.02.01', 'neurofinder.03.00',
+     'neurofinder.04.00', 'neurofinder.04.01'] +
+    ['neurofinder.%s.test' % s for s in ('00.00', '00.01', '01.00', '01.01', '02.00', '02.01', '03.00', '04.00',
+                                         '04.01')])
+NAME_TO_URL = dict((n, 'https://s3.amazonaws.com/neuro.datasets/challenges/neurofinder/%s.zip' % n)
+                   for n in NEUROFINDER_NAMES)
+
+
+def _imread(p):
+    from PIL import Image            # what scipy.misc.imread (nf.py:6) was: PIL's reader -> ndarray
+    return np.array(Image.open(p))
+
+
+def _to_int(a, dtype):
+    """libhdf5's integer / float -> integer conversion on store: saturate at the target's limits."""
+    info = np.iinfo(dtype)
+    a = np.asarray(a)
+    if a.dtype.kind == 'f':
+        a = np.trunc(a)
+    return np.clip(a, info.min, info.max).astype(dtype)
+
+
+def _expand_names(names):
+    if isinstance(names, str):
+        low = names.lower()
+        if low == 'all':
+            return list(NEUROFINDER_NAMES)
+        if low == 'all_train':
+            return sorted(n for n in NEUROFINDER_NAMES if '.test' not in n)
+        if low == 'all_test':
+            return sorted(n for n in NEUROFINDER_NAMES if '.test' in n)
+        return names.split(',')
+    return list(names)
+
+
+def _download(name, datasets_dir, logger):
+    """nf.py:70-97: fetch and unpack the challenge zip when the directory is missing."""
+    from zipfile import ZipFile
+    try:
+        import requests
+    except ImportError:
+        raise IOError('%s/%s is missing and `requests` is not importable: unpack %s there' %
+                      (datasets_dir, name, NAME_TO_URL[name]))
+    zip_path = '%s/%s.zip' % (datasets_dir, name)
+    logger.info('Downloading %s.zip.' % name)
+    try:
+        download = requests.get(NAME_TO_URL[name])
+        download.raise_for_status()
+    except Exception as e:
+        raise IOError('%s/%s is missing and %s could not be fetched (%s): unpack the zip there by hand' %
+                      (datasets_dir, name, NAME_TO_URL[name], e))
+    with open(zip_path, 'wb') as fp:
+        fp.write(download.content)
+    with ZipFile(zip_path, 'r') as z:
+        z.extractall(datasets_dir)
+    os.remove(zip_path)
+
+
+def nf_load_hdf5(names, datasets_dir=None):
+    """Returns the list of `dataset.hdf5` paths for `names` ('all' | 'all_train' | 'all_test' | 'a,b' | list), building
+    the files that do not exist yet.  nf.py:37-150."""
+    logger = logging.getLogger('nf_load_hdf5')
+    if datasets_dir is None:
+        datasets_dir = '%s/.deep-calcium-datasets/neurons_nf' % os.path.expanduser('~')
+    dataset_names = _expand_names(names)
+    os.makedirs(datasets_dir, exist_ok=True)
+    for name in dataset_names:
+        url = NAME_TO_URL[name]          # KeyError for an unknown name, as in the reference (:72)
+        del url
+        if os.path.exists('%s/%s' % (datasets_dir, name)):
+            logger.info('%s already downloaded.' % name)
+            continue
+        _download(name, datasets_dir, logger)
+
+    dataset_paths = []
+    for name in dataset_names:
+        ds_path = '%s/%s/dataset.hdf5' % (datasets_dir, name)
+        if not os.path.exists(ds_path):
+            logger.info('Populating %s.' % ds_path)
+            _populate(name, '%s/%s' % (datasets_dir, name), ds_path)
+        dataset_paths.append(ds_path)
+    return dataset_paths
+
+
+def _populate(name, root, ds_path):
+    s_paths = sorted(glob('%s/images/*.tiff' % root))
+    if not s_paths:
+        raise IOError('no TIFF frames under %s/images' % root)
+    i_shape = _imread(s_paths[0]).shape
+    n = len(s_paths)
+    regions = None
+    if '.test' not in name:
+        with open('%s/regions/regions.json' % root) as fp:
+            regions = json.load(fp)
+
+    w = hdf5_min.Writer()
+    w.attrs['name'] = name
+    d_raw = w.create_dataset('series/raw', shape=(n,) + i_shape, dtype='int16')
+    d_mean = w.create_dataset('series/mean', shape=i_shape, dtype='float16')
+    d_max = w.create_dataset('series/max', shape=i_shape, dtype='int16')
+    if regions is not None:
+        d_mraw = w.create_dataset('masks/raw', shape=(len(regions),) + i_shape, dtype='int8')
+        d_mmax = w.create_dataset('masks/max', shape=i_shape, dtype='int8')
+    tmp = ds_path + '.partial'
+    w.save(tmp)
+
+    raw = w.open_deferred(d_raw)
+    mean = np.zeros(i_shape, np.float16)
+    mx = np.zeros(i_shape, np.int16)
+    with np.errstate(over='ignore'):
+        for idx, p in enumerate(s_paths):
+            img = _imread(p)
+            raw[idx] = _to_int(img, np.int16)
+            mean = (mean + (img * 1. / n)).astype(np.float16)          # one float16 rounding per frame
+            mx = _to_int(np.maximum(mx, img), np.int16)
+    raw.flush()
+    del raw
+    for d, a in ((d_mean, mean), (d_max, mx)):
+        m = w.open_deferred(d)
+        m[...] = a
+        m.flush()
+        del m
+    if regions is not None:
+        mraw = w.open_deferred(d_mraw)
+        mmax = np.zeros(i_shape, np.int8)
+        for idx, r in enumerate(regions):
+            msk = np.zeros(i_shape)
+            yy, xx = [c[0] for c in r['coordinates']], [c[1] for c in r['coordinates']]
+            msk[yy, xx] = 1
+            mraw[idx] = _to_int(msk, np.int8)
+            mmax = _to_int(np.maximum(mmax, msk), np.int8)
+        mraw.flush()
+        del mraw
+        m = w.open_deferred(d_mmax)
+        m[...] = mmax
+        m.flush()
+        del m
+    os.replace(tmp, ds_path)         # a crash mid-way leaves no half-written dataset.hdf5 behind

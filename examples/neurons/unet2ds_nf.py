@@ -13,9 +13,10 @@ weights and the Neurofinder data in place, `evaluate neurofinder.00.00` is the o
 README quotes (prec=0.976, reca=1.000, comb=0.988 with TTA; 0.919 / 1.000 / 0.958 without: /root/reference/README.md:30-37)
 -- neither is available offline, so that comparison cannot be run inside the build container.
 
-Datasets: names (`neurofinder.00.00`, comma lists, `all`, `all_train`, `all_test`) resolve to the HDF5 files the
-reference's `nf_load_hdf5` leaves at <datasets_dir>/neurons_nf/<name>/dataset.hdf5 (datasets/nf.py:37-150); paths to
-.hdf5 / .npz dataset files are taken as they are.  Downloading and TIFF preprocessing are out of scope.
+Datasets: names (`neurofinder.00.00`, comma lists, `all`, `all_train`, `all_test`) go through
+`deep_calcium_amd.nf_datasets.nf_load_hdf5` (the reference's datasets/nf.py:37-150): <datasets_dir>/neurons_nf/<name>/
+dataset.hdf5 is built from the unpacked challenge directory (images/*.tiff + regions/regions.json; the zip is fetched
+first when the machine has network access); paths to existing .hdf5 / .npz dataset files are taken as they are.
 Multi-GPU training: launch with `python -m torch.distributed.run --nproc-per-node N examples/neurons/unet2ds_nf.py train ...`.
 """
 from time import time
@@ -30,16 +31,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 
 from deep_calcium_amd import UNet2DSummary, parallel             # noqa: E402
 from deep_calcium_amd.nf_metrics import nf_submit                # noqa: E402
+from deep_calcium_amd.nf_datasets import nf_load_hdf5            # noqa: E402
 
 BASE_DIR = os.path.join(os.path.expanduser('~'), '.deep-calcium')
 DATASETS_DIR = os.path.join(BASE_DIR, 'datasets')
 CHECKPOINTS_DIR = os.path.join(BASE_DIR, 'checkpoints', 'neurons_unet2ds_nf')
-
-NEUROFINDER_NAMES = sorted(
-    ['neurofinder.00.%02d' % i for i in range(12)] +
-    ['neurofinder.01.00', 'neurofinder.01.01', 'neurofinder.02.00', 'neurofinder.02.01', 'neurofinder.03.00',
-     'neurofinder.04.00', 'neurofinder.04.01'] +
-    ['neurofinder.%s.test' % s for s in ('00.00', '00.01', '01.00', '01.01', '02.00', '02.01', '03.00', '04.00', '04.01')])
 
 np.random.seed(865)                 # examples/neurons/unet2ds_nf.py:18: the batch generator's stream
 # :19 tf.set_random_seed(7535) seeds TF's dropout / initialisers; here 7535 is the default `seed` of unet_hip's engine
@@ -48,23 +44,17 @@ logging.basicConfig(level=logging.INFO)
 
 
 def nf_find_hdf5(names, datasets_dir=os.path.join(DATASETS_DIR, 'neurons_nf')):
-    """The path-resolution half of the reference's nf_load_hdf5 (datasets/nf.py:56-66, :111): names -> dataset files."""
-    if isinstance(names, str) and names.lower() == 'all':
-        names = NEUROFINDER_NAMES
-    elif isinstance(names, str) and names.lower() == 'all_train':
-        names = [n for n in NEUROFINDER_NAMES if '.test' not in n]
-    elif isinstance(names, str) and names.lower() == 'all_test':
-        names = [n for n in NEUROFINDER_NAMES if '.test' in n]
-    elif isinstance(names, str):
+    """names -> dataset files.  Explicit paths of existing dataset .hdf5 / .npz files pass through; Neurofinder names go
+    to nf_load_hdf5 (the reference's datasets/nf.py:37-150), which builds `<datasets_dir>/<name>/dataset.hdf5` from the
+    unpacked challenge directory (images/*.tiff, regions/regions.json), fetching the zip first if it can."""
+    if isinstance(names, str) and names.lower() not in ('all', 'all_train', 'all_test'):
         names = names.split(',')
-    paths = []
-    for n in names:
-        p = n if os.path.exists(n) else '%s/%s/dataset.hdf5' % (datasets_dir, n)
-        if not os.path.exists(p):
-            raise SystemExit('dataset %r: %s not found (downloading / TIFF preprocessing is not part of this build: create '
-                             'it with the reference\'s nf_load_hdf5, or pass the path of a dataset .hdf5 / .npz file)' % (n, p))
-        paths.append(p)
-    return paths
+    if not isinstance(names, str) and all(os.path.isfile(n) for n in names):
+        return list(names)
+    try:
+        return nf_load_hdf5(names, datasets_dir=datasets_dir)
+    except (IOError, KeyError) as e:
+        raise SystemExit('dataset %r: %s' % (names, e))
 
 
 def training(dataset_name, model_path, checkpoints_dir):
