@@ -34,6 +34,20 @@ NAME_TO_URL = dict((n, 'https://s3.amazonaws.com/neuro.datasets/challenges/neuro
                    for n in NEUROFINDER_NAMES)
 
 
+def default_dirs():
+    """(datasets_dir, checkpoints_dir) as /root/reference/deepcalcium/utils/config.py resolves them: the values of
+    ~/.deep-calcium/deep-calcium.json when that file exists, else ~/.deep-calcium/{datasets,checkpoints}.  Read-only:
+    unlike the reference, importing this module creates nothing."""
+    base = '%s/.deep-calcium' % os.path.expanduser('~')
+    cfg = {'datasets_dir': '%s/datasets' % base, 'checkpoints_dir': '%s/checkpoints' % base}
+    try:
+        with open('%s/deep-calcium.json' % base) as fp:
+            cfg.update(json.load(fp))
+    except (IOError, OSError, ValueError):
+        pass
+    return cfg['datasets_dir'], cfg['checkpoints_dir']
+
+
 def _imread(p):
     from PIL import Image            # what scipy.misc.imread (nf.py:6) was: PIL's reader -> ndarray
     return np.array(Image.open(p))
@@ -89,7 +103,7 @@ def nf_load_hdf5(names, datasets_dir=None):
     the files that do not exist yet.  nf.py:37-150."""
     logger = logging.getLogger('nf_load_hdf5')
     if datasets_dir is None:
-        datasets_dir = '%s/.deep-calcium-datasets/neurons_nf' % os.path.expanduser('~')
+        datasets_dir = '%s/neurons_nf' % default_dirs()[0]         # nf.py:37
     dataset_names = _expand_names(names)
     os.makedirs(datasets_dir, exist_ok=True)
     for name in dataset_names:

@@ -31,11 +31,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 
 from deep_calcium_amd import UNet2DSummary, parallel             # noqa: E402
 from deep_calcium_amd.nf_metrics import nf_submit                # noqa: E402
-from deep_calcium_amd.nf_datasets import nf_load_hdf5            # noqa: E402
+from deep_calcium_amd.nf_datasets import nf_load_hdf5, default_dirs      # noqa: E402
 
-BASE_DIR = os.path.join(os.path.expanduser('~'), '.deep-calcium')
-DATASETS_DIR = os.path.join(BASE_DIR, 'datasets')
-CHECKPOINTS_DIR = os.path.join(BASE_DIR, 'checkpoints', 'neurons_unet2ds_nf')
+DATASETS_DIR, CHECKPOINTS_DIR = default_dirs()                   # ~/.deep-calcium/deep-calcium.json or the defaults
+CHECKPOINTS_DIR = '%s/neurons_unet2ds_nf' % CHECKPOINTS_DIR      # reference :16
 
 np.random.seed(865)                 # examples/neurons/unet2ds_nf.py:18: the batch generator's stream
 # :19 tf.set_random_seed(7535) seeds TF's dropout / initialisers; here 7535 is the default `seed` of unet_hip's engine

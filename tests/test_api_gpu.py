@@ -190,3 +190,46 @@ def test_example_script_evaluate_and_predict(tmp_path):
     sub = json.load(open(os.path.join(cp, 'submission_latest.json')))
     # (an untrained model predicts next to nothing: an empty mask gives the dummy region, a single component gives [])
     assert [s['dataset'] for s in sub] == ['00.00', '01.00'] and all(isinstance(s['regions'], list) for s in sub)
+
+
+def test_example_script_trains_by_name_from_a_neurofinder_directory(tmp_path):
+    """`train neurofinder.00.00` as the reference's README runs it: the unpacked challenge directory (TIFF frames +
+    regions.json) under ~/.deep-calcium/datasets/neurons_nf becomes dataset.hdf5 (nf_load_hdf5), fit() runs the example's
+    10 epochs x 100 steps of 128^2 x 20 with validation, checkpoints and history land in the checkpoint directory."""
+    import json
+    import subprocess
+    import sys
+    from PIL import Image
+    home = str(tmp_path / 'home')
+    name = 'neurofinder.00.00'
+    root = '%s/.deep-calcium/datasets/neurons_nf/%s' % (home, name)
+    os.makedirs(root + '/images')
+    os.makedirs(root + '/regions')
+    rs = np.random.RandomState(11)
+    hw = (512, 512)
+    regions, base = [], rs.randint(200, 400, size=hw)
+    for k in range(60):
+        cy, cx = rs.randint(8, hw[0] - 8), rs.randint(8, hw[1] - 8)
+        coords = [[int(cy + dy), int(cx + dx)] for dy in range(-3, 4) for dx in range(-3, 4) if dy * dy + dx * dx <= 10]
+        regions.append({'coordinates': coords})
+        for y, x in coords:
+            base[y, x] += 600
+    for i in range(6):
+        Image.fromarray((base + rs.randint(0, 60, size=hw)).astype(np.uint16)).save('%s/images/image%05d.tiff' % (root, i))
+    with open(root + '/regions/regions.json', 'w') as fp:
+        json.dump(regions, fp)
+    cp = str(tmp_path / 'cp')
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'neurons', 'unet2ds_nf.py')
+    env = dict(os.environ, HOME=home)
+    r = subprocess.run([sys.executable, script, 'train', name, '-c', cp], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert os.path.exists(root + '/dataset.hdf5')
+    files = os.listdir(cp)
+    assert any(f.endswith('.hdf5') and '_model_' in f for f in files), files
+    hist = [f for f in files if f.endswith('.csv')]
+    assert hist, files
+    rows = open(os.path.join(cp, hist[0])).read().strip().splitlines()
+    assert len(rows) == 11 and 'val_nf_f1_mean' in rows[0] and 'loss' in rows[0]
+    cols = rows[0].split(',')
+    first, last = [dict(zip(cols, r_.split(','))) for r_ in (rows[1], rows[-1])]
+    assert float(last['loss']) < float(first['loss'])          # bright 7-pixel discs on noise: it learns
