@@ -113,6 +113,15 @@ class _Object(object):
 
 class Group(_Object):
     def _links(self):
+        """name -> object header address.  Walked once per group address and kept on the (read-only) File: a Keras model
+        file is ~140 lookups below `model_weights`, each of which used to re-walk the B-trees of every level."""
+        cache = self.f._link_cache
+        links = cache.get(self.addr)
+        if links is None:
+            links = cache[self.addr] = self._read_links()
+        return links
+
+    def _read_links(self):
         links = {}
         for mtype, flags, body in self.msgs:
             if mtype == 0x0011:                             # symbol table: old-style group
@@ -224,11 +233,15 @@ class File(Group):
         self.f = self
         self.root = self
         self._gcol = {}
+        self._link_cache = {}
+        self._obj_cache = {}
         _Object.__init__(self, self, root_addr)
 
     def close(self):
         if hasattr(self.buf, 'close'):
             self._gcol.clear()
+            self._link_cache.clear()
+            self._obj_cache.clear()
             self.buf.close()
 
     def __enter__(self):
@@ -245,10 +258,13 @@ class File(Group):
         return self.buf[a:a + size]
 
     def _open(self, addr):
-        obj = _Object(self, addr)
-        kind = Dataset if any(m[0] == 0x0008 for m in obj.msgs) else Group
-        o = kind.__new__(kind)
-        o.f, o.addr, o.msgs = self, addr, obj.msgs
+        o = self._obj_cache.get(addr)
+        if o is None:
+            obj = _Object(self, addr)
+            kind = Dataset if any(m[0] == 0x0008 for m in obj.msgs) else Group
+            o = kind.__new__(kind)
+            o.f, o.addr, o.msgs = self, addr, obj.msgs
+            self._obj_cache[addr] = o
         return o
 
     def _read_object_header(self, addr):

@@ -82,6 +82,92 @@ def build_layer_table(nfb=32, drp=0.25, upsampling=False):
     return L
 
 
+_PINNED = {}
+
+
+def _pinned(tag, shape, dtype):
+    """Page-locked host buffers outlive engines: predict() builds a new engine per call (it loads a model file, as the
+    reference does) and pinning costs ~9 ms per buffer."""
+    key = (tag, tuple(shape), dtype)
+    t = _PINNED.get(key)
+    if t is None:
+        t = _PINNED[key] = torch.empty(tuple(shape), dtype=dtype).pin_memory()
+    return t
+
+
+class _TtaJob(object):
+    """predict() over several datasets WITHOUT a host synchronisation per dataset: enqueue(i, ...) stages image i in one
+    of two pinned slots, launches gather -> one batch-K forward -> merge/crop/threshold -> D2H of the mask and returns;
+    finish() synchronises once and hands back the masks.  The host reads / pads dataset i+1 while the device works on i.
+    The optimistic fp16 range flag of every forward is kept per dataset; flagged ones (never on trained weights) are
+    redone in measured mode by finish().  augmentations None = the plain forward (K = 1, identity map)."""
+
+    def __init__(self, eng, count, augmentations):
+        self.eng, self.count = eng, int(count)
+        self.aug = list(augmentations) if augmentations is not None else [('identity', lambda a: a, lambda a: a)]
+        K, H, W = len(self.aug), eng.H, eng.W
+        n = H * W
+        dev = eng.device
+        key = ('ttamaps', K, tuple(name for name, _, _ in self.aug))
+        m = eng._bufs.get(key)
+        if m is None:
+            idx = np.arange(n, dtype=np.int32).reshape(1, H, W)
+            fwd = np.stack([np.ascontiguousarray(f(idx)).reshape(-1) for _, f, _ in self.aug])
+            inv = np.stack([np.ascontiguousarray(g(idx)).reshape(-1) for _, _, g in self.aug])
+            if fwd.shape != (K, n) or inv.shape != (K, n):
+                raise ValueError('test-time augmentations must map (N,H,W) to (N,H,W) on a square window')
+            m = eng._bufs[key] = dict(fwd=torch.from_numpy(fwd).to(dev), inv=torch.from_numpy(inv).to(dev),
+                                      x=torch.empty((K, H, W), dtype=torch.float32, device=dev),
+                                      src=[torch.empty(n, dtype=torch.float32, device=dev) for _ in range(2)])
+        self.m = m
+        self.host = [_pinned('tta_img%d' % k, (H, W), torch.float32) for k in range(2)]
+        self.slot_free = [None, None]
+        self.mask = torch.empty((self.count, n), dtype=torch.uint8, device=dev)
+        self.mask_host = _pinned('tta_mask', (max(self.count, 1), n), torch.uint8)
+        self.ovf = torch.zeros(max(self.count, 1), dtype=torch.float32, device=dev)
+        self.jobs = [None] * self.count
+
+    def enqueue(self, i, img, hs, ws, threshold):
+        eng, m = self.eng, self.m
+        K, H, W = len(self.aug), eng.H, eng.W
+        with torch.cuda.device(eng.device):
+            L, st = eng.L, eng._stream()
+            k = i & 1
+            if self.slot_free[k] is not None:
+                self.slot_free[k].synchronize()          # the H2D copy that last read this pinned slot has finished
+            self.host[k].numpy()[...] = img
+            m['src'][k].copy_(self.host[k].view(-1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.slot_free[k] = ev
+            L.dc_gather_maps(_ptr(m['src'][k]), m['fwd'].data_ptr(), _ptr(m['x']), K, H * W, st)
+            p = eng.forward_infer(m['x'])
+            if eng.mfma == 'f16x3' and eng.range_guard and not eng.infer_measured:
+                self.ovf[i:i + 1].copy_(eng._ovf[0:1])
+            L.dc_tta_merge(_ptr(p), m['inv'].data_ptr(), K, H, W, int(hs), int(ws), float(threshold),
+                           self.mask[i].data_ptr(), None, st)
+            self.mask_host[i, :hs * ws].copy_(self.mask[i, :hs * ws], non_blocking=True)
+        self.jobs[i] = (np.array(img, dtype=np.float32, copy=True), int(hs), int(ws), float(threshold))
+
+    def finish(self):
+        eng = self.eng
+        torch.cuda.current_stream(eng.device).synchronize()
+        redo = [i for i, f in enumerate(self.ovf.cpu().numpy()[:self.count]) if f != 0.0 and self.jobs[i] is not None]
+        out = []
+        for i, j in enumerate(self.jobs):
+            if j is None:
+                out.append(None)
+                continue
+            _, hs, ws, _ = j
+            out.append(self.mask_host[i, :hs * ws].numpy().reshape(hs, ws).copy())
+        if redo:                                         # an activation left fp16's range: measured bounds, one by one
+            eng.infer_measured = True
+            for i in redo:
+                img, hs, ws, thr = self.jobs[i]
+                out[i] = eng.predict_tta(img, self.aug, hs, ws, thr)
+        return out
+
+
 class UNetEngine(object):
     def __init__(self, window_shape, nb_filters_base=32, prop_dropout_base=0.25, device=None, seed=7535, mfma=None,
                  upsampling=False, bn_mode=None, conv_kernel_init='he_normal'):
@@ -651,6 +737,10 @@ class UNetEngine(object):
         m['mask_host'][:hs * ws].copy_(m['mask'][:hs * ws], non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
         return m['mask_host'][:hs * ws].numpy().reshape(hs, ws).copy()
+
+    def tta_begin(self, count, augmentations):
+        """Pipelined predict() over `count` datasets: see _TtaJob."""
+        return _TtaJob(self, count, augmentations)
 
     # ---- training ----------------------------------------------------------------------------------------
     def _train_bufs(self, N):

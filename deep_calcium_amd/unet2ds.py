@@ -397,21 +397,20 @@ class UNet2DSummary(object):
         _, hw, ww = model.input_shape
         Mp, names = [], []
         mean_prec = mean_reca = mean_comb = 0.
-        for dsp in dataset_paths:
-            name = self.dataset_name_func(dsp)
+        # Every dataset's forward is ENQUEUED (no host synchronisation per dataset: the summary of dataset i+1 is read
+        # and padded while the device works on i); with augmentation the 8 copies are made on the device, go through
+        # ONE batch-8 forward (inference BatchNorm is per-image) and are inverse-mapped, averaged (float64, table
+        # order), cropped and thresholded there -- without it the same path runs with the identity map alone.
+        job = model.engine.tta_begin(len(dataset_paths), INVERTIBLE_2D_AUGMENTATIONS if augmentation else None)
+        for i, dsp in enumerate(dataset_paths):
+            names.append(self.dataset_name_func(dsp))
             s = self.series_summary_func(dsp)
             hs, ws = s.shape
-            s_batch = np.pad(s, ((0, hw - hs), (0, ww - ws)), mode='reflect')[np.newaxis, :, :]
-            if augmentation:
-                # the 8 augmented copies are made on the device, go through ONE batch-8 forward (inference BatchNorm is
-                # per-image), and are inverse-mapped, averaged (float64, table order), cropped and thresholded there
-                mp = model.engine.predict_tta(s_batch[0].astype(np.float32), INVERTIBLE_2D_AUGMENTATIONS, hs, ws, threshold)
-                Mp.append(mp)
-            else:
-                mp = model.predict(s_batch)[0, :hs, :ws]
-                Mp.append((mp > threshold).astype(np.uint8))
-            mp = Mp[-1]
-            names.append(name)
+            s_pad = np.pad(s, ((0, hw - hs), (0, ww - ws)), mode='reflect')
+            # (:594 compares float32 probabilities with the threshold in float32 when there is no float64 TTA mean)
+            job.enqueue(i, s_pad.astype(np.float32), hs, ws, threshold if augmentation else float(np.float32(threshold)))
+        Mp = job.finish()
+        for dsp, name, mp in zip(dataset_paths, names, Mp):
             if print_scores:
                 m = self.mask_summary_func(dsp)
                 prec, reca, incl, excl, comb = nf_mask_metrics(m, mp.round())
