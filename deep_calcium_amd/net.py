@@ -88,7 +88,8 @@ _PINNED = {}
 def _pinned(tag, shape, dtype):
     """Page-locked host buffers outlive engines: predict() builds a new engine per call (it loads a model file, as the
     reference does) and pinning costs ~9 ms per buffer."""
-    key = (tag, tuple(shape), dtype)
+    import threading
+    key = (tag, tuple(shape), dtype, threading.get_ident())      # one set per calling thread: no sharing between concurrent predict()s
     t = _PINNED.get(key)
     if t is None:
         t = _PINNED[key] = torch.empty(tuple(shape), dtype=dtype).pin_memory()

@@ -233,3 +233,47 @@ def test_example_script_trains_by_name_from_a_neurofinder_directory(tmp_path):
     cols = rows[0].split(',')
     first, last = [dict(zip(cols, r_.split(','))) for r_ in (rows[1], rows[-1])]
     assert float(last['loss']) < float(first['loss'])          # bright 7-pixel discs on noise: it learns
+
+
+@pytest.mark.parametrize('aug', [True, False])
+def test_pipelined_predict_equals_one_by_one(aug):
+    """The enqueue-all-then-synchronise path of predict() (engine.tta_begin) gives, for datasets of different sizes, the
+    masks the per-dataset path gives -- with the 8x table and with the plain forward (identity map); a dataset whose
+    activations leave fp16's range (un-normalised image) is flagged, redone with measured bounds, and the rest are kept."""
+    from deep_calcium_amd.net import UNetEngine
+    from deep_calcium_amd.unet2ds import INVERTIBLE_2D_AUGMENTATIONS
+    from oracle import unet_numpy as on
+    H = W = 64
+    nfb = 8
+    Wt = on.init_weights(nfb, seed=9, randomize_bn=True)
+    rs = np.random.RandomState(4)
+    sizes = [(64, 64), (50, 61), (33, 64), (64, 40), (17, 23)]
+    imgs = []
+    for k, (hs, ws) in enumerate(sizes):
+        s = rs.standard_normal((hs, ws)).astype(np.float32)
+        if k == 2:
+            s *= 3e5                                           # this one overflows the optimistic pass
+        imgs.append(np.pad(s, ((0, H - hs), (0, W - ws)), mode='reflect'))
+    table = INVERTIBLE_2D_AUGMENTATIONS if aug else None
+    eng = UNetEngine((H, W), nb_filters_base=nfb)
+    eng.set_weights(Wt)
+    thr = 0.5
+    job = eng.tta_begin(len(sizes), table)
+    for i, ((hs, ws), im) in enumerate(zip(sizes, imgs)):
+        job.enqueue(i, im, hs, ws, thr)
+    assert not eng.infer_measured
+    got = job.finish()
+    assert eng.infer_measured                                  # dataset 2 raised the flag and was redone
+    ref_eng = UNetEngine((H, W), nb_filters_base=nfb)
+    ref_eng.set_weights(Wt)
+    one = [('identity', lambda a: a, lambda a: a)]
+    for i, ((hs, ws), im) in enumerate(zip(sizes, imgs)):
+        e = UNetEngine((H, W), nb_filters_base=nfb)            # fresh engine: optimistic unless it has to switch
+        e.set_weights(Wt)
+        want = e.predict_tta(im, table if aug else one, hs, ws, thr)
+        assert got[i].shape == (hs, ws) and got[i].dtype == np.uint8
+        assert np.array_equal(got[i], want), i
+        if not aug and i != 2:
+            p = ref_eng.forward_infer_checked(torch.from_numpy(im[None]).cuda()).cpu().numpy()[0, :hs, :ws]
+            assert np.array_equal(got[i], (p > thr).astype(np.uint8))
+    assert eng.tta_begin(0, table).finish() == []
