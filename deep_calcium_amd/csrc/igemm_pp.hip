@@ -22,6 +22,13 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // Step timestamps of sampled workgroups (scripts/igemm_pp_phases.py; compiled out unless -DDC_IGEMM_TRACE): per role the
 // first wave stores s_memtime when its work of a step is done and again when the step's barrier has released it.
+// DC_PP_ABL (debug builds only, scripts/igemm_pp_ablate.py): bit 0 no epilogue work (the compiler then drops the MFMAs
+// too: unusable), bit 1 producers do not split / write LDS, bit 2 consumers read their fragments once per step, bit 3
+// producers do not load, bit 4 two more stamps per consumer step (tile setup done, first fragments landed).  Results are
+// garbage for bits 0-3.
+#ifndef DC_PP_ABL
+#define DC_PP_ABL 0
+#endif
 #ifdef DC_IGEMM_TRACE
 __device__ unsigned long long* g_pp_trace = nullptr;
 extern "C" int dc_debug_set_pp_trace(unsigned long long* p) {
@@ -253,11 +260,11 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
     int cs = cl;                                                // chunk of the step held in the registers (step k+1)
     for (int k = 0; k < K; ++k) {
       if (k + 1 < K) {
-        stage(smem + ((k + 1) & 1) * STAGE_BYTES, cs * CK);     // uses the a_voff of that step's item (padding mask)
+        if (!(DC_PP_ABL & 2)) stage(smem + ((k + 1) & 1) * STAGE_BYTES, cs * CK);     // uses the a_voff of that step's item (padding mask)
         advance();
         if (k + 2 < K) {
           if (cl == 0) setup_item(jl);
-          load_chunk(cl * CK);
+          if (!(DC_PP_ABL & 8)) load_chunk(cl * CK);
         }
         cs = cl;
       }
@@ -309,13 +316,15 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
       }
     };
     fetch(0, 0);
+    if (DC_PP_ABL & 4) fetch(0, 1);
+    if (DC_PP_ABL & 16) { __builtin_amdgcn_s_waitcnt(0xc07f); PP_TRACE(); }    // detail stamp 2: first fragments landed (lgkmcnt 0)
     // Hand-ordered schedule (every statement pinned by sched_barrier): the 8 fragment reads of tap t+1 go one per gap
     // between the first 8 MFMAs of tap t, in the order tap t+1 will use them -- a burst of 8 b128 reads in front of the
     // group kept the wave from issuing MFMAs for ~50 cycles per tap and the pipe ran dry.
 #define PP_SB() __builtin_amdgcn_sched_barrier(0)
 #define PP_MFMA(mb, nb, A, B) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[b][mb], B[b][nb], acc[mb][nb], 0, 0, 0); PP_SB()
-#define PP_RA(X, mb, off) if (more) { X[nx][mb] = __builtin_bit_cast(f16x8, ldsA[a_base[mb] + toff + (off)]); PP_SB(); }
-#define PP_RB(X, nb, off) if (more) { X[nx][nb] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + (off)]); PP_SB(); }
+#define PP_RA(X, mb, off) if (more && !(DC_PP_ABL & 4)) { X[nx][mb] = __builtin_bit_cast(f16x8, ldsA[a_base[mb] + toff + (off)]); PP_SB(); }
+#define PP_RB(X, nb, off) if (more && !(DC_PP_ABL & 4)) { X[nx][nb] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + (off)]); PP_SB(); }
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int b = tap & 1, nx = b ^ 1;
@@ -500,12 +509,14 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
       }
+      if (DC_PP_ABL & 16) PP_TRACE();                           // detail stamp 1: tile setup done
       __builtin_amdgcn_s_setprio(3);                            // the wave that feeds the matrix pipe goes first
       mfma_block(smem + (k & 1) * STAGE_BYTES);
       __builtin_amdgcn_s_setprio(0);
       if (c == nch - 1) { pend = cur; pending = true; }
-    } else if (pending) {
-      epi_slice(c);
+    } else {
+      if (DC_PP_ABL & 16) { PP_TRACE(); PP_TRACE(); }
+      if (pending && !(DC_PP_ABL & 1)) epi_slice(c);
     }
     if (++c == nch) { c = 0; ++j; }
     PP_TRACE();
