@@ -143,7 +143,7 @@ def _populate(name, root, ds_path):
     if regions is not None:
         d_mraw = w.create_dataset('masks/raw', shape=(len(regions),) + i_shape, dtype='int8')
         d_mmax = w.create_dataset('masks/max', shape=i_shape, dtype='int8')
-    tmp = ds_path + '.partial'
+    tmp = '%s.partial.%d' % (ds_path, os.getpid())      # concurrent builders (ranks) never share a half-written file
     w.save(tmp)
 
     raw = w.open_deferred(d_raw)

@@ -239,8 +239,7 @@ class UNet2DSummary(object):
         self.series_summary_func = series_summary_func
         self.mask_summary_func = mask_summary_func
         self.net_builder_func = net_builder_func
-        if not os.path.exists(self.cpdir):
-            os.makedirs(self.cpdir)
+        os.makedirs(self.cpdir, exist_ok=True)         # (several ranks may get here at once)
         self.custom_objects = {}
 
     def fit(self, dataset_paths, model_path=None, proceed=False, shape_trn=(96, 96), shape_val=(512, 512),

@@ -56,9 +56,13 @@ def nf_find_hdf5(names, datasets_dir=os.path.join(DATASETS_DIR, 'neurons_nf')):
         raise SystemExit('dataset %r: %s' % (names, e))
 
 
-def training(dataset_name, model_path, checkpoints_dir):
-    """Train on neurofinder datasets (reference :23-44, same hyper-parameters)."""
+def training(dataset_name, model_path, checkpoints_dir, nb_steps=100, nb_epochs=10):
+    """Train on neurofinder datasets (reference :23-44, same hyper-parameters; --nb_steps / --nb_epochs are additions
+    for short runs, the defaults are the reference's 100 x 10)."""
     parallel.init_from_env()                       # no-op unless launched with torch.distributed.run
+    if parallel.rank() == 0:
+        nf_find_hdf5(dataset_name)                 # rank 0 builds missing dataset files, the others wait for them
+    parallel.barrier()
     dspaths = nf_find_hdf5(dataset_name)
     model = UNet2DSummary(cpdir=checkpoints_dir)
     return model.fit(
@@ -67,8 +71,8 @@ def training(dataset_name, model_path, checkpoints_dir):
         shape_trn=(128, 128),
         shape_val=(512, 512),
         batch_size_trn=20,
-        nb_steps_trn=100,
-        nb_epochs=10,
+        nb_steps_trn=nb_steps,
+        nb_epochs=nb_epochs,
         keras_callbacks=[],
         prop_trn=0.75,
         prop_val=0.25,
@@ -107,6 +111,8 @@ if __name__ == '__main__':
     sp_trn.add_argument('dataset_name', help='dataset name', default='all_train', type=str)
     sp_trn.add_argument('-m', '--model_path', help='path to model')
     sp_trn.add_argument('-c', '--checkpoints_dir', help='checkpoint directory', default=CHECKPOINTS_DIR)
+    sp_trn.add_argument('--nb_steps', help='training batches per epoch', default=100, type=int)
+    sp_trn.add_argument('--nb_epochs', help='epochs', default=10, type=int)
     sp_eva = sp.add_parser('evaluate', help='CLI for evaluation.')
     sp_eva.set_defaults(which='evaluate')
     sp_eva.add_argument('dataset_name', help='dataset name', default='all_train', type=str)

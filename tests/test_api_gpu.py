@@ -199,25 +199,11 @@ def test_example_script_trains_by_name_from_a_neurofinder_directory(tmp_path):
     import json
     import subprocess
     import sys
-    from PIL import Image
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _nf_dirs import make_neurofinder_dir
     home = str(tmp_path / 'home')
     name = 'neurofinder.00.00'
-    root = '%s/.deep-calcium/datasets/neurons_nf/%s' % (home, name)
-    os.makedirs(root + '/images')
-    os.makedirs(root + '/regions')
-    rs = np.random.RandomState(11)
-    hw = (512, 512)
-    regions, base = [], rs.randint(200, 400, size=hw)
-    for k in range(60):
-        cy, cx = rs.randint(8, hw[0] - 8), rs.randint(8, hw[1] - 8)
-        coords = [[int(cy + dy), int(cx + dx)] for dy in range(-3, 4) for dx in range(-3, 4) if dy * dy + dx * dx <= 10]
-        regions.append({'coordinates': coords})
-        for y, x in coords:
-            base[y, x] += 600
-    for i in range(6):
-        Image.fromarray((base + rs.randint(0, 60, size=hw)).astype(np.uint16)).save('%s/images/image%05d.tiff' % (root, i))
-    with open(root + '/regions/regions.json', 'w') as fp:
-        json.dump(regions, fp)
+    root = make_neurofinder_dir('%s/.deep-calcium/datasets/neurons_nf' % home, name)
     cp = str(tmp_path / 'cp')
     script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'neurons', 'unet2ds_nf.py')
     env = dict(os.environ, HOME=home)

@@ -50,6 +50,33 @@ def test_bench_self_launches_two_ranks():
     assert out['config']['shared_gpus'] is True and np.isfinite(out['config']['loss'])
 
 
+def test_example_train_under_torch_distributed_run(tmp_path):
+    """The documented multi-GPU command: `python -m torch.distributed.run --nproc-per-node 2 examples/neurons/unet2ds_nf.py
+    train <name>`.  Both ranks replay the same sampling stream on their half of every batch of 20, validation runs on
+    each, rank 0 alone writes the metrics CSV and the checkpoints, and the loss goes down (2 epochs of 5 steps here)."""
+    sys.path.insert(0, HERE)
+    from _nf_dirs import make_neurofinder_dir
+    home = str(tmp_path / 'home')
+    name = 'neurofinder.01.00'
+    root = make_neurofinder_dir('%s/.deep-calcium/datasets/neurons_nf' % home, name, seed=5)
+    cp = str(tmp_path / 'cp')
+    env = dict(os.environ, DC_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', HOME=home)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29547', os.path.join(ROOT, 'examples', 'neurons', 'unet2ds_nf.py'), 'train', name, '-c', cp,
+           '--nb_steps', '5', '--nb_epochs', '2']        # (over gloo on ONE shared GPU every 31 MB gradient exchange costs ~0.5 s)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert os.path.exists(root + '/dataset.hdf5')
+    files = os.listdir(cp)
+    csvs = [f for f in files if f.endswith('.csv')]
+    assert len(csvs) == 1, files                                    # rank 0 only
+    assert len([f for f in files if '_model_' in f and f.endswith('.hdf5')]) == 2, files
+    rows = open(os.path.join(cp, csvs[0])).read().strip().splitlines()
+    cols = rows[0].split(',')
+    first, last = [dict(zip(cols, r_.split(','))) for r_ in (rows[1], rows[-1])]
+    assert len(rows) == 3 and float(last['loss']) < float(first['loss'])
+
+
 def test_shard_dropout_seed_reproduces_single_device_masks():
     """RNG dropout under data parallelism: rank r's shard with the offset seed gets the keep-bits ONE device draws for the
     same elements of the global batch (common.h dc_hash32: an element-index offset is a seed offset)."""
