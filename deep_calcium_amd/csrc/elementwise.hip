@@ -250,6 +250,81 @@ extern "C" int dc_bn_relu_drop_fwd(const float* z, const float* mean, const floa
   return DC_OK;
 }
 
+// BN + ReLU + dropout of a block that feeds MaxPooling2D, AND the pooling, in one pass: a thread takes one 2x2 window of
+// 4 channels, forms the four activations exactly as bn_relu_drop_fwd_kernel does (same expressions, same dropout
+// element indices), writes them (they are also the skip connection) and the first-max + argmax of the window exactly as
+// maxpool_fwd_kernel does.  Saves re-reading the activation: 1 of the 4.3 tensor passes of the two separate kernels.
+__global__ __launch_bounds__(256) void bn_relu_drop_pool_fwd_kernel(BnParams p, float* __restrict__ pooled,
+                                                                    uint8_t* __restrict__ idx, int N, int H, int W) {
+  const int C = p.C, C4 = C >> 2, h2 = H >> 1, w2 = W >> 1;
+  const bool drop = p.keep < 1.f;
+  const float inv_keep = drop ? 1.f / p.keep : 1.f;
+  const long total = (long)N * h2 * w2 * C4;
+  if (p.partial && blockIdx.x == 0 && threadIdx.x < C4) {
+    const int q = threadIdx.x;
+    const f32x4 ga = ld4(p.gamma + 4 * q), be = ld4(p.beta + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p.partial[4 * q + e] = bn_abound(ga[e], be[e], p.count, inv_keep);
+  }
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int q = (int)(i % C4);
+    long r = i / C4;
+    const int x = (int)(r % w2); r /= w2;
+    const int y = (int)(r % h2);
+    const long n = r / h2;
+    const f32x4 mu = ld4(p.mean + 4 * q), is = ld4(p.invstd + 4 * q), ga = ld4(p.gamma + 4 * q), be = ld4(p.beta + 4 * q);
+    f32x4 sc, sh;
+    bn_affine4(mu, is, ga, be, sc, sh);
+    const long pix00 = (n * H + 2 * y) * W + 2 * x;
+    const long pix[4] = {pix00, pix00 + 1, pix00 + W, pix00 + W + 1};
+    f32x4 z[4], a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = ld4(p.z + pix[k] * C + 4 * q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 v = fma4(z[k], sc, sh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      if (drop) v *= drop_factor(p, pix[k] * C + 4 * q, inv_keep);
+      a[k] = v;
+      st4(p.out + pix[k] * p.out_ld + 4 * q, v);
+    }
+    f32x4 m = a[0];
+    uchar4 kq = make_uchar4(0, 0, 0, 0);
+    uint8_t* kk = reinterpret_cast<uint8_t*>(&kq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (a[1][e] > m[e]) { m[e] = a[1][e]; kk[e] = 1; }
+      if (a[2][e] > m[e]) { m[e] = a[2][e]; kk[e] = 2; }
+      if (a[3][e] > m[e]) { m[e] = a[3][e]; kk[e] = 3; }
+    }
+    st4(pooled + i * 4, m);
+    if (idx) *reinterpret_cast<uchar4*>(idx + i * 4) = kq;
+  }
+}
+
+extern "C" int dc_bn_relu_drop_pool_fwd(const float* z, const float* mean, const float* invstd, const float* gamma,
+                                        const float* beta, const uint8_t* mask, float keep, uint64_t seed, float* out,
+                                        long out_ld, float* pooled, uint8_t* idx, int N, int H, int W, int C, double count,
+                                        float* abound, dc_stream_t stream) {
+  DC_REQUIRE(z && mean && invstd && gamma && beta && out && pooled, DC_EINVAL, "dc_bn_relu_drop_pool_fwd: null pointer");
+  DC_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && out_ld >= C && out_ld % 4 == 0 && keep > 0.f, DC_EINVAL,
+             "dc_bn_relu_drop_pool_fwd: bad sizes");
+  int rc = chan_check("dc_bn_relu_drop_pool_fwd", C);
+  if (rc) return rc;
+  BnParams p{};
+  const long pixels = (long)N * H * W;
+  p.z = z; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.mask = mask; p.keep = keep;
+  p.seed = seed; p.out = out; p.out_ld = out_ld; p.pixels = pixels; p.C = C;
+  p.partial = abound; p.count = count > 0 ? count : (double)pixels;
+  const long total = pixels / 4 * (C / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+  hipLaunchKernelGGL(bn_relu_drop_pool_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, pooled, idx, N, H, W);
+  DC_CHECK_LAUNCH("dc_bn_relu_drop_pool_fwd");
+  return DC_OK;
+}
+
 // dy = da * [y > 0] * dropfactor ; xhat = (z - mean) * invstd
 __device__ __forceinline__ void bn_bwd_math(const BnParams& p, long pix, int q, const f32x4& z, const f32x4& da,
                                             const f32x4& mu, const f32x4& is, const f32x4& sc, const f32x4& sh,

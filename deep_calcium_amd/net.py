@@ -187,6 +187,8 @@ class UNetEngine(object):
         self.bnin = self.mfma == 'f16x3' and os.environ.get('DC_BNIN', '1') == '1'
         # BatchNorm-backward pass-1 sums emitted by the kernel that produces da (head / max-pool backward)
         self.bnred = os.environ.get('DC_BNRED', '1') == '1'
+        # BN + ReLU + dropout of the block in front of a max-pool also does the pooling (one pass less over its activation)
+        self.pool_fused = os.environ.get('DC_POOL_FUSED', '1') == '1'
         # fp16 range guard of the activation operands (A/B knob; the weights' pack-time scale is unconditional)
         self.range_guard = os.environ.get('DC_RANGE_GUARD', '1') == '1'
         # Inference starts OPTIMISTIC: no activation scale (a BatchNorm network's activations are O(1)), the kernels only
@@ -843,8 +845,13 @@ class UNetEngine(object):
         self._last = (N, masks, step_seed, x_dev, y_dev)
         world = parallel.world_size()
         sync = self.bn_mode == 'sync' and world > 1
-        for step in self._plan(A):
+        plan = self._plan(A)
+        pooled_with_block = False
+        for si, step in enumerate(plan):
             if step[0] == 'pool':
+                if pooled_with_block:          # the block's BN + ReLU + dropout pass has pooled it already
+                    pooled_with_block = False
+                    continue
                 _, lvl, src, coff, ld, h, w = step
                 L.dc_maxpool2x2_fwd(_ptr(src, coff), ld, _ptr(A['pool%d' % lvl]), A['idx%d' % lvl].data_ptr(),
                                     N, h, w, self.nfb << lvl, st)
@@ -901,6 +908,16 @@ class UNetEngine(object):
                                        self.stat_ptr(l, 0), self.stat_ptr(l, 1), self.sview(l, 'mmean'),
                                        self.sview(l, 'mvar'), st)
             mptr, keep, seed = self._drop_args(l, masks, step_seed)
+            nxt = plan[si + 1] if si + 1 < len(plan) else None
+            if self.pool_fused and nxt is not None and nxt[0] == 'pool' and nxt[2] is dst and nxt[3] == coff:
+                lvl = nxt[1]
+                L.dc_bn_relu_drop_pool_fwd(_ptr(z), self.stat_ptr(l, 0), self.stat_ptr(l, 1),
+                                           self.pview(self.pflat, l, 'gamma'), self.pview(self.pflat, l, 'beta'),
+                                           mptr, keep, seed, _ptr(dst, coff), ld, _ptr(A['pool%d' % lvl]),
+                                           A['idx%d' % lvl].data_ptr(), N, h, w, l.cout,
+                                           float((world if sync else 1) * pixels), self._ab_out(l), st)
+                pooled_with_block = True
+                continue
             L.dc_bn_relu_drop_fwd(_ptr(z), self.stat_ptr(l, 0), self.stat_ptr(l, 1),
                                   self.pview(self.pflat, l, 'gamma'), self.pview(self.pflat, l, 'beta'),
                                   mptr, keep, seed, _ptr(dst, coff), ld, pixels, l.cout,

@@ -177,6 +177,14 @@ int dc_bn_fold(const float* gamma, const float* beta, const float* mmean, const 
 int dc_bn_relu_drop_fwd(const float* z, const float* mean, const float* invstd, const float* gamma,
                         const float* beta, const uint8_t* mask, float keep, uint64_t seed,
                         float* out, long out_ld, long pixels, int C, double count, float* abound, dc_stream_t stream);
+/* dc_bn_relu_drop_fwd of a block that feeds MaxPooling2D((2,2)) (unet_2d_summary.py:166-170) AND that pooling, in one
+ * pass over z [N,H,W,C]: writes the activation (out, strided: it is also the skip connection), pooled [N,H/2,W/2,C] and
+ * idx (nullable uint8, argmax 0..3 in row-major window order, first max on ties).  Bit-identical to the two separate
+ * calls; one tensor read less. */
+int dc_bn_relu_drop_pool_fwd(const float* z, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, const uint8_t* mask, float keep, uint64_t seed, float* out, long out_ld,
+                             float* pooled, uint8_t* idx, int N, int H, int W, int C, double count, float* abound,
+                             dc_stream_t stream);
 /* backward, pass 1: partial[blocks][C][2] = (sum dy, sum dy*xhat) with dy = da*relu'(.)*dropmask/keep.
  * blocks = dc_bn_bwd_blocks(pixels, C). */
 int dc_bn_bwd_blocks(long pixels, int C);

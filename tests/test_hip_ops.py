@@ -524,6 +524,40 @@ def test_maxpool_bit_exact_with_ties(dclib, N, H, W, C):
     assert np.array_equal(dx.cpu().numpy(), on.maxpool2x2_bwd(dy, i_ref))
 
 
+@pytest.mark.parametrize('N,H,W,C,drop', [(2, 16, 16, 32, 'rng'), (1, 12, 20, 8, 'mask'), (3, 8, 8, 64, 'none'), (1, 64, 64, 256, 'rng')])
+def test_bn_relu_drop_pool_fused_equals_separate_calls(dclib, N, H, W, C, drop):
+    """dc_bn_relu_drop_pool_fwd == dc_bn_relu_drop_fwd followed by dc_maxpool2x2_fwd, bit for bit: activation (strided
+    into a concat buffer), pooled values, argmax (post-ReLU / dropout zeros give plenty of ties), range-guard bound."""
+    L = dclib
+    rs = np.random.RandomState(C + H)
+    z = dev(rs.standard_normal((N, H, W, C)).astype(np.float32) * 2)
+    v = [dev(a.astype(np.float32)) for a in (rs.standard_normal(C), rs.random_sample(C) + 0.5, rs.standard_normal(C), rs.standard_normal(C) * 0.3)]
+    mask = dev((rs.random_sample((N, H, W, C)) < 0.75).astype(np.uint8)) if drop == 'mask' else None
+    keep = 1.0 if drop == 'none' else 0.75
+    seed = 0x1234567 if drop == 'rng' else 0
+    mptr = mask.data_ptr() if mask is not None else None
+    ld = 2 * C
+    res = []
+    for fused in (False, True):
+        cat = torch.zeros((N, H, W, ld), device='cuda')
+        pooled = torch.empty((N, H // 2, W // 2, C), device='cuda')
+        idx = torch.empty((N, H // 2, W // 2, C), dtype=torch.uint8, device='cuda')
+        ab = torch.zeros(C, device='cuda')
+        if fused:
+            L.dc_bn_relu_drop_pool_fwd(z.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(), mptr, keep, seed,
+                                       cat.data_ptr() + 4 * C, ld, pooled.data_ptr(), idx.data_ptr(), N, H, W, C, float(N * H * W),
+                                       ab.data_ptr(), None)
+        else:
+            L.dc_bn_relu_drop_fwd(z.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(), mptr, keep, seed,
+                                  cat.data_ptr() + 4 * C, ld, N * H * W, C, float(N * H * W), ab.data_ptr(), None)
+            L.dc_maxpool2x2_fwd(cat.data_ptr() + 4 * C, ld, pooled.data_ptr(), idx.data_ptr(), N, H, W, C, None)
+        torch.cuda.synchronize()
+        res.append([t.cpu().numpy() for t in (cat, pooled, idx, ab)])
+    for a, b, what in zip(res[0], res[1], ('activation', 'pooled', 'argmax', 'bound')):
+        assert np.array_equal(a, b), what
+    assert (res[1][0][..., :C] == 0).all() and (res[1][2] > 0).any() and (res[1][1] == 0).any()
+
+
 @pytest.mark.parametrize('C,pixels', [(32, 5000), (8, 777), (4, 64)])
 def test_head_fwd_bwd_metrics(dclib, C, pixels):
     L = dclib
