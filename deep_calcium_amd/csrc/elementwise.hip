@@ -1021,6 +1021,147 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
 }
 
+// Training step with a per-pixel loss (loss_kind 0 / 1): the head's backward needs nothing but the pixel's own p and y, so
+// the forward can do it while the C/4 values of the pixel are still in cache -- head_fwd_kernel's pixel-group scheme,
+// then lane q hands the dL/dlogit of ITS pixel back to the group and every lane writes its 4 channels of da, the head's
+// weight-gradient partials and (bn_partial) the producing BatchNorm layer's backward sums, as head_bwd_kernel does.
+// One read of the 512^2 x nfb tensor instead of two, no read of p.  Per-block summation order differs from
+// head_bwd_kernel's (same terms).
+__global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restrict__ a, const float* __restrict__ kh,
+                                                          const float* __restrict__ bh, const uint8_t* __restrict__ y,
+                                                          float* __restrict__ p, float* __restrict__ partial,
+                                                          float* __restrict__ da, float* __restrict__ gpartial, long pixels,
+                                                          int C, int loss_kind, const float* __restrict__ in_sc,
+                                                          const float* __restrict__ in_sh, const float* __restrict__ bn_mean,
+                                                          const float* __restrict__ bn_invstd, float* __restrict__ bn_partial) {
+  __shared__ float sm[256][DC_HEAD_SUMS];
+  __shared__ f32x4 sm4[256], sm4b[256];
+  __shared__ float sms[256];
+  const int C4 = C >> 2, PPB = 256 / C4;
+  const int tid = threadIdx.x, q = tid % C4, pl = tid / C4, lane = tid & 63;
+  float k0[4], k1[4];
+  f32x4 kd;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { k0[e] = kh[(4 * q + e) * 2]; k1[e] = kh[(4 * q + e) * 2 + 1]; kd[e] = k1[e] - k0[e]; }
+  const float b0 = bh[0], b1 = bh[1];
+  const float invM = 1.f / (float)pixels;
+  const bool bnin = in_sc != nullptr, bnred = bn_partial != nullptr;
+  const f32x4 isc = bnin ? ld4(in_sc + 4 * q) : f32x4{1.f, 1.f, 1.f, 1.f};
+  const f32x4 ish = bnin ? ld4(in_sh + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 bmu = bnred ? ld4(bn_mean + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 bis = bnred ? ld4(bn_invstd + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  float acc[DC_HEAD_SUMS];
+#pragma unroll
+  for (int k = 0; k < DC_HEAD_SUMS; ++k) acc[k] = 0.f;
+  f32x4 sa = {0.f, 0.f, 0.f, 0.f}, r1 = sa, r2 = sa;
+  float ss = 0.f;
+  const long iters = (pixels + (long)gridDim.x * PPB - 1) / ((long)gridDim.x * PPB);
+  for (long it0 = 0; it0 < iters; it0 += C4) {
+    float kz0 = 0.f, kz1 = 0.f;
+    long kpix = pixels;
+    for (int j = 0; j < C4; ++j) {
+      const long pix = ((it0 + j) * gridDim.x + blockIdx.x) * PPB + pl;
+      const bool ok = pix < pixels;
+      f32x4 v = ok ? ld4(a + pix * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (bnin) {
+        v = fma4(v, isc, ish);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ok ? fmaxf(v[e], 0.f) : 0.f;
+      }
+      float z0 = v[0] * k0[0] + v[1] * k0[1] + v[2] * k0[2] + v[3] * k0[3];
+      float z1 = v[0] * k1[0] + v[1] * k1[1] + v[2] * k1[2] + v[3] * k1[3];
+      for (int s = 1; s < C4; s <<= 1) { z0 += __shfl_xor(z0, s); z1 += __shfl_xor(z1, s); }
+      if (j == q) { kz0 = z0; kz1 = z1; kpix = pix; }
+    }
+    float sown = 0.f;                              // dL/dlogit1 of this lane's pixel
+    if (kpix < pixels) {
+      const long pix = kpix;
+      const float z0 = kz0 + b0, z1 = kz1 + b1;
+      const float m = fmaxf(z0, z1);
+      const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+      const float pr = e1 / (e0 + e1);
+      p[pix] = pr;
+      const float yt = (float)y[pix];
+      const float pc = fminf(fmaxf(pr, 1e-7f), 1.f - 1e-7f);
+      const float x = logf(pc / (1.f - pc));
+      acc[0] += fmaxf(x, 0.f) - x * yt + log1pf(expf(-fabsf(x)));
+      const float rp = round_half_even(pr);
+      acc[1] += rp * yt;
+      acc[2] += rp;
+      acc[3] += fminf(fmaxf(yt - rp, 0.f), 1.f);
+      acc[4] += yt;
+      acc[5] += yt * pr;
+      acc[6] += pr * pr;
+      acc[7] += yt * yt;
+      acc[8] += pr;
+      acc[9] -= 2.f * yt * logf(pr + 1e-7f) + (1.f - yt) * logf(1.f - pr + 1e-7f);
+      if (loss_kind == 0) {
+        const bool inside = pr > 1e-7f && pr < 1.f - 1e-7f;
+        sown = inside ? (pr - yt) * invM : 0.f;
+      } else {
+        const float dp = -(2.f * yt / (pr + 1e-7f) - (1.f - yt) / (1.f - pr + 1e-7f)) * invM;
+        sown = dp * pr * (1.f - pr);
+      }
+    }
+    // backward of the C4 pixels of this group (their values are re-read: they were loaded a moment ago)
+    for (int j = 0; j < C4; ++j) {
+      const float s = __shfl(sown, lane - q + j);
+      const long pix = ((it0 + j) * gridDim.x + blockIdx.x) * PPB + pl;
+      if (pix < pixels) {
+        f32x4 v = ld4(a + pix * C + 4 * q);
+        if (bnin) {
+          const f32x4 zraw = v;
+          v = fma4(v, isc, ish);
+          if (bnred) {
+            const f32x4 xh = (zraw - bmu) * bis;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float dy = (v[e] > 0.f) ? kd[e] * s : 0.f;
+              r1[e] += dy;
+              r2[e] += dy * xh[e];
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        st4(da + pix * C + 4 * q, kd * s);
+        sa += v * s;
+        if (q == 0) ss += s;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DC_HEAD_SUMS; ++k) sm[tid][k] = acc[k];
+  sm4[tid] = sa;
+  sms[tid] = (q == 0) ? ss : 0.f;
+  __syncthreads();
+  if (tid < DC_HEAD_SUMS) {
+    double s = 0.0;
+    for (int t = 0; t < 256; ++t) s += (double)sm[t][tid];
+    partial[(long)blockIdx.x * DC_HEAD_SUMS + tid] = (float)s;
+  }
+  if (pl == 0) {
+    for (int k = 1; k < PPB; ++k) sa += sm4[k * C4 + q];
+    st4(gpartial + (long)blockIdx.x * (C + 4) + 4 * q, sa);
+  }
+  if (tid == 0) {
+    float s = 0.f;
+    for (int k = 0; k < PPB; ++k) s += sms[k * C4];
+    gpartial[(long)blockIdx.x * (C + 4) + C] = s;
+  }
+  if (bnred) {
+    __syncthreads();
+    sm4[tid] = r1; sm4b[tid] = r2;
+    __syncthreads();
+    if (pl == 0) {
+      for (int k = 1; k < PPB; ++k) { r1 += sm4[k * C4 + q]; r2 += sm4b[k * C4 + q]; }
+      float* dst = bn_partial + ((long)blockIdx.x * C + 4 * q) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dst[2 * e] = r1[e]; dst[2 * e + 1] = r2[e]; }
+    }
+  }
+}
+
 // partial rows are padded to C+4 floats to keep float4 alignment; one block per output element, fixed order
 __global__ __launch_bounds__(256) void head_grad_finalize_kernel(const float* __restrict__ partial, int blocks, int C,
                                                                 float* dkh, float* dbh) {
@@ -1103,6 +1244,23 @@ static int head_bwd_impl(const float* a, const float* in_sc, const float* in_sh,
   hipLaunchKernelGGL(head_bwd_kernel, dim3(head_blocks(pixels)), dim3(256), 0, (hipStream_t)stream, a, p, y, kh, da,
                      partial, pixels, C, loss_kind, sums, in_sc, in_sh, bn_mean, bn_invstd, bn_partial);
   DC_CHECK_LAUNCH("dc_head_bwd");
+  return DC_OK;
+}
+extern "C" int dc_head_fwd_bwd(const float* a, const float* in_scale, const float* in_shift, const float* kh,
+                               const float* bh, const uint8_t* y, float* p, float* partial, float* da, float* grad_partial,
+                               int loss_kind, const float* bn_mean, const float* bn_invstd, float* bn_partial, long pixels,
+                               int C, dc_stream_t stream) {
+  DC_REQUIRE(a && kh && bh && y && p && partial && da && grad_partial && pixels > 0, DC_EINVAL, "dc_head_fwd_bwd: bad arguments");
+  DC_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), DC_EINVAL, "dc_head_fwd_bwd: in_scale and in_shift go together");
+  DC_REQUIRE(loss_kind == 0 || loss_kind == 1, DC_EUNSUP,
+             "dc_head_fwd_bwd: loss_kind %d needs the global sums first (use dc_head_fwd + dc_head_bwd)", loss_kind);
+  DC_REQUIRE(!bn_partial || (in_scale && bn_mean && bn_invstd), DC_EINVAL, "dc_head_fwd_bwd: bn_partial needs in_scale / bn_mean / bn_invstd");
+  int rc = chan_check("dc_head_fwd_bwd", C);
+  if (rc) return rc;
+  DC_REQUIRE(C <= 64, DC_EUNSUP, "dc_head_fwd_bwd: C=%d > 64 (the C/4 lanes of a pixel group must divide a wave)", C);
+  hipLaunchKernelGGL(head_fwd_bwd_kernel, dim3(head_blocks(pixels)), dim3(256), 0, (hipStream_t)stream, a, kh, bh, y, p,
+                     partial, da, grad_partial, pixels, C, loss_kind, in_scale, in_shift, bn_mean, bn_invstd, bn_partial);
+  DC_CHECK_LAUNCH("dc_head_fwd_bwd");
   return DC_OK;
 }
 extern "C" int dc_head_grad_finalize(const float* partial, int blocks, int C, float* dkh, float* dbh, dc_stream_t stream) {

@@ -189,6 +189,9 @@ class UNetEngine(object):
         self.bnred = os.environ.get('DC_BNRED', '1') == '1'
         # BN + ReLU + dropout of the block in front of a max-pool also does the pooling (one pass less over its activation)
         self.pool_fused = os.environ.get('DC_POOL_FUSED', '1') == '1'
+        # BCE-type losses: the head's backward is done by its forward kernel (dc_head_fwd_bwd)
+        self.head_fused = os.environ.get('DC_HEAD_FUSED', '1') == '1'
+        self._head_bwd_done = False
         # fp16 range guard of the activation operands (A/B knob; the weights' pack-time scale is unconditional)
         self.range_guard = os.environ.get('DC_RANGE_GUARD', '1') == '1'
         # Inference starts OPTIMISTIC: no activation scale (a BatchNorm network's activations are O(1)), the kernels only
@@ -779,6 +782,7 @@ class UNetEngine(object):
         T['stats_ws'] = torch.empty(stats_floats, dtype=torch.float64, device=dev)      # (sum, sum of squares) partials
         T['part_ws'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['part_ws2'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
+        T['head_gpart'] = torch.empty(hb * (nfb + 4), dtype=torch.float32, device=dev)
         T['absmax'] = torch.empty(4096, dtype=torch.float32, device=dev)
         T['dz_scale'] = torch.ones(self.dz_bufs * 4, dtype=torch.float32, device=dev)      # one (16-B aligned) scalar per dz buffer
         T['red_tmp'] = torch.empty(32 * 1024, dtype=torch.float32, device=dev)
@@ -928,7 +932,19 @@ class UNetEngine(object):
         pixels = N * self.H * self.W
         hb = L.dc_head_blocks(pixels)
         hsrc = self._bnin_src(self.by_name['d0b'], T)
-        if hsrc is not None:
+        self._head_bwd_done = False
+        if self.head_fused and self.loss_kind in (0, 1):
+            # per-pixel losses: the head's backward rides on its forward (one pass over the 512^2 x nfb tensor instead of
+            # two); backward() picks up da, the weight-gradient partials and d0b's BatchNorm-backward sums from here
+            a_in, sc_in, sh_in = (hsrc[0], hsrc[1][0], hsrc[1][1]) if hsrc is not None else (_ptr(A['d0b']), None, None)
+            ld0 = self.by_name['d0b']
+            red = hsrc is not None and self.bnred
+            L.dc_head_fwd_bwd(a_in, sc_in, sh_in, self.pview(self.pflat, lo, 'k'), self.pview(self.pflat, lo, 'b'),
+                              y_dev.data_ptr(), _ptr(A['p']), _ptr(T['part_ws']), _ptr(T['gA']), _ptr(T['head_gpart']),
+                              self.loss_kind, self.stat_ptr(ld0, 0) if red else None, self.stat_ptr(ld0, 1) if red else None,
+                              _ptr(T['part_ws2']) if red else None, pixels, self.nfb, st)
+            self._head_bwd_done = True
+        elif hsrc is not None:
             L.dc_head_fwd_bnin(hsrc[0], hsrc[1][0], hsrc[1][1], self.pview(self.pflat, lo, 'k'),
                                self.pview(self.pflat, lo, 'b'), y_dev.data_ptr(), _ptr(A['p']), _ptr(T['part_ws']),
                                pixels, self.nfb, st)
@@ -959,7 +975,13 @@ class UNetEngine(object):
         hb = L.dc_head_blocks(pixels0)
         hsrc = self._bnin_src(self.by_name['d0b'], T)
         fused_d0b = None          # (partial ptr, rows): BN-backward sums of d0b already produced by the head kernel
-        if hsrc is not None and self.bnred:
+        gpart = T['part_ws']
+        if self._head_bwd_done:   # forward_train's fused head kernel has written gA, the gradient partials and the sums
+            self._head_bwd_done = False
+            gpart = T['head_gpart']
+            if hsrc is not None and self.bnred:
+                fused_d0b = (_ptr(T['part_ws2']), hb)
+        elif hsrc is not None and self.bnred:
             ld0 = self.by_name['d0b']
             L.dc_head_bwd_bnin_bnred(hsrc[0], hsrc[1][0], hsrc[1][1], _ptr(A['p']), y_dev.data_ptr(),
                                      self.pview(self.pflat, lo, 'k'), _ptr(T['gA']), _ptr(T['part_ws']), self.loss_kind,
@@ -973,7 +995,7 @@ class UNetEngine(object):
         else:
             L.dc_head_bwd(_ptr(A['d0b']), _ptr(A['p']), y_dev.data_ptr(), self.pview(self.pflat, lo, 'k'),
                           _ptr(T['gA']), _ptr(T['part_ws']), self.loss_kind, T['sums'].data_ptr(), pixels0, nfb, st)
-        L.dc_head_grad_finalize(_ptr(T['part_ws']), hb, nfb, self.pview(self.gflat, lo, 'k'),
+        L.dc_head_grad_finalize(_ptr(gpart), hb, nfb, self.pview(self.gflat, lo, 'k'),
                                 self.pview(self.gflat, lo, 'b'), st)
 
         # Two HIP streams: the critical path (BN backward -> dgrad -> next block) stays on the caller's stream; the

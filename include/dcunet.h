@@ -272,6 +272,16 @@ int dc_head_fwd(const float* a, const float* kh, const float* bh, const uint8_t*
 int dc_head_bwd(const float* a, const float* p, const uint8_t* y, const float* kh, float* da, float* partial,
                 int loss_kind, const double* sums, long pixels, int C, dc_stream_t stream);
 /* head gradient from partial: dkh[c][0] = -S_c, dkh[c][1] = S_c, dbh = (-S, S) */
+/* Training with a per-pixel loss (loss_kind 0 binary_crossentropy / 1 weighted_binary_crossentropy): dc_head_fwd and
+ * dc_head_bwd(_bnin)(_bnred) in ONE pass over the head's input -- p, the 12 metric partials, da, the head's
+ * weight-gradient partials (grad_partial: [blocks][C+4], for dc_head_grad_finalize) and, when bn_partial is given, the
+ * producing BatchNorm layer's backward sums ([blocks][C][2]; needs in_scale / in_shift / bn_mean / bn_invstd).
+ * in_scale / in_shift NULL: `a` is a materialised activation.  The dice losses need the global sums before their
+ * backward: DC_EUNSUP. */
+int dc_head_fwd_bwd(const float* a, const float* in_scale, const float* in_shift, const float* kh, const float* bh,
+                    const uint8_t* y, float* p, float* partial, float* da, float* grad_partial, int loss_kind,
+                    const float* bn_mean, const float* bn_invstd, float* bn_partial, long pixels, int C,
+                    dc_stream_t stream);
 int dc_head_grad_finalize(const float* partial, int blocks, int C, float* dkh, float* dbh, dc_stream_t stream);
 
 /* ---- generic deterministic reductions ------------------------------------------

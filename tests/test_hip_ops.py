@@ -524,6 +524,57 @@ def test_maxpool_bit_exact_with_ties(dclib, N, H, W, C):
     assert np.array_equal(dx.cpu().numpy(), on.maxpool2x2_bwd(dy, i_ref))
 
 
+@pytest.mark.parametrize('C,pixels,kind,bnin', [(32, 5000, 0, True), (8, 777, 1, True), (4, 64, 0, False), (64, 4097, 0, True), (16, 300, 1, False)])
+def test_head_fused_forward_backward_equals_separate_calls(dclib, C, pixels, kind, bnin):
+    """dc_head_fwd_bwd (training with a per-pixel loss) against dc_head_fwd followed by dc_head_bwd(_bnin_bnred): p, da
+    and the metric partial sums bit for bit (same per-pixel arithmetic), the head's weight gradient and the producing
+    BatchNorm layer's backward sums to summation-order accuracy (same terms, different order inside a block)."""
+    L = dclib
+    rs = np.random.RandomState(C + pixels)
+    a = dev((rs.standard_normal((pixels, C)) * 1.5).astype(np.float32))
+    kh = dev((rs.standard_normal((C, 2)) * 0.4).astype(np.float32)); bh = dev(rs.standard_normal(2).astype(np.float32) * 0.1)
+    y = dev((rs.random_sample(pixels) < 0.2).astype(np.uint8))
+    sc = dev((rs.random_sample(C) + 0.5).astype(np.float32)); sh = dev((rs.standard_normal(C) * 0.3).astype(np.float32))
+    mu = dev(rs.standard_normal(C).astype(np.float32) * 0.2); isd = dev((rs.random_sample(C) + 0.5).astype(np.float32))
+    hb = L.dc_head_blocks(pixels)
+    def bufs():
+        return dict(p=torch.empty(pixels, device='cuda'), part=torch.zeros(hb * 12, device='cuda'), da=torch.empty((pixels, C), device='cuda'),
+                    gp=torch.zeros(hb * (C + 4), device='cuda'), bp=torch.zeros(hb * C * 2, device='cuda'),
+                    sums=torch.zeros(12, dtype=torch.float64, device='cuda'), dk=torch.zeros((C, 2), device='cuda'), db=torch.zeros(2, device='cuda'),
+                    dg=torch.zeros(C, device='cuda'), dbt=torch.zeros(C, device='cuda'))
+    A, B = bufs(), bufs()
+    scp, shp = (sc.data_ptr(), sh.data_ptr()) if bnin else (None, None)
+    # separate
+    if bnin:
+        L.dc_head_fwd_bnin(a.data_ptr(), scp, shp, kh.data_ptr(), bh.data_ptr(), y.data_ptr(), A['p'].data_ptr(), A['part'].data_ptr(), pixels, C, None)
+        L.dc_reduce_partials_f64(A['part'].data_ptr(), hb, 12, A['sums'].data_ptr(), None)
+        L.dc_head_bwd_bnin_bnred(a.data_ptr(), scp, shp, A['p'].data_ptr(), y.data_ptr(), kh.data_ptr(), A['da'].data_ptr(), A['gp'].data_ptr(), kind,
+                                 A['sums'].data_ptr(), mu.data_ptr(), isd.data_ptr(), A['bp'].data_ptr(), pixels, C, None)
+    else:
+        L.dc_head_fwd(a.data_ptr(), kh.data_ptr(), bh.data_ptr(), y.data_ptr(), A['p'].data_ptr(), A['part'].data_ptr(), pixels, C, None)
+        L.dc_reduce_partials_f64(A['part'].data_ptr(), hb, 12, A['sums'].data_ptr(), None)
+        L.dc_head_bwd(a.data_ptr(), A['p'].data_ptr(), y.data_ptr(), kh.data_ptr(), A['da'].data_ptr(), A['gp'].data_ptr(), kind, A['sums'].data_ptr(), pixels, C, None)
+    # fused
+    L.dc_head_fwd_bwd(a.data_ptr(), scp, shp, kh.data_ptr(), bh.data_ptr(), y.data_ptr(), B['p'].data_ptr(), B['part'].data_ptr(), B['da'].data_ptr(),
+                      B['gp'].data_ptr(), kind, mu.data_ptr() if bnin else None, isd.data_ptr() if bnin else None, B['bp'].data_ptr() if bnin else None,
+                      pixels, C, None)
+    L.dc_reduce_partials_f64(B['part'].data_ptr(), hb, 12, B['sums'].data_ptr(), None)
+    for X in (A, B):
+        L.dc_head_grad_finalize(X['gp'].data_ptr(), hb, C, X['dk'].data_ptr(), X['db'].data_ptr(), None)
+        if bnin:
+            L.dc_bn_bwd_finalize(X['bp'].data_ptr(), hb, C, X['dg'].data_ptr(), X['dbt'].data_ptr(), None)
+    torch.cuda.synchronize()
+    assert np.array_equal(A['p'].cpu().numpy(), B['p'].cpu().numpy())
+    assert np.array_equal(A['da'].cpu().numpy(), B['da'].cpu().numpy())
+    assert np.array_equal(A['sums'].cpu().numpy(), B['sums'].cpu().numpy())
+    for k in ('dk', 'db') + (('dg', 'dbt') if bnin else ()):
+        x, z = A[k].cpu().numpy().astype(np.float64), B[k].cpu().numpy().astype(np.float64)
+        assert np.abs(x - z).max() <= 2e-6 * max(np.abs(x).max(), 1e-30), (k, x, z)
+    with pytest.raises(Exception):
+        L.dc_head_fwd_bwd(a.data_ptr(), scp, shp, kh.data_ptr(), bh.data_ptr(), y.data_ptr(), B['p'].data_ptr(), B['part'].data_ptr(), B['da'].data_ptr(),
+                          B['gp'].data_ptr(), 2, None, None, None, pixels, C, None)
+
+
 @pytest.mark.parametrize('N,H,W,C,drop', [(2, 16, 16, 32, 'rng'), (1, 12, 20, 8, 'mask'), (3, 8, 8, 64, 'none'), (1, 64, 64, 256, 'rng')])
 def test_bn_relu_drop_pool_fused_equals_separate_calls(dclib, N, H, W, C, drop):
     """dc_bn_relu_drop_pool_fwd == dc_bn_relu_drop_fwd followed by dc_maxpool2x2_fwd, bit for bit: activation (strided
