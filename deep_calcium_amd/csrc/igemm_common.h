@@ -30,5 +30,15 @@ struct IgemmParams {
   long inAboundLd;   // 0: one slot (training bound); > 0: DC_ABOUND_SLOTS measured replicas, this many floats apart
   float* outAbsmax;
   long outAbsmaxLd;  // floats between the replicas of the output's array
+  // role-split kernel only, data-gradient launches: the output IS `da` of a BatchNorm layer (dense, outLd == Ncols, no
+  // dropout) -- the epilogue also reads that layer's pre-BN tensor bnZ (same layout) and emits its BatchNorm-backward
+  // pass-1 partials bnPartial[tile][Ncols][2] = (sum dy, sum dy*xhat), dy = da * [fmaf(z, sc, sh) > 0] with (sc, sh) =
+  // dc_bn_affine(mean, invstd, gamma, beta): what dc_bn_bwd_reduce would re-read da and z for.
+  const float* bnZ;
+  const float* bnMean;
+  const float* bnInvstd;
+  const float* bnGamma;
+  const float* bnBeta;
+  float* bnPartial;
 };
 

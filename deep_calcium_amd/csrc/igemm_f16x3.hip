@@ -667,6 +667,38 @@ extern "C" int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* 
   return conv3x3_h_launch(p, (hipStream_t)stream);
 }
 
+// Data gradient that also emits the BatchNorm-backward pass-1 sums of the layer whose `da` it writes (role-split kernel
+// only: dc_conv3x3_dgrad_bnred_blocks() == 0 tells the caller to use dc_conv3x3_dgrad_f16x3 + dc_bn_bwd_reduce instead).
+static IgemmParams dgrad_bnred_params(const float* dz, const void* wp16, float* dx, const float* in_scale, int N, int H, int W,
+                                      int Cin, int Cout) {
+  IgemmParams p{};
+  p.in = dz; p.wp = reinterpret_cast<const float*>(wp16); p.out = dx; p.inScale = in_scale;
+  p.N = N; p.Hin = H; p.Win = W; p.Cin = Cout; p.Hout = H; p.Wout = W; p.Ncols = Cin;
+  p.biasMod = Cin; p.outLd = Cin;
+  return p;
+}
+extern "C" int dc_conv3x3_dgrad_bnred_blocks(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  static const bool off = getenv("DC_DGRAD_BNRED") && atoi(getenv("DC_DGRAD_BNRED")) == 0;
+  float dummy = 1.f;      // (a non-null inScale marks a data-gradient launch for the DC_IGEMM_PP=2 setting)
+  IgemmParams p = dgrad_bnred_params(nullptr, nullptr, nullptr, &dummy, N, H, W, Cin, Cout);
+  if (off || !dc_igemm_pp_serves(p)) return 0;
+  return N * dc_cdiv(W, 32) * dc_cdiv(H, Cin <= 32 ? 16 : 8);
+}
+extern "C" int dc_conv3x3_dgrad_bnred_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
+                                            const float* z, const float* mean, const float* invstd, const float* gamma,
+                                            const float* beta, float* bn_partial, int N, int H, int W, int Cin, int Cout,
+                                            dc_stream_t stream) {
+  int rc = check_h("dc_conv3x3_dgrad_bnred_f16x3", dz, wp16, dx, N, H, W, Cout, Cin);
+  if (rc) return rc;
+  DC_REQUIRE(z && mean && invstd && gamma && beta && bn_partial, DC_EINVAL, "dc_conv3x3_dgrad_bnred_f16x3: null pointer");
+  IgemmParams p = dgrad_bnred_params(dz, wp16, dx, in_scale, N, H, W, Cin, Cout);
+  p.bnZ = z; p.bnMean = mean; p.bnInvstd = invstd; p.bnGamma = gamma; p.bnBeta = beta; p.bnPartial = bn_partial;
+  DC_REQUIRE(dc_conv3x3_dgrad_bnred_blocks(N, H, W, Cin, Cout) > 0, DC_EUNSUP,
+             "dc_conv3x3_dgrad_bnred_f16x3: shape not served (dc_conv3x3_dgrad_bnred_blocks() == 0): use the two-pass path");
+  return dc_igemm_pp_launch(p, (hipStream_t)stream, "conv3x3_dgrad_bnred_f16x3_pp");
+}
+
 extern "C" int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld,
                                      double* stats, const float* scale, const float* shift, int relu,
                                      const float* in_abound, long in_abound_ld, float* out_absmax, long out_absmax_ld,

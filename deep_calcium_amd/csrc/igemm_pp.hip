@@ -95,7 +95,9 @@ struct Item {          // one output tile x column block (wave-uniform)
 };
 }  // namespace pp
 
-template <int MB_, int NB_>
+// BNRED: the data-gradient variant that also emits the BatchNorm-backward sums of the layer it writes `da` of (its own
+// instantiation: the statistics / tracking epilogues are compiled out of it, and its code out of the other one)
+template <int MB_, int NB_, bool BNRED = false>
 __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p) {
   using namespace pp;
   using C = Cfg<MB_, NB_>;
@@ -151,6 +153,14 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
     lds_ep[i] = p.bias ? p.bias[i] : 0.f;
     lds_ep[EP_COLS + i] = p.scale ? p.scale[i] : 1.f;
     lds_ep[2 * EP_COLS + i] = p.shift ? p.shift[i] : 0.f;
+    if constexpr (BNRED) { // BatchNorm-backward sums of the layer this launch writes `da` of: its gate affine, mean, 1/std
+      float gsc, gsh;      // (a data-gradient launch has no epilogue scale / shift and no BN-on-load table: their slots)
+      dc_bn_affine(p.bnMean[i], p.bnInvstd[i], p.bnGamma[i], p.bnBeta[i], gsc, gsh);
+      lds_ep[EP_COLS + i] = gsc;
+      lds_ep[2 * EP_COLS + i] = gsh;
+      lds_sc[i] = p.bnMean[i];
+      lds_sc[EP_COLS + i] = p.bnInvstd[i];
+    }
   }
   const float in_scale = (p.inScale ? *p.inScale : 1.f) * dc_block_guard_scale(p.inAbound, p.Cin, tmp, p.inAboundLd);
   if (p.inAbound == nullptr) __syncthreads();                 // (the guard's own barriers publish the tables otherwise)
@@ -370,14 +380,15 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
   // (mode 2), stores.  Slices run in the order (nb 0: mb 0, 1), (nb 1: mb 0, 1); the per-column shifted sums of a column
   // block live in four registers across its two slices and go to LDS after the second; the cross-wave merge of the tile's
   // partials happens one step later (merge_pending), whatever that step is for this set.
-  const int mode = p.outAbsmax ? 2 : (p.stats ? 1 : 0);          // wave-uniform
+  const int mode = BNRED ? 4 : (p.outAbsmax ? 2 : (p.stats ? 1 : 0));          // wave-uniform
   float e_s1 = 0.f, e_s2 = 0.f, e_cnt = 0.f, e_K = 0.f;
   auto epi_values = [&](auto nb_tag, auto mb_tag, auto interior_tag, auto mode_tag) __attribute__((always_inline)) {
     constexpr int nb = decltype(nb_tag)::value;
     constexpr int mb = decltype(mb_tag)::value;
     constexpr bool INT = decltype(interior_tag)::value;
     constexpr int MODE = decltype(mode_tag)::value;                 // border tiles (!INT): MODE == 3, resolved at run time
-    const bool m_stats = MODE == 1 || (MODE == 3 && mode == 1), m_track = MODE == 2 || (MODE == 3 && mode == 2);
+    const bool m_stats = !BNRED && (MODE == 1 || (MODE == 3 && mode == 1)), m_track = !BNRED && (MODE == 2 || (MODE == 3 && mode == 2));
+    constexpr bool m_bnred = BNRED && (MODE == 4 || MODE == 3);
     const long out_img_floats = (long)p.Hout * p.Wout * p.outLd;
     const __amdgpu_buffer_rsrc_t rsrcO = dc_make_rsrc(p.out + (long)pend.img * out_img_floats, (unsigned)(out_img_floats * 4));
     const int n = pend.n0 + nb * 32 + li;
@@ -392,6 +403,19 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
     const int mblk = wave_m * MB + mb;
     const int oyb = pend.oy0 + mblk * RPM, oxb = pend.ox0 + 4 * h;
     const unsigned base = (unsigned)((oyb * sy + oxb * sx + n) * 4);
+    // BatchNorm-backward sums: the z values of this block are requested first, the stores of da go out while they fly
+    float zr[16];
+    if (m_bnred) {
+      const __amdgpu_buffer_rsrc_t rsrcZ = dc_make_rsrc(p.bnZ + (long)pend.img * out_img_floats, (unsigned)(out_img_floats * 4));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mr = (r & 3) + 8 * (r >> 2);
+        const int rowc = mr / TW, colc = mr % TW;
+        const bool ok = INT || (n_ok && (oyb + rowc) < p.Hout && (oxb + colc) < p.Wout);
+        const unsigned off = ok ? base + (unsigned)((rowc * sy + colc * sx) * 4) : OOB;
+        zr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcZ, off, 0, 0));
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int mr = (r & 3) + 8 * (r >> 2);
@@ -412,6 +436,27 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
         if (m_track) amax = fmaxf(amax, ok ? fabsf(v) : 0.f);
         const unsigned off = ok ? base + (unsigned)((rowc * sy + colc * sx) * 4) : OOB;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, off, 0, 0);
+      }
+    }
+    if (m_bnred) {
+      const float mu = lds_sc[nl], is = lds_sc[EP_COLS + nl];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mr = (r & 3) + 8 * (r >> 2);
+        const int rowc = mr / TW, colc = mr % TW;
+        const bool ok = INT || (n_ok && (oyb + rowc) < p.Hout && (oxb + colc) < p.Wout);
+        const float v = __builtin_fmaf(acc[mb][nb][r], out_scale, bv);
+        const float y = __builtin_fmaf(zr[r], sc, sh);          // the forward's own expression: identical ReLU gate
+        const float dy = (ok && y > 0.f) ? v : 0.f;
+        e_s1 += dy;
+        e_s2 = __builtin_fmaf(dy, (zr[r] - mu) * is, e_s2);
+      }
+      if (mb == MB - 1) {
+        DcMoments m;                                             // container: (unused, sum dy, sum dy*xhat)
+        m.n = 0.f;
+        m.mean = e_s1 + __shfl_xor(e_s1, 32);
+        m.m2 = e_s2 + __shfl_xor(e_s2, 32);
+        if (h == 0) red[(wave_m * NB + nb) * 32 + li] = m;
       }
     }
     if (m_stats && mb == MB - 1) {
@@ -439,7 +484,7 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
   bool merge_pending = false;
   Item mitem = {0, 0, 0, 0, 0};
   auto epi_merge = [&]() __attribute__((always_inline)) {      // the red[] entries of both column blocks are complete
-    if (mode == 1) {
+    if (!BNRED && mode == 1) {
       const int ts = tid & 255;                                 // thread within the consumer set
       if (ts < NB * 32) {
         const int nb = ts / 32, l = ts % 32;
@@ -449,6 +494,19 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
         const int n = mitem.n0 + nb * 32 + l;
         if (n < p.Ncols) dc_moments_store(p.stats + ((long)mitem.tile_id * p.Ncols + n) * 2, m);
       }
+    } else if (BNRED) {
+      const int ts = tid & 255;
+      if (ts < NB * 32) {
+        const int nb = ts / 32, l = ts % 32;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int wm = 0; wm < WAVES_M; ++wm) { const DcMoments m = red[(wm * NB + nb) * 32 + l]; s1 += m.mean; s2 += m.m2; }
+        const int n = mitem.n0 + nb * 32 + l;
+        if (n < p.Ncols) {
+          float* dst = p.bnPartial + ((long)mitem.tile_id * p.Ncols + n) * 2;
+          dst[0] = s1; dst[1] = s2;
+        }
+      }
     }
     merge_pending = false;
   };
@@ -457,9 +515,13 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
     using T1 = std::integral_constant<int, 1>;
     using T2 = std::integral_constant<int, 2>;
     using T3 = std::integral_constant<int, 3>;
+    using T4 = std::integral_constant<int, 4>;
     const bool interior = (pend.oy0 + TH <= p.Hout) && (pend.ox0 + TW <= p.Wout) && (pend.n0 + BN <= p.Ncols);
     auto run = [&](auto nb_tag, auto mb_tag) __attribute__((always_inline)) {
-      if (interior) {
+      if constexpr (BNRED) {
+        if (interior) epi_values(nb_tag, mb_tag, std::true_type{}, T4{});
+        else epi_values(nb_tag, mb_tag, std::false_type{}, T3{});
+      } else if (interior) {
         if (mode == 0) epi_values(nb_tag, mb_tag, std::true_type{}, T0{});
         else if (mode == 1) epi_values(nb_tag, mb_tag, std::true_type{}, T1{});
         else epi_values(nb_tag, mb_tag, std::true_type{}, T2{});
@@ -542,10 +604,10 @@ bool dc_igemm_pp_serves(const IgemmParams& p) {
          !(p.outAbsmax && p.outAbsmaxLd >= 0) && p.Cin <= 1024 && p.Ncols <= pp::EP_COLS && total >= 8;
 }
 
-template <int MB_, int NB_>
+template <int MB_, int NB_, bool BNRED>
 static int pp_launch(IgemmParams p, hipStream_t st, const char* name) {
   using C = pp::Cfg<MB_, NB_>;
-  auto kern = igemm_pp_kernel<MB_, NB_>;
+  auto kern = igemm_pp_kernel<MB_, NB_, BNRED>;
   static DcLdsAttr lds_attr;
   const int lds = C::FIXED_LDS + pp::TABLE_BYTES + 3 * pp::EP_COLS * 4;
   if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), lds, name)) return rc;
@@ -570,5 +632,6 @@ static int pp_launch(IgemmParams p, hipStream_t st, const char* name) {
 
 // same tile-shape choice as igemm_f16x3.hip's conv3x3 dispatch (and therefore the same BatchNorm-partial tile count)
 int dc_igemm_pp_launch(IgemmParams p, hipStream_t st, const char* name) {
-  return p.Ncols <= 32 ? pp_launch<4, 1>(p, st, name) : pp_launch<2, 2>(p, st, name);
+  if (p.bnPartial) return p.Ncols <= 32 ? pp_launch<4, 1, true>(p, st, name) : pp_launch<2, 2, true>(p, st, name);
+  return p.Ncols <= 32 ? pp_launch<4, 1, false>(p, st, name) : pp_launch<2, 2, false>(p, st, name);
 }

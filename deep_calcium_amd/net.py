@@ -191,6 +191,8 @@ class UNetEngine(object):
         self.pool_fused = os.environ.get('DC_POOL_FUSED', '1') == '1'
         # BCE-type losses: the head's backward is done by its forward kernel (dc_head_fwd_bwd)
         self.head_fused = os.environ.get('DC_HEAD_FUSED', '1') == '1'
+        # data gradients served by the role-split kernel also emit the BatchNorm-backward sums of the layer they feed
+        self.dgrad_bnred = os.environ.get('DC_DGRAD_BNRED', '1') == '1'
         self._head_bwd_done = False
         # fp16 range guard of the activation operands (A/B knob; the weights' pack-time scale is unconditional)
         self.range_guard = os.environ.get('DC_RANGE_GUARD', '1') == '1'
@@ -776,6 +778,10 @@ class UNetEngine(object):
             part_floats = max(part_floats, blocks * l.cout * 2)
         hb = L.dc_head_blocks(N * self.H * self.W)
         part_floats = max(part_floats, hb * (nfb + 4), hb * 12, hb * nfb * 2)
+        for l in self.layers:            # data gradients that emit the previous layer's BatchNorm-backward sums
+            if l.kind == 'conv' and l.cin > 1:
+                h, w = self._hw(l.lvl)
+                part_floats = max(part_floats, L.dc_conv3x3_dgrad_bnred_blocks(N, h, w, l.cin, l.cout) * l.cin * 2)
         for lvl in range(4):
             h, w = self._hw(lvl)
             part_floats = max(part_floats, L.dc_maxpool2x2_bwd_blocks(N, h, w, nfb << lvl) * (nfb << lvl) * 2)
@@ -1016,8 +1022,18 @@ class UNetEngine(object):
             side.wait_stream(main)        # everything queued so far (forward, head) precedes the first wgrad
         self._dz_turn = getattr(self, '_dz_turn', 0)
 
-        def launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16):
+        def launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16, red=None):
+            """red = the BatchNorm layer whose `da` this data gradient writes (dense, no dropout): when the role-split
+            kernel serves the shape its epilogue also emits that layer's backward sums -> (partial ptr, rows)."""
             if l.kind == 'conv':
+                if f16 and red is not None:
+                    rows = L.dc_conv3x3_dgrad_bnred_blocks(N, h, w, l.cin, l.cout)
+                    if rows > 0:
+                        L.dc_conv3x3_dgrad_bnred_f16x3(dz, wpd, dx_ptr, scale, _ptr(T['z_' + red.name]), self.stat_ptr(red, 0),
+                                                       self.stat_ptr(red, 1), self.pview(self.pflat, red, 'gamma'),
+                                                       self.pview(self.pflat, red, 'beta'), _ptr(T['part_ws']), N, h, w,
+                                                       l.cin, l.cout, st)
+                        return (_ptr(T['part_ws']), rows)
                 if f16:
                     L.dc_conv3x3_dgrad_f16x3(dz, wpd, dx_ptr, scale, N, h, w, l.cin, l.cout, st)
                 else:
@@ -1026,13 +1042,16 @@ class UNetEngine(object):
                 L.dc_convT2x2_dgrad_f16x3(dz, wpd, dx_ptr, scale, N, h // 2, w // 2, l.cin, l.cout, st)
             else:
                 L.dc_convT2x2_dgrad(dz, wpd, dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
+            return None
 
         world = parallel.world_size()
         sync = self.bn_mode == 'sync' and world > 1
 
-        def block_bwd(l, x_in, da_ptr, da_ld, dx_ptr, prod=None, fused=None):
+        def block_bwd(l, x_in, da_ptr, da_ld, dx_ptr, prod=None, fused=None, red=None):
             """da (strided) -> grads of l; dx written to dx_ptr (dense [.., cin]) unless None.  prod: the layer that
-            produced x_in (its activation may be non-materialised: BN + ReLU on load)."""
+            produced x_in (its activation may be non-materialised: BN + ReLU on load).  red: the layer whose `da` dx is
+            (see launch_dgrad); returns what that layer's block_bwd takes as `fused`."""
+            fused_next = None
             bsrc = self._bnin_src(prod, T)
             h, w = self._hw(l.lvl)
             pixels = N * h * w
@@ -1078,7 +1097,7 @@ class UNetEngine(object):
             # ---- main stream first: the data gradient feeds the next block ---------------------------------------
             wpd = _ptr(self.wp_dgrad[l.name]) if dx_ptr is not None else None
             if dx_ptr is not None and self.wgrad_after_dgrad:
-                launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16)
+                fused_next = launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16, red)
                 if two:
                     ready = torch.cuda.Event()
                     ready.record(main)
@@ -1105,16 +1124,21 @@ class UNetEngine(object):
                 self._dz_free[k] = torch.cuda.Event()
                 self._dz_free[k].record(side)
             if dx_ptr is not None and not self.wgrad_after_dgrad:
-                launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16)
+                fused_next = launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16, red)
+            return fused_next
+
+        def red_of(la):          # dgrad-fused BatchNorm-backward sums: dense da of a dropout-free layer only
+            return la if (self.bnred and self.dgrad_bnred and la.drop <= 0.0) else None
 
         g, other = T['gA'], T['gB']      # g holds the gradient w.r.t. the current block's output
         for lvl in (0, 1, 2, 3):
             c = nfb << lvl
             cat, dcat = A['cat%d' % lvl], T['dcat%d' % lvl]
-            block_bwd(self.by_name['d%db' % lvl], _ptr(A['d%da' % lvl]), _ptr(g), c, _ptr(other),
-                      prod=self.by_name['d%da' % lvl], fused=fused_d0b if lvl == 0 else None)
+            la = self.by_name['d%da' % lvl]
+            fa = block_bwd(self.by_name['d%db' % lvl], _ptr(A['d%da' % lvl]), _ptr(g), c, _ptr(other),
+                           prod=la, fused=fused_d0b if lvl == 0 else None, red=red_of(la))
             g, other = other, g
-            block_bwd(self.by_name['d%da' % lvl], _ptr(cat), _ptr(g), c, _ptr(dcat))
+            block_bwd(la, _ptr(cat), _ptr(g), c, _ptr(dcat), fused=fa)
             x_up = A['bb'] if lvl == 3 else A['d%db' % (lvl + 1)]
             l_up = self.by_name['bb' if lvl == 3 else 'd%db' % (lvl + 1)]
             if self.upsampling:
@@ -1157,13 +1181,14 @@ class UNetEngine(object):
                 g, other = other, g
             else:
                 fused_pool = None
-            block_bwd(self.by_name[tag + 'b'], _ptr(A[tag + 'a']), _ptr(g), c, _ptr(other), prod=self.by_name[tag + 'a'],
-                      fused=fused_pool)
+            la = self.by_name[tag + 'a']
+            fa = block_bwd(self.by_name[tag + 'b'], _ptr(A[tag + 'a']), _ptr(g), c, _ptr(other), prod=la,
+                           fused=fused_pool, red=red_of(la))
             g, other = other, g
             if lvl == 0:
-                block_bwd(self.by_name['e0a'], _ptr(x_dev), _ptr(g), c, None)
+                block_bwd(la, _ptr(x_dev), _ptr(g), c, None, fused=fa)
             else:
-                block_bwd(self.by_name[tag + 'a'], _ptr(A['pool%d' % (lvl - 1)]), _ptr(g), c, _ptr(other))
+                block_bwd(la, _ptr(A['pool%d' % (lvl - 1)]), _ptr(g), c, _ptr(other), fused=fa)
                 g, other = other, g
         if two:
             main.wait_stream(side)        # gflat is complete once both streams have drained

@@ -211,6 +211,13 @@ int dc_bn_bwd_apply_finalize(const float* dbias_partial, const float* absmax_par
  * re-read of da and z) is skipped; dc_bn_bwd_finalize(bn_partial, blocks, ...) follows as usual.
  *   dc_head_bwd_bnin_bnred : blocks = dc_head_blocks(pixels); BN layer = the head's (non-materialised) input layer
  *   dc_maxpool2x2_bwd_bnred: blocks = dc_maxpool2x2_bwd_blocks(); BN layer = the pooled layer (z dense [N,H,W,C]) */
+/*   dc_conv3x3_dgrad_bnred_f16x3: dc_conv3x3_dgrad_f16x3 whose output dx IS the `da` of the BatchNorm layer in front
+ *   (dense [N,H,W,Cin], no dropout, pre-BN tensor z of the same shape): rows = dc_conv3x3_dgrad_bnred_blocks(...) partial
+ *   rows of bn_partial[rows][Cin][2]; rows == 0 -> shape not served, use dc_conv3x3_dgrad_f16x3 + dc_bn_bwd_reduce. */
+int dc_conv3x3_dgrad_bnred_blocks(int N, int H, int W, int Cin, int Cout);
+int dc_conv3x3_dgrad_bnred_f16x3(const float* dz, const void* wp16, float* dx, const float* dz_scale, const float* z,
+                                 const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                 float* bn_partial, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 int dc_head_bwd_bnin_bnred(const float* z_in, const float* in_scale, const float* in_shift, const float* p,
                            const uint8_t* y, const float* kh, float* da, float* partial, int loss_kind,
                            const double* sums, const float* bn_mean, const float* bn_invstd, float* bn_partial,

@@ -145,3 +145,80 @@ def test_fullsize_window_train_step_vs_float64_torch_oracle(n):
     cos = fg.dot(fr) / (np.linalg.norm(fg) * np.linalg.norm(fr))
     rel = np.linalg.norm(fg - fr) / np.linalg.norm(fr)
     assert cos > 0.9995 and rel < 0.05, (cos, rel)
+
+
+def _tile_sums(a, TH, C):
+    n, h, w, _ = a.shape
+    return a.reshape(n, h // TH, TH, w // 32, 32, C).sum(axis=(2, 4)).reshape(-1, C)
+
+
+@pytest.mark.parametrize('HW,Ci,Co', [(256, 64, 64), (64, 256, 256)])
+def test_role_split_kernel_moments_per_tile_at_batch_16(HW, Ci, Co):
+    """The persistent kernel's per-tile BatchNorm partials (sum, sum of squares) at the benchmark batch -- many tiles
+    per workgroup, both consumer sets busy -- against a float64 reduction of its own output, tile by tile, and run to
+    run.  (A build in which this kernel carried three more epilogue variants, 190 spilled SGPRs instead of 64, produced
+    wrong and run-to-run different partials in lanes 16-31 here while every small-shape test stayed green.)"""
+    from deep_calcium_amd._lib import lib
+    L = lib()
+    Nb = 16
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn(Nb, HW, HW, Ci, device='cuda', generator=g)
+    K = torch.randn(3, 3, Ci, Co, device='cuda', generator=g) * 0.05
+    b = torch.randn(Co, device='cuda', generator=g)
+    wp = torch.empty(L.dc_pack_weights_f16x3_floats(9, Ci, Co), device='cuda')
+    L.dc_pack_weights_f16x3(K.data_ptr(), wp.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
+    tiles = L.dc_conv3x3_tiles(Nb, HW, HW, Co)
+    z = torch.empty(Nb, HW, HW, Co, device='cuda')
+    outs = []
+    for _ in range(3):
+        stats = torch.full((tiles * Co * 2,), float('nan'), dtype=torch.float64, device='cuda')
+        L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, stats.data_ptr(), None, None, 0, None, 0,
+                               None, 0, Nb, HW, HW, Ci, Co, None)
+        torch.cuda.synchronize()
+        outs.append(stats.cpu().numpy().reshape(tiles, Co, 2))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    zz = z.cpu().numpy().astype(np.float64)
+    assert tiles == Nb * (HW // 8) * (HW // 32)
+    ref = np.stack([_tile_sums(zz, 8, Co), _tile_sums(zz * zz, 8, Co)], axis=2)
+    assert np.abs(outs[0][..., 0] - ref[..., 0]).max() < 1e-5 * np.abs(ref[..., 0]).max()
+    assert np.abs(outs[0][..., 1] - ref[..., 1]).max() < 1e-5 * np.abs(ref[..., 1]).max()
+
+
+@pytest.mark.parametrize('HW,Cin,Cout', [(256, 64, 64), (512, 32, 32), (64, 256, 256)])
+def test_dgrad_bn_backward_sums_per_tile_at_batch_16(HW, Cin, Cout):
+    """dc_conv3x3_dgrad_bnred_f16x3 at the benchmark batch: the partial (sum dy, sum dy*xhat) of every tile against a
+    float64 reduction of the data gradient it wrote (gate = sign of the exact fmaf argument), and run to run."""
+    from deep_calcium_amd._lib import lib
+    L = lib()
+    Nb = 16
+    rows = L.dc_conv3x3_dgrad_bnred_blocks(Nb, HW, HW, Cin, Cout)
+    TH = 16 if Cin <= 32 else 8
+    assert rows == Nb * (HW // TH) * (HW // 32)
+    g = torch.Generator(device='cuda').manual_seed(4)
+    dz = torch.randn(Nb, HW, HW, Cout, device='cuda', generator=g)
+    K = torch.randn(3, 3, Cin, Cout, device='cuda', generator=g) * 0.05
+    wpd = torch.empty(L.dc_pack_weights_f16x3_floats(9, Cout, Cin), device='cuda')
+    L.dc_pack_weights_f16x3(K.data_ptr(), wpd.data_ptr(), 9, Cout, Cin, Cin * Cout, 1, Cout, 1, None)
+    z = torch.randn(Nb, HW, HW, Cin, device='cuda', generator=g)
+    mu = torch.randn(Cin, device='cuda', generator=g) * 0.2
+    isd = torch.rand(Cin, device='cuda', generator=g) + 0.5
+    ga = torch.randn(Cin, device='cuda', generator=g)
+    be = torch.randn(Cin, device='cuda', generator=g) * 0.3
+    scale = torch.full((4,), 4.0, device='cuda')
+    dx = torch.empty(Nb, HW, HW, Cin, device='cuda')
+    outs = []
+    for _ in range(3):
+        part = torch.full((rows * Cin * 2,), float('nan'), device='cuda')
+        L.dc_conv3x3_dgrad_bnred_f16x3(dz.data_ptr(), wpd.data_ptr(), dx.data_ptr(), scale.data_ptr(), z.data_ptr(), mu.data_ptr(),
+                                       isd.data_ptr(), ga.data_ptr(), be.data_ptr(), part.data_ptr(), Nb, HW, HW, Cin, Cout, None)
+        torch.cuda.synchronize()
+        outs.append(part.cpu().numpy().reshape(rows, Cin, 2))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    dxa, za = dx.cpu().numpy().astype(np.float64), z.cpu().numpy().astype(np.float64)
+    mu64, is64 = mu.cpu().numpy().astype(np.float64), isd.cpu().numpy().astype(np.float64)
+    sc = (ga * isd).cpu().numpy()                                                   # dc_bn_affine: fp32 product, then ONE fmaf
+    sh = (be.cpu().numpy().astype(np.float64) - mu64 * sc.astype(np.float64)).astype(np.float32)
+    gate = (za * sc.astype(np.float64) + sh.astype(np.float64)) > 0
+    dy = np.where(gate, dxa, 0.0)
+    ref = np.stack([_tile_sums(dy, TH, Cin), _tile_sums(dy * (za - mu64) * is64, TH, Cin)], axis=2)
+    assert np.abs(outs[0] - ref).max() < 1e-5 * np.abs(ref).max()

@@ -524,6 +524,59 @@ def test_maxpool_bit_exact_with_ties(dclib, N, H, W, C):
     assert np.array_equal(dx.cpu().numpy(), on.maxpool2x2_bwd(dy, i_ref))
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 64, 64, 64, 64), (1, 40, 72, 48, 80), (2, 48, 48, 32, 32), (1, 32, 32, 128, 256), (3, 33, 50, 64, 96)])
+def test_dgrad_with_fused_bn_backward_sums(dclib, N, H, W, Cin, Cout):
+    """dc_conv3x3_dgrad_bnred_f16x3: the data gradient is the plain kernel's bit for bit, and the BatchNorm-backward sums
+    it emits for the layer in front (gate from that layer's own affine, xhat from its statistics) finalize to what
+    dc_bn_bwd_reduce gives on the same da / z -- interior and ragged tiles, 2- / 3- / many-step tiles, both tile shapes."""
+    L = dclib
+    rows = L.dc_conv3x3_dgrad_bnred_blocks(N, H, W, Cin, Cout)
+    assert rows > 0
+    rs = np.random.RandomState(Cin + H)
+    dz = dev(rs.standard_normal((N, H, W, Cout)).astype(np.float32))
+    K = dev((rs.standard_normal((3, 3, Cin, Cout)) * 0.05).astype(np.float32))
+    wpd = torch.empty(L.dc_pack_weights_f16x3_floats(9, Cout, Cin), device='cuda')
+    L.dc_pack_weights_f16x3(K.data_ptr(), wpd.data_ptr(), 9, Cout, Cin, Cin * Cout, 1, Cout, 1, None)
+    z = dev(rs.standard_normal((N, H, W, Cin)).astype(np.float32))
+    mu = dev((rs.standard_normal(Cin) * 0.2).astype(np.float32)); isd = dev((rs.random_sample(Cin) + 0.5).astype(np.float32))
+    ga = dev((rs.standard_normal(Cin)).astype(np.float32)); be = dev((rs.standard_normal(Cin) * 0.3).astype(np.float32))
+    scale = torch.full((4,), 4.0, device='cuda')
+    dx0 = torch.full((N, H, W, Cin), float('nan'), device='cuda'); dx1 = torch.full_like(dx0, float('nan'))
+    L.dc_conv3x3_dgrad_f16x3(dz.data_ptr(), wpd.data_ptr(), dx0.data_ptr(), scale.data_ptr(), N, H, W, Cin, Cout, None)
+    part = torch.full((rows * Cin * 2,), float('nan'), device='cuda')
+    L.dc_conv3x3_dgrad_bnred_f16x3(dz.data_ptr(), wpd.data_ptr(), dx1.data_ptr(), scale.data_ptr(), z.data_ptr(), mu.data_ptr(),
+                                   isd.data_ptr(), ga.data_ptr(), be.data_ptr(), part.data_ptr(), N, H, W, Cin, Cout, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(dx0.cpu().numpy(), dx1.cpu().numpy())
+    assert np.isfinite(part.cpu().numpy()).all()
+    pixels = N * H * W
+    todo = [(part, rows)]
+    if Cin & (Cin - 1) == 0:             # (the two-pass kernel takes power-of-two channel counts only)
+        blocks = L.dc_bn_bwd_blocks(pixels, Cin)
+        p2 = torch.zeros(blocks * Cin * 2, device='cuda')
+        L.dc_bn_bwd_reduce(dx0.data_ptr(), Cin, z.data_ptr(), mu.data_ptr(), isd.data_ptr(), ga.data_ptr(), be.data_ptr(), None, 1.0, 0,
+                           p2.data_ptr(), pixels, Cin, None)
+        todo.append((p2, blocks))
+    out = []
+    for ptr, r in todo:
+        dg, db = torch.zeros(Cin, device='cuda'), torch.zeros(Cin, device='cuda')
+        L.dc_bn_bwd_finalize(ptr.data_ptr(), r, Cin, dg.data_ptr(), db.data_ptr(), None)
+        torch.cuda.synchronize()
+        out.append((dg.cpu().numpy().astype(np.float64), db.cpu().numpy().astype(np.float64)))
+    # float64 reference of the sums
+    dxa, za = dx0.cpu().numpy().astype(np.float64).reshape(-1, Cin), z.cpu().numpy().astype(np.float64).reshape(-1, Cin)
+    sc = (ga.cpu().numpy() * isd.cpu().numpy()).astype(np.float32)               # dc_bn_affine: fp32 product, then ONE fmaf
+    sh = (be.cpu().numpy().astype(np.float64) - mu.cpu().numpy().astype(np.float64) * sc.astype(np.float64)).astype(np.float32)
+    gate = (za * sc.astype(np.float64) + sh.astype(np.float64)) > 0                 # the sign of the exact fmaf argument
+    dy = np.where(gate, dxa, 0.0)
+    ref_db = dy.sum(0)
+    ref_dg = (dy * (za - mu.cpu().numpy().astype(np.float64)) * isd.cpu().numpy().astype(np.float64)).sum(0)
+    tol = 2e-5 * max(np.abs(ref_dg).max(), np.abs(ref_db).max())
+    for dg, db in out:
+        assert np.abs(dg - ref_dg).max() < tol and np.abs(db - ref_db).max() < tol
+    assert L.dc_conv3x3_dgrad_bnred_blocks(2, 16, 16, 64, 64) == 0          # narrow layers stay on the two-pass path
+
+
 @pytest.mark.parametrize('C,pixels,kind,bnin', [(32, 5000, 0, True), (8, 777, 1, True), (4, 64, 0, False), (64, 4097, 0, True), (16, 300, 1, False)])
 def test_head_fused_forward_backward_equals_separate_calls(dclib, C, pixels, kind, bnin):
     """dc_head_fwd_bwd (training with a per-pixel loss) against dc_head_fwd followed by dc_head_bwd(_bnin_bnred): p, da
