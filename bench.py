@@ -193,7 +193,7 @@ def bench_infer(args, model, xd, rank, world):
         return
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     kname, peak, mpf = KernelTimer.KERNELS[eng.mfma]
-    print(json.dumps({
+    emit_json(json.dumps({
         'metric': '512x512 summary images/sec (forward only)', 'value': round(world * B * args.steps / dt, 2),
         'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -240,7 +240,7 @@ def bench_tta(args, model, rank):
         api.predict(paths, mpath, augmentation=False)
     torch.cuda.synchronize()
     dt_plain = time.perf_counter() - t1
-    print(json.dumps({
+    emit_json(json.dumps({
         'metric': '512x512 forwards/sec through UNet2DSummary.predict with 8x test-time augmentation',
         'value': round(19 * 8 * steps / dt, 2), 'unit': 'forwards/s', 'n_gpus': 1, 'steps': steps, 'warmup': max(1, args.warmup // 3),
         'ms_per_step': round(dt / steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -253,10 +253,33 @@ def bench_tta(args, model, rank):
     shutil.rmtree(tmp, ignore_errors=True)
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """From here on fd 1 of this process IS stderr: whatever a native library (RCCL, Gloo, the HIP runtime) prints to
+    stdout cannot land next to the one JSON line, which goes out through a private duplicate of the original stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(line):
+    data = (line + '\n').encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line + '\n')
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) from THIS process,
     which has not touched the GPU (no HIP call, only a device count), wait for them and return their exit code.
-    Rank 0 inherits stdout (it prints the JSON line); the other ranks' stdout goes to stderr."""
+    Rank 0's stdout is piped through this process: the JSON line goes to stdout, anything else a native library prints
+    there (Gloo / RCCL banners) goes to stderr with the other ranks' output -- stdout carries exactly ONE line."""
     import socket
     import subprocess
     import torch
@@ -279,7 +302,19 @@ def launch_ranks(n):
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
-                                      stdout=None if r == 0 else sys.stderr))
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    json_lines = []
+
+    def pump(stream):
+        for raw in iter(stream.readline, b''):
+            line = raw.decode('utf8', 'replace')
+            if line.lstrip().startswith('{"metric"'):
+                json_lines.append(line.rstrip('\n'))
+            else:
+                sys.stderr.write(line)
+    th = threading.Thread(target=pump, args=(procs[0].stdout,), daemon=True)
+    th.start()
     rc = 0
     try:
         while procs:
@@ -296,6 +331,10 @@ def launch_ranks(n):
     finally:
         for q in procs:
             q.kill()
+    th.join(timeout=10)
+    for line in json_lines:
+        print(line)
+    sys.stdout.flush()
     return rc
 
 
@@ -320,6 +359,7 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args.gpus))         # before anything in this process touches the GPU
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    claim_stdout()
 
     import torch
     from deep_calcium_amd import parallel
@@ -434,7 +474,7 @@ def main():
             out['allreduce_buckets'] = 1 if os.environ.get('DC_AR_BUCKETS', '3') == '1' else 3
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
+        emit_json(json.dumps(out))
 
 
 if __name__ == '__main__':
