@@ -64,3 +64,29 @@ def test_product_never_imports_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
+
+
+def test_role_split_kernels_stay_below_the_sgpr_spill_cliff(tmp_path):
+    """hipcc 7.0 / gfx950: with three more epilogue variants compiled into igemm_pp_kernel the compiler spilled 186-196
+    SGPRs to VGPR lanes (60-64 today) and the kernel computed wrong, run-to-run different BatchNorm partials at batch 16
+    (DESIGN 5c).  The variants are separate instantiations now; this keeps an edit from walking back over that cliff
+    unnoticed on the CPU box (the full-size GPU tests are the real check)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, 'deep_calcium_amd', 'csrc', 'igemm_pp.hip')
+    out = str(tmp_path / 'pp.s')
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-x', 'hip', '-S', '--cuda-device-only', src, '-o', out],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(out).read()
+    names = re.findall(r'\.name:\s+(_Z15igemm_pp_kernel\w+)\n', text)
+    spills = [int(x) for x in re.findall(r'\.sgpr_spill_count:\s+(\d+)', text)]
+    scratch = [int(x) for x in re.findall(r'; ScratchSize: (\d+)', text)]
+    assert len(spills) >= 4 and len(set(names)) >= 4, (names, spills)
+    assert max(spills) <= 72, spills            # verified good at 53-64; broken at 186-196
+    assert all(s == 0 for s in scratch), scratch
