@@ -152,12 +152,13 @@ def _tile_sums(a, TH, C):
     return a.reshape(n, h // TH, TH, w // 32, 32, C).sum(axis=(2, 4)).reshape(-1, C)
 
 
-@pytest.mark.parametrize('HW,Ci,Co', [(256, 64, 64), (64, 256, 256)])
+@pytest.mark.parametrize('HW,Ci,Co', [(256, 64, 64), (64, 256, 256), (512, 32, 32), (256, 32, 64)])
 def test_role_split_kernel_moments_per_tile_at_batch_16(HW, Ci, Co):
     """The persistent kernel's per-tile BatchNorm partials (sum, sum of squares) at the benchmark batch -- many tiles
     per workgroup, both consumer sets busy -- against a float64 reduction of its own output, tile by tile, and run to
     run.  (A build in which this kernel carried three more epilogue variants, 190 spilled SGPRs instead of 64, produced
-    wrong and run-to-run different partials in lanes 16-31 here while every small-shape test stayed green.)"""
+    wrong and run-to-run different partials in lanes 16-31 here while every small-shape test stayed green.)  The two
+    32-input-channel shapes run on the 256-thread kernel (one of its instantiations carries 174 spilled SGPRs)."""
     from deep_calcium_amd._lib import lib
     L = lib()
     Nb = 16
@@ -178,8 +179,9 @@ def test_role_split_kernel_moments_per_tile_at_batch_16(HW, Ci, Co):
         outs.append(stats.cpu().numpy().reshape(tiles, Co, 2))
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
     zz = z.cpu().numpy().astype(np.float64)
-    assert tiles == Nb * (HW // 8) * (HW // 32)
-    ref = np.stack([_tile_sums(zz, 8, Co), _tile_sums(zz * zz, 8, Co)], axis=2)
+    TH = 16 if Co <= 32 else 8
+    assert tiles == Nb * (HW // TH) * (HW // 32)
+    ref = np.stack([_tile_sums(zz, TH, Co), _tile_sums(zz * zz, TH, Co)], axis=2)
     assert np.abs(outs[0][..., 0] - ref[..., 0]).max() < 1e-5 * np.abs(ref[..., 0]).max()
     assert np.abs(outs[0][..., 1] - ref[..., 1]).max() < 1e-5 * np.abs(ref[..., 1]).max()
 
