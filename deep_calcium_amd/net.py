@@ -177,10 +177,15 @@ class UNetEngine(object):
         if self.mfma not in ('f16x3', 'f32'):
             raise ValueError("mfma must be 'f16x3' or 'f32', got %r" % self.mfma)
         self.streams = 1 if os.environ.get('DC_STREAMS', '2') == '1' else 2     # 2: weight gradients on a side stream
-        # the weight gradient of a block starts when its data gradient has FINISHED: the role-split conv kernel owns a CU's
-        # whole LDS, so the two cannot share a CU anyway -- ordered this way the data gradient (critical path) never waits
-        # behind 256 persistent weight-gradient workgroups, and those overlap with the next block's BatchNorm passes
-        self.wgrad_after_dgrad = os.environ.get('DC_WGRAD_AFTER_DGRAD', '1') == '1'
+        # Backward schedule, DC_WGRAD_AFTER_DGRAD: 2 (default) = the weight gradient of a block starts when its data gradient
+        # has FINISHED wherever that data gradient runs on the role-split conv kernel -- it owns a CU's whole LDS, so the
+        # two cannot share a CU anyway, and ordered this way the critical path never queues behind 256 persistent
+        # weight-gradient workgroups -- and together with it elsewhere (conv-transpose, narrow layers: the 256-thread
+        # kernels co-reside); 1 = always after, 0 = always together.  Same-box: 840.6 / 838.7 / 843.0 images/s for 2 / 1 / 0,
+        # dominant-kernel launch 0.235 / 0.235 / 0.243 ms.
+        _order = os.environ.get('DC_WGRAD_AFTER_DGRAD', '2')
+        self.wgrad_after_dgrad = _order == '1'
+        self.wgrad_order_hybrid = _order == '2'
         self.dz_bufs = int(os.environ.get('DC_DZ_BUFS', '3'))
         # BN + ReLU on load: activations that only feed a conv / conv-transpose / the head (no dropout, pool or
         # skip) are never written; their consumers take (z, scale, shift) instead.  f16x3 kernels only.
@@ -1096,7 +1101,10 @@ class UNetEngine(object):
                 ready.record(main)
             # ---- main stream first: the data gradient feeds the next block ---------------------------------------
             wpd = _ptr(self.wp_dgrad[l.name]) if dx_ptr is not None else None
-            if dx_ptr is not None and self.wgrad_after_dgrad:
+            after = self.wgrad_after_dgrad
+            if self.wgrad_order_hybrid:
+                after = f16 and l.kind == 'conv' and L.dc_conv3x3_dgrad_bnred_blocks(N, h, w, l.cin, l.cout) > 0
+            if dx_ptr is not None and after:
                 fused_next = launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16, red)
                 if two:
                     ready = torch.cuda.Event()
@@ -1123,7 +1131,7 @@ class UNetEngine(object):
             if two:
                 self._dz_free[k] = torch.cuda.Event()
                 self._dz_free[k].record(side)
-            if dx_ptr is not None and not self.wgrad_after_dgrad:
+            if dx_ptr is not None and not after:
                 fused_next = launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16, red)
             return fused_next
 
