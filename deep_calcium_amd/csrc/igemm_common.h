@@ -34,6 +34,9 @@ struct IgemmParams {
   // dropout) -- the epilogue also reads that layer's pre-BN tensor bnZ (same layout) and emits its BatchNorm-backward
   // pass-1 partials bnPartial[tile][Ncols][2] = (sum dy, sum dy*xhat), dy = da * [fmaf(z, sc, sh) > 0] with (sc, sh) =
   // dc_bn_affine(mean, invstd, gamma, beta): what dc_bn_bwd_reduce would re-read da and z for.
+  // role-split kernel only, inference: the output also feeds MaxPooling2D((2,2)) -- the epilogue writes the pooled tensor
+  // [N][Hout/2][Wout/2][Ncols] (dense) next to the activation (same values, same maxima as dc_maxpool2x2_fwd on it)
+  float* poolOut;
   const float* bnZ;
   const float* bnMean;
   const float* bnInvstd;

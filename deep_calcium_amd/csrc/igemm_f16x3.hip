@@ -667,6 +667,37 @@ extern "C" int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* 
   return conv3x3_h_launch(p, (hipStream_t)stream);
 }
 
+// Inference convolution whose output also feeds MaxPooling2D((2,2)): role-split kernel only
+// (dc_conv3x3_fwd_pool_blocks() == 0: use dc_conv3x3_fwd_f16x3 + dc_maxpool2x2_fwd).
+static IgemmParams fwd_pool_params(const float* x, const void* wp16, const float* bias, float* z, long z_ld, const float* scale,
+                                   const float* shift, int relu, float* out_flag, float* pool, int N, int H, int W, int Cin,
+                                   int Cout) {
+  IgemmParams p{};
+  p.in = x; p.wp = reinterpret_cast<const float*>(wp16); p.bias = bias; p.out = z;
+  p.scale = scale; p.shift = shift; p.outAbsmax = out_flag; p.outAbsmaxLd = -1;
+  p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = Cout;
+  p.relu = relu; p.biasMod = Cout; p.outLd = z_ld; p.poolOut = pool;
+  return p;
+}
+extern "C" int dc_conv3x3_fwd_pool_blocks(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (H & 1) || (W & 1)) return 0;
+  static const bool off = getenv("DC_CONV_POOL") && atoi(getenv("DC_CONV_POOL")) == 0;
+  IgemmParams p = fwd_pool_params(nullptr, nullptr, nullptr, nullptr, Cout, nullptr, nullptr, 1, nullptr, nullptr, N, H, W, Cin, Cout);
+  if (off || !dc_igemm_pp_serves(p)) return 0;
+  return N * dc_cdiv(W, 32) * dc_cdiv(H, Cout <= 32 ? 16 : 8);
+}
+extern "C" int dc_conv3x3_fwd_pool_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld,
+                                         const float* scale, const float* shift, int relu, float* out_flag, float* pool,
+                                         int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
+  int rc = check_h("dc_conv3x3_fwd_pool_f16x3", x, wp16, z, N, H, W, Cin, Cout);
+  if (rc) return rc;
+  DC_REQUIRE(pool && z_ld >= Cout && (scale == nullptr) == (shift == nullptr), DC_EINVAL, "dc_conv3x3_fwd_pool_f16x3: bad arguments");
+  DC_REQUIRE(dc_conv3x3_fwd_pool_blocks(N, H, W, Cin, Cout) > 0, DC_EUNSUP,
+             "dc_conv3x3_fwd_pool_f16x3: shape not served (dc_conv3x3_fwd_pool_blocks() == 0): use the two-kernel path");
+  IgemmParams p = fwd_pool_params(x, wp16, bias, z, z_ld, scale, shift, relu, out_flag, pool, N, H, W, Cin, Cout);
+  return dc_igemm_pp_launch(p, (hipStream_t)stream, "conv3x3_fwd_pool_f16x3_pp");
+}
+
 // Data gradient that also emits the BatchNorm-backward pass-1 sums of the layer whose `da` it writes (role-split kernel
 // only: dc_conv3x3_dgrad_bnred_blocks() == 0 tells the caller to use dc_conv3x3_dgrad_f16x3 + dc_bn_bwd_reduce instead).
 static IgemmParams dgrad_bnred_params(const float* dz, const void* wp16, float* dx, const float* in_scale, int N, int H, int W,

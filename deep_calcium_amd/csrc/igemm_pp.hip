@@ -95,10 +95,12 @@ struct Item {          // one output tile x column block (wave-uniform)
 };
 }  // namespace pp
 
-// BNRED: the data-gradient variant that also emits the BatchNorm-backward sums of the layer it writes `da` of (its own
-// instantiation: the statistics / tracking epilogues are compiled out of it, and its code out of the other one)
-template <int MB_, int NB_, bool BNRED = false>
+// VARIANT 1 (BNRED): the data-gradient variant that also emits the BatchNorm-backward sums of the layer it writes `da` of.
+// VARIANT 2 (POOL): the inference variant whose output also feeds a 2x2 max-pool: the epilogue writes the pooled tensor
+// too.  Each is its own instantiation: the other epilogues are compiled out of it, and its code out of the base kernel.
+template <int MB_, int NB_, int VARIANT = 0>
 __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p) {
+  constexpr bool BNRED = VARIANT == 1, POOL = VARIANT == 2;
   using namespace pp;
   using C = Cfg<MB_, NB_>;
   constexpr int MB = C::MB, NB = C::NB, RPM = C::RPM, TH = C::TH, BN = C::BN, THI = C::THI, TWI = C::TWI, NPIXH = C::NPIXH;
@@ -380,14 +382,14 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
   // (mode 2), stores.  Slices run in the order (nb 0: mb 0, 1), (nb 1: mb 0, 1); the per-column shifted sums of a column
   // block live in four registers across its two slices and go to LDS after the second; the cross-wave merge of the tile's
   // partials happens one step later (merge_pending), whatever that step is for this set.
-  const int mode = BNRED ? 4 : (p.outAbsmax ? 2 : (p.stats ? 1 : 0));          // wave-uniform
+  const int mode = BNRED ? 4 : (p.outAbsmax ? 2 : ((p.stats && !POOL) ? 1 : 0));          // wave-uniform
   float e_s1 = 0.f, e_s2 = 0.f, e_cnt = 0.f, e_K = 0.f;
   auto epi_values = [&](auto nb_tag, auto mb_tag, auto interior_tag, auto mode_tag) __attribute__((always_inline)) {
     constexpr int nb = decltype(nb_tag)::value;
     constexpr int mb = decltype(mb_tag)::value;
     constexpr bool INT = decltype(interior_tag)::value;
     constexpr int MODE = decltype(mode_tag)::value;                 // border tiles (!INT): MODE == 3, resolved at run time
-    const bool m_stats = !BNRED && (MODE == 1 || (MODE == 3 && mode == 1)), m_track = !BNRED && (MODE == 2 || (MODE == 3 && mode == 2));
+    const bool m_stats = !BNRED && !POOL && (MODE == 1 || (MODE == 3 && mode == 1)), m_track = !BNRED && (MODE == 2 || (MODE == 3 && mode == 2));
     constexpr bool m_bnred = BNRED && (MODE == 4 || MODE == 3);
     const long out_img_floats = (long)p.Hout * p.Wout * p.outLd;
     const __amdgpu_buffer_rsrc_t rsrcO = dc_make_rsrc(p.out + (long)pend.img * out_img_floats, (unsigned)(out_img_floats * 4));
@@ -438,6 +440,29 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, off, 0, 0);
       }
     }
+    if constexpr (POOL && (mb & 1)) {
+      // 2x2 max-pool of the row pair (mb - 1, mb) of this wave: both blocks' accumulators are still here, registers
+      // (r, r + 1) of a lane are x-neighbours; the activations are re-formed with the store loop's own expressions
+      const long pool_img_floats = (long)(p.Hout >> 1) * (p.Wout >> 1) * p.Ncols;
+      const __amdgpu_buffer_rsrc_t rsrcP = dc_make_rsrc(p.poolOut + (long)pend.img * pool_img_floats, (unsigned)(pool_img_floats * 4));
+      const int py = (oyb - RPM) >> 1;                                  // RPM == 1: block rows mb - 1 and mb are y, y + 1
+      auto act = [&](float a) __attribute__((always_inline)) {
+        float v = __builtin_fmaf(a, out_scale, bv);
+        if (p.scale) v = v * sc + sh;
+        if (p.relu) v = fmaxf(v, 0.f);
+        return v;
+      };
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int mr = (r & 3) + 8 * (r >> 2);
+        const int colc = mr % TW;
+        const float m0 = fmaxf(act(acc[mb - 1][nb][r]), act(acc[mb - 1][nb][r + 1]));
+        const float m1 = fmaxf(act(acc[mb][nb][r]), act(acc[mb][nb][r + 1]));
+        const bool ok = INT || (n_ok && oyb < p.Hout && (oxb + colc + 1) < p.Wout);
+        const unsigned off = ok ? (unsigned)(((py * (p.Wout >> 1) + ((oxb + colc) >> 1)) * p.Ncols + n) * 4) : OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(m0, m1)), rsrcP, off, 0, 0);
+      }
+    }
     if (m_bnred) {
       const float mu = lds_sc[nl], is = lds_sc[EP_COLS + nl];
 #pragma unroll
@@ -484,7 +509,7 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
   bool merge_pending = false;
   Item mitem = {0, 0, 0, 0, 0};
   auto epi_merge = [&]() __attribute__((always_inline)) {      // the red[] entries of both column blocks are complete
-    if (!BNRED && mode == 1) {
+    if (!BNRED && !POOL && mode == 1) {
       const int ts = tid & 255;                                 // thread within the consumer set
       if (ts < NB * 32) {
         const int nb = ts / 32, l = ts % 32;
@@ -523,7 +548,7 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
         else epi_values(nb_tag, mb_tag, std::false_type{}, T3{});
       } else if (interior) {
         if (mode == 0) epi_values(nb_tag, mb_tag, std::true_type{}, T0{});
-        else if (mode == 1) epi_values(nb_tag, mb_tag, std::true_type{}, T1{});
+        else if (!POOL && mode == 1) epi_values(nb_tag, mb_tag, std::true_type{}, T1{});
         else epi_values(nb_tag, mb_tag, std::true_type{}, T2{});
       } else {
         epi_values(nb_tag, mb_tag, std::false_type{}, T3{});
@@ -604,10 +629,11 @@ bool dc_igemm_pp_serves(const IgemmParams& p) {
          !(p.outAbsmax && p.outAbsmaxLd >= 0) && p.Cin <= 1024 && p.Ncols <= pp::EP_COLS && total >= 8;
 }
 
-template <int MB_, int NB_, bool BNRED>
+template <int MB_, int NB_, int VARIANT>
 static int pp_launch(IgemmParams p, hipStream_t st, const char* name) {
   using C = pp::Cfg<MB_, NB_>;
-  auto kern = igemm_pp_kernel<MB_, NB_, BNRED>;
+  static_assert(C::RPM == 1, "the pooled epilogue pairs block rows mb - 1, mb");
+  auto kern = igemm_pp_kernel<MB_, NB_, VARIANT>;
   static DcLdsAttr lds_attr;
   const int lds = C::FIXED_LDS + pp::TABLE_BYTES + 3 * pp::EP_COLS * 4;
   if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), lds, name)) return rc;
@@ -632,6 +658,7 @@ static int pp_launch(IgemmParams p, hipStream_t st, const char* name) {
 
 // same tile-shape choice as igemm_f16x3.hip's conv3x3 dispatch (and therefore the same BatchNorm-partial tile count)
 int dc_igemm_pp_launch(IgemmParams p, hipStream_t st, const char* name) {
-  if (p.bnPartial) return p.Ncols <= 32 ? pp_launch<4, 1, true>(p, st, name) : pp_launch<2, 2, true>(p, st, name);
-  return p.Ncols <= 32 ? pp_launch<4, 1, false>(p, st, name) : pp_launch<2, 2, false>(p, st, name);
+  if (p.bnPartial) return p.Ncols <= 32 ? pp_launch<4, 1, 1>(p, st, name) : pp_launch<2, 2, 1>(p, st, name);
+  if (p.poolOut) return p.Ncols <= 32 ? pp_launch<4, 1, 2>(p, st, name) : pp_launch<2, 2, 2>(p, st, name);
+  return p.Ncols <= 32 ? pp_launch<4, 1, 0>(p, st, name) : pp_launch<2, 2, 0>(p, st, name);
 }

@@ -196,6 +196,8 @@ class UNetEngine(object):
         self.pool_fused = os.environ.get('DC_POOL_FUSED', '1') == '1'
         # BCE-type losses: the head's backward is done by its forward kernel (dc_head_fwd_bwd)
         self.head_fused = os.environ.get('DC_HEAD_FUSED', '1') == '1'
+        # inference: the convolution in front of a max-pool writes the pooled tensor too (role-split kernel, POOL variant)
+        self.conv_pool = os.environ.get('DC_CONV_POOL', '1') == '1'
         # data gradients served by the role-split kernel also emit the BatchNorm-backward sums of the layer they feed
         self.dgrad_bnred = os.environ.get('DC_DGRAD_BNRED', '1') == '1'
         self._head_bwd_done = False
@@ -683,8 +685,13 @@ class UNetEngine(object):
                 self.abound.zero_()       # the conv epilogues fold the measured max |a| per channel into it
             else:
                 self._ovf.zero_()         # optimistic: they only raise this flag (forward_infer_checked looks at it)
-        for step in self._plan(A):
+        plan = self._plan(A)
+        pooled_by_conv = False
+        for si, step in enumerate(plan):
             if step[0] == 'pool':
+                if pooled_by_conv:             # the convolution's epilogue has written the pooled tensor
+                    pooled_by_conv = False
+                    continue
                 _, lvl, src, coff, ld, h, w = step
                 L.dc_maxpool2x2_fwd(_ptr(src, coff), ld, _ptr(A['pool%d' % lvl]), None, N, h, w, self.nfb << lvl, st)
                 continue
@@ -700,6 +707,16 @@ class UNetEngine(object):
                 L.dc_conv3x3_c1_fwd(_ptr(x_dev), self.pview(self.pflat, l, 'k'), None, _ptr(dst, coff), ld, None,
                                     sc, sh, 1, *self._ab_infer(l)[2:], N, h, w, l.cout, st)
             elif l.kind == 'conv':
+                nxt = plan[si + 1] if si + 1 < len(plan) else None
+                if (self.conv_pool and self.mfma == 'f16x3' and not (self.range_guard and self.infer_measured)
+                        and nxt is not None and nxt[0] == 'pool' and nxt[2] is dst and nxt[3] == coff
+                        and L.dc_conv3x3_fwd_pool_blocks(N, h, w, l.cin, l.cout) > 0):
+                    # the block in front of a max-pool: activation (into the concat buffer) and pooled tensor in one kernel
+                    flag = self._ovf.data_ptr() if self.range_guard else None
+                    L.dc_conv3x3_fwd_pool_f16x3(_ptr(src), _ptr(self.wp_fwd[l.name]), None, _ptr(dst, coff), ld, sc, sh, 1, flag,
+                                                _ptr(A['pool%d' % nxt[1]]), N, h, w, l.cin, l.cout, st)
+                    pooled_by_conv = True
+                    continue
                 self._conv_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h, w, st, measured=True)
             else:
                 self._convT_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h // 2, w // 2, st, measured=True)

@@ -205,6 +205,14 @@ int dc_pow2_scale_from_absmax(const float* partial, int n, float target, float* 
 int dc_bn_bwd_apply_finalize(const float* dbias_partial, const float* absmax_partial, int blocks, int C, float target,
                              float* dbias, float* scale, dc_stream_t stream);
 
+/* ---- inference: Conv2D -> (folded BN) -> ReLU whose output also feeds MaxPooling2D((2,2)) ----------------------------
+ * dc_conv3x3_fwd_f16x3 (optimistic range flag out_flag, nullable) that also writes pool [N,H/2,W/2,Cout] = what
+ * dc_maxpool2x2_fwd gives on z.  dc_conv3x3_fwd_pool_blocks() == 0: shape not served, use the two kernels. */
+int dc_conv3x3_fwd_pool_blocks(int N, int H, int W, int Cin, int Cout);
+int dc_conv3x3_fwd_pool_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld,
+                              const float* scale, const float* shift, int relu, float* out_flag, float* pool,
+                              int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+
 /* ---- BatchNorm-backward sums fused into the kernel that PRODUCES da ("bnred") -------------------------------
  * The kernel that writes da of a BatchNorm layer also emits that layer's pass-1 partial sums
  * bn_partial[blocks][C][2] = (sum dy, sum dy*xhat), dy = da * [relu gate] * dropout, so dc_bn_bwd_reduce (and its

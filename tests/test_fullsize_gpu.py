@@ -224,3 +224,34 @@ def test_dgrad_bn_backward_sums_per_tile_at_batch_16(HW, Cin, Cout):
     dy = np.where(gate, dxa, 0.0)
     ref = np.stack([_tile_sums(dy, TH, Cin), _tile_sums(dy * (za - mu64) * is64, TH, Cin)], axis=2)
     assert np.abs(outs[0] - ref).max() < 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('HW,Ci,Co', [(512, 32, 32), (256, 64, 64), (64, 256, 256)])
+def test_inference_conv_with_pooled_output_at_batch_8(HW, Ci, Co):
+    """The POOL variant of the role-split kernel at the inference benchmark's batch: activation and pooled tensor equal the
+    two-kernel path bit for bit, and repeat run to run."""
+    from deep_calcium_amd._lib import lib
+    L = lib()
+    Nb = 8
+    assert L.dc_conv3x3_fwd_pool_blocks(Nb, HW, HW, Ci, Co) > 0
+    g = torch.Generator(device='cuda').manual_seed(8)
+    x = torch.randn(Nb, HW, HW, Ci, device='cuda', generator=g)
+    K = torch.randn(3, 3, Ci, Co, device='cuda', generator=g) * 0.06
+    wp = torch.empty(L.dc_pack_weights_f16x3_floats(9, Ci, Co), device='cuda')
+    L.dc_pack_weights_f16x3(K.data_ptr(), wp.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
+    sc = torch.rand(Co, device='cuda', generator=g) + 0.5
+    sh = torch.randn(Co, device='cuda', generator=g) * 0.4
+    z0 = torch.empty(Nb, HW, HW, Co, device='cuda')
+    p0 = torch.empty(Nb, HW // 2, HW // 2, Co, device='cuda')
+    flag = torch.zeros(4, device='cuda')
+    L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), None, z0.data_ptr(), Co, None, sc.data_ptr(), sh.data_ptr(), 1, None, 0,
+                           flag.data_ptr(), -1, Nb, HW, HW, Ci, Co, None)
+    L.dc_maxpool2x2_fwd(z0.data_ptr(), Co, p0.data_ptr(), None, Nb, HW, HW, Co, None)
+    for _ in range(3):
+        z1 = torch.full_like(z0, float('nan'))
+        p1 = torch.full_like(p0, float('nan'))
+        L.dc_conv3x3_fwd_pool_f16x3(x.data_ptr(), wp.data_ptr(), None, z1.data_ptr(), Co, sc.data_ptr(), sh.data_ptr(), 1, flag.data_ptr(),
+                                    p1.data_ptr(), Nb, HW, HW, Ci, Co, None)
+        torch.cuda.synchronize()
+        assert torch.equal(z0, z1) and torch.equal(p0, p1)
+    assert float(flag[0].item()) == 0.0

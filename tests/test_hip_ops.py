@@ -577,6 +577,38 @@ def test_dgrad_with_fused_bn_backward_sums(dclib, N, H, W, Cin, Cout):
     assert L.dc_conv3x3_dgrad_bnred_blocks(2, 16, 16, 64, 64) == 0          # narrow layers stay on the two-pass path
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 64, 64, 64, 64), (1, 40, 72, 48, 80), (2, 48, 64, 32, 32), (8, 128, 128, 64, 128), (3, 34, 50, 64, 96)])
+def test_inference_conv_with_pooled_output_equals_conv_then_pool(dclib, N, H, W, Cin, Cout):
+    """dc_conv3x3_fwd_pool_f16x3 (folded BN + ReLU, optimistic range flag) == dc_conv3x3_fwd_f16x3 followed by
+    dc_maxpool2x2_fwd on its (strided) output, bit for bit -- interior and ragged tiles, both tile shapes."""
+    L = dclib
+    assert L.dc_conv3x3_fwd_pool_blocks(N, H, W, Cin, Cout) > 0
+    rs = np.random.RandomState(H + Cout)
+    x = dev(rs.standard_normal((N, H, W, Cin)).astype(np.float32))
+    K = dev((rs.standard_normal((3, 3, Cin, Cout)) * 0.06).astype(np.float32))
+    wp = torch.empty(L.dc_pack_weights_f16x3_floats(9, Cin, Cout), device='cuda')
+    L.dc_pack_weights_f16x3(K.data_ptr(), wp.data_ptr(), 9, Cin, Cout, Cin * Cout, Cout, 1, 0, None)
+    sc = dev((rs.random_sample(Cout) + 0.5).astype(np.float32)); sh = dev((rs.standard_normal(Cout) * 0.4).astype(np.float32))
+    ld = 2 * Cout
+    outs = []
+    for fused in (False, True):
+        cat = torch.zeros((N, H, W, ld), device='cuda')
+        pool = torch.full((N, H // 2, W // 2, Cout), float('nan'), device='cuda')
+        flag = torch.zeros(4, device='cuda')
+        if fused:
+            L.dc_conv3x3_fwd_pool_f16x3(x.data_ptr(), wp.data_ptr(), None, cat.data_ptr() + 4 * Cout, ld, sc.data_ptr(), sh.data_ptr(), 1,
+                                        flag.data_ptr(), pool.data_ptr(), N, H, W, Cin, Cout, None)
+        else:
+            L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), None, cat.data_ptr() + 4 * Cout, ld, None, sc.data_ptr(), sh.data_ptr(), 1,
+                                   None, 0, flag.data_ptr(), -1, N, H, W, Cin, Cout, None)
+            L.dc_maxpool2x2_fwd(cat.data_ptr() + 4 * Cout, ld, pool.data_ptr(), None, N, H, W, Cout, None)
+        torch.cuda.synchronize()
+        outs.append((cat.cpu().numpy(), pool.cpu().numpy(), flag.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    assert np.isfinite(outs[1][1]).all() and (outs[1][1] > 0).any() and (outs[1][0][..., :Cout] == 0).all()
+    assert L.dc_conv3x3_fwd_pool_blocks(2, 16, 16, 64, 64) == 0 and L.dc_conv3x3_fwd_pool_blocks(2, 63, 64, 64, 64) == 0
+
+
 @pytest.mark.parametrize('C,pixels,kind,bnin', [(32, 5000, 0, True), (8, 777, 1, True), (4, 64, 0, False), (64, 4097, 0, True), (16, 300, 1, False)])
 def test_head_fused_forward_backward_equals_separate_calls(dclib, C, pixels, kind, bnin):
     """dc_head_fwd_bwd (training with a per-pixel loss) against dc_head_fwd followed by dc_head_bwd(_bnin_bnred): p, da
