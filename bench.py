@@ -39,10 +39,10 @@ class KernelTimer(object):
     # dc_conv3x3_dgrad* whenever W > 16 and the output has > 32 columns: the persistent role-split kernel of
     # csrc/igemm_pp.hip (Cin a multiple of 16, >= 64; the 256-thread igemm_f16x3_kernel<3,3,1,1,32,4,2,2,16> serves the one
     # Cin = 32 training-forward launch of that shape; the data gradients that also emit BatchNorm-backward sums run its
-    # <2,2,true> instantiation through dc_conv3x3_dgrad_bnred_f16x3 and are not counted here), csrc/igemm_conv.hip for
+    # <2,2,1> instantiation through dc_conv3x3_dgrad_bnred_f16x3 and are not counted here), csrc/igemm_conv.hip for
     # mfma='f32'.
     KERNELS = {
-        'f16x3': ('igemm_pp_kernel<2,2,false>', PEAK_FP16_MFMA_TFLOPS, 3),
+        'f16x3': ('igemm_pp_kernel<2,2,0>', PEAK_FP16_MFMA_TFLOPS, 3),
         'f32': ('igemm_kernel<3,3,1,1,32,4,2,2,16>', PEAK_FP32_MFMA_TFLOPS, 1),
     }
     # entry point -> which channel count is the GEMM column count (every one ends with N, H, W, Cin, Cout, stream)
