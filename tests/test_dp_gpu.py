@@ -107,3 +107,33 @@ def test_shard_dropout_seed_reproduces_single_device_masks():
         part = run(z[r * per:(r + 1) * per].contiguous(), parallel.shard_drop_seed(seed, per * h * w * C, r))
         assert np.array_equal(part, full[r * per:(r + 1) * per])
     assert not np.array_equal(run(z[per:].contiguous(), seed), full[per:])      # without the offset the masks repeat
+
+
+def test_bench_default_line_schema():
+    """`python bench.py` (N = 1): ONE JSON line on stdout with every field of the driver's contract, the roofline object of
+    the dominant kernel and the CPU baseline."""
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1'], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in out, k
+    assert out['n_gpus'] == 1 and out['steps'] == 3 and out['warmup'] == 1 and out['scaling'] == 'weak'
+    assert out['unit'] == 'images/s' and out['higher_is_better'] is True and out['vs_baseline'] is None
+    assert out['dtype'] == 'f32' and out['data'] == 'synthetic' and 'workload' in out['config'] and 'model' not in out['config']
+    assert abs(out['value'] - 16 * 1000.0 / out['ms_per_step']) < 0.01 * out['value']
+    rf = out['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in rf, k
+    assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and rf['peak'] == 2500.0
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3 and 0.05 < rf['frac'] < 0.25
+    assert rf['traffic'] is None or rf['traffic'] > 1e8
+    cb = out['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in cb, k
+    assert cb['kind'] == 'port' and cb['unit'] == 'images/s' and cb['value'] > 0 and cb['cores'] >= 1
