@@ -458,7 +458,17 @@ static int conv3x3_h_launch(IgemmParams p, hipStream_t st) {
     if (p.Ncols <= 32) return igemm_h_launch<3, 3, 1, 1, 32, 4, 4, 1>(p, st, "conv3x3_f16x3");
     return igemm_h_launch<3, 3, 1, 1, 32, 4, 2, 2>(p, st, "conv3x3_f16x3");
   }
-  if (p.Wout > 8) return igemm_h_launch<3, 3, 1, 1, 16, 4, 2, 2>(p, st, "conv3x3_f16x3");
+  // The narrow layers at small batch x window (the reference's 128^2 x 20 training configuration: 16^2 and 8^2 images at
+  // 256 / 512 channels) give 80 workgroups of 64 / 128 columns: half-width column blocks double the workgroups -- same
+  // pixel tiles, so the BatchNorm-partial tile count does not change.
+  static const bool narrow = !(getenv("DC_NARROW_COLS") && atoi(getenv("DC_NARROW_COLS")) == 0);
+  if (p.Wout > 8) {
+    const long wgs = (long)p.N * dc_cdiv(p.Wout, 16) * dc_cdiv(p.Hout, 16) * dc_cdiv(p.Ncols, 64);
+    if (narrow && wgs < 256 && p.Ncols > 32) return igemm_h_launch<3, 3, 1, 1, 16, 4, 2, 1>(p, st, "conv3x3_f16x3");
+    return igemm_h_launch<3, 3, 1, 1, 16, 4, 2, 2>(p, st, "conv3x3_f16x3");
+  }
+  const long wgs = (long)p.N * dc_cdiv(p.Wout, 8) * dc_cdiv(p.Hout, 8) * dc_cdiv(p.Ncols, 128);
+  if (narrow && wgs < 256 && p.Ncols > 64) return igemm_h_launch<3, 3, 1, 1, 8, 2, 1, 1>(p, st, "conv3x3_f16x3");
   return igemm_h_launch<3, 3, 1, 1, 8, 2, 1, 2>(p, st, "conv3x3_f16x3");
 }
 
