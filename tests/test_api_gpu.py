@@ -222,13 +222,14 @@ def test_example_script_trains_by_name_from_a_neurofinder_directory(tmp_path):
 
 
 @pytest.mark.parametrize('aug', [True, False])
-def test_pipelined_predict_equals_one_by_one(aug):
+def test_pipelined_predict_equals_one_by_one(aug, monkeypatch):
     """The enqueue-all-then-synchronise path of predict() (engine.tta_begin) gives, for datasets of different sizes, the
     masks the per-dataset path gives -- with the 8x table and with the plain forward (identity map); a dataset whose
     activations leave fp16's range (un-normalised image) is flagged, redone with measured bounds, and the rest are kept."""
     from deep_calcium_amd.net import UNetEngine
     from deep_calcium_amd.unet2ds import INVERTIBLE_2D_AUGMENTATIONS
     from oracle import unet_numpy as on
+    monkeypatch.delenv('DC_INFER_GUARD', raising=False)        # the test is about the (default) optimistic mode
     H = W = 64
     nfb = 8
     Wt = on.init_weights(nfb, seed=9, randomize_bn=True)

@@ -249,12 +249,13 @@ def test_train_step_with_extreme_weights_matches_oracle(kscale, gscale):
 
 
 @pytest.mark.parametrize('xscale', [1e4, 1e-4])
-def test_inference_on_unnormalised_input(xscale):
+def test_inference_on_unnormalised_input(xscale, monkeypatch):
     """predict() on images that were NOT normalised (a custom series_summary_func): folded-BN activations of ~1e5 go
     through the measured-max range guard.  At that magnitude the logits are ~1e5 and fp32 itself resolves them to ~1e-2,
     so the yardstick is relative: every tapped activation within 2e-5 of the oracle's scale, the probabilities as close
     to the oracle as the library's own fp32-MFMA path (no fp16 anywhere) gets -- and no inf / nan."""
     from deep_calcium_amd.net import UNetEngine
+    monkeypatch.delenv('DC_INFER_GUARD', raising=False)        # starts in the (default) optimistic mode
     N, H, W, nfb = 2, 48, 48, 8
     Wt = on.init_weights(nfb, seed=5, randomize_bn=True)
     x, _ = on.synthetic_batch(N, H, W)
