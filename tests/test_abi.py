@@ -34,7 +34,7 @@ def test_host_side_helpers_run_without_gpu(dclib):
     assert L.dc_convT2x2_tiles(2, 32, 32, 256) == 2 * 4
     assert L.dc_conv3x3_wgrad_ws_floats(16, 512, 512, 32, 32) > 9 * 32 * 32
     assert L.dc_conv3x3_wgrad_ws_floats(2, 32, 32, 1, 32) > 0
-    assert L.dc_bn_bwd_blocks(16 * 512 * 512, 32) == 2048 and L.dc_head_blocks(100) == 1
+    assert L.dc_bn_bwd_blocks(16 * 512 * 512, 32) == 1280 and L.dc_head_blocks(100) == 1
 
 
 def test_argument_validation_returns_codes(dclib):
