@@ -29,6 +29,48 @@ NFB = 32
 
 
 PEAK_FP16_MFMA_TFLOPS = 2500.0    # same guide: dense fp16/bf16 matrix peak (the 2:1-sparse figure is not used)
+DTYPE_LABEL = {'f16x3': 'f32 (fp16x3 split, fp32 accumulate)', 'f32': 'f32'}
+
+
+def synthetic_batch(N, Hh, Ww, seed_x=865, seed_y=866, pos_rate=0.126):
+    """SURVEY 8(d) synthetic inputs: x ~ N(0,1) (the real pipeline feeds zero-mean / unit-std summary images,
+    /root/reference/deepcalcium/models/neurons/unet_2d_summary.py:239), y ~ Bernoulli(0.126)."""
+    x = np.random.RandomState(seed_x).standard_normal((N, Hh, Ww)).astype(np.float32)
+    y = (np.random.RandomState(seed_y).random_sample((N, Hh, Ww)) < pos_rate).astype(np.uint8)
+    return x, y
+
+
+class Watchdog(object):
+    """Per-rank hang detector: every phase of the run has a deadline; when one passes, the rank says which phase of which
+    rank hung and exits non-zero (a hard exit of THIS process -- never a re-exec), so that a launcher (bench.py's own
+    or torch.distributed.run) tears the job down instead of sitting in a collective until the driver's limit.
+    DC_BENCH_WATCHDOG_S = seconds allowed per train step (default 30; 0 disables)."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank, self.phase_name, self.deadline = rank, 'start', None
+        self.step_s = float(os.environ.get('DC_BENCH_WATCHDOG_S', '30'))
+        if self.step_s > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def phase(self, name, limit_s=None):
+        self.phase_name = name
+        self.deadline = time.time() + (limit_s if limit_s is not None else self.step_s)
+
+    tick = phase
+
+    def done(self):
+        self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            d = self.deadline
+            if d is not None and time.time() > d:
+                sys.stderr.write('bench.py watchdog: rank %d made no progress in phase %r within its limit -- exiting 17\n'
+                                 % (self.rank, self.phase_name))
+                sys.stderr.flush()
+                os._exit(17)
 
 
 class KernelTimer(object):
@@ -45,9 +87,11 @@ class KernelTimer(object):
         'f16x3': ('igemm_pp_kernel<2,2,0>', PEAK_FP16_MFMA_TFLOPS, 3),
         'f32': ('igemm_kernel<3,3,1,1,32,4,2,2,16>', PEAK_FP32_MFMA_TFLOPS, 1),
     }
-    # entry point -> which channel count is the GEMM column count (every one ends with N, H, W, Cin, Cout, stream)
-    SITES = {'dc_conv3x3_fwd': 'cout', 'dc_conv3x3_dgrad': 'cin', 'dc_conv3x3_fwd_f16x3': 'cout',
-             'dc_conv3x3_dgrad_f16x3': 'cin', 'dc_conv3x3_fwd_bnin_f16x3': 'cout'}
+    # entry point -> (GEMM column count is Cout / Cin, is a data gradient, index of the `stats` argument | None); every
+    # one ends with N, H, W, Cin, Cout, stream.  A launch is counted only if the library's own routing query says it runs the
+    # named symbol (f16x3: dc_conv3x3_pp_blocks() > 0 and > 32 columns = igemm_pp_kernel<2,2,0>).
+    SITES = {'dc_conv3x3_fwd': ('cout', 0, 5), 'dc_conv3x3_dgrad': ('cin', 1, None), 'dc_conv3x3_fwd_f16x3': ('cout', 0, 5),
+             'dc_conv3x3_dgrad_f16x3': ('cin', 1, None), 'dc_conv3x3_fwd_bnin_f16x3': ('cout', 0, 8)}
 
     def __init__(self, lib):
         self._lib = lib
@@ -58,7 +102,8 @@ class KernelTimer(object):
         fn = getattr(self._lib, name)
         if name not in self.SITES:
             return fn
-        colkey = self.SITES[name]
+        colkey, dgrad, stats_at = self.SITES[name]
+        f16 = name.endswith('_f16x3')
 
         def wrapped(*args):
             if not self.enabled:
@@ -67,6 +112,9 @@ class KernelTimer(object):
             ncols = Cout if colkey == 'cout' else Cin
             if not (Ww > 16 and ncols > 32):
                 return fn(*args)
+            if f16 and self._lib.dc_conv3x3_pp_blocks(N, Hh, Ww, Cin, Cout, dgrad,
+                                                      int(stats_at is not None and args[stats_at] is not None)) <= 0:
+                return fn(*args)          # a 256-thread kernel serves this launch (e.g. the 32-input-channel forward layer)
             e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
             self._lib.dc_event_create(ctypes.byref(e0))
             self._lib.dc_event_create(ctypes.byref(e1))
@@ -74,21 +122,24 @@ class KernelTimer(object):
             self._lib.dc_event_record(e0, stream)
             rc = fn(*args)
             self._lib.dc_event_record(e1, stream)
-            self.records.append((e0, e1, 2.0 * 9 * Cin * Cout * N * Hh * Ww))
+            # algorithmic bytes (input + output + weights, fp32, each moved once)
+            self.records.append((e0, e1, 2.0 * 9 * Cin * Cout * N * Hh * Ww, 4.0 * (N * Hh * Ww * (Cin + Cout) + 9 * Cin * Cout)))
             return rc
         return wrapped
 
     def summarize(self):
-        tot_ms, tot_flops = 0.0, 0.0
-        for e0, e1, flops in self.records:
+        tot_ms, tot_flops, tot_bytes = 0.0, 0.0, 0.0
+        for e0, e1, flops, nbytes in self.records:
             ms = ctypes.c_float()
             self._lib.dc_event_elapsed_ms(e0, e1, ctypes.byref(ms))
             tot_ms += ms.value
             tot_flops += flops
+            tot_bytes += nbytes
             self._lib.dc_event_destroy(e0)
             self._lib.dc_event_destroy(e1)
         n = len(self.records)
         self.records = []
+        self.last_bytes = tot_bytes
         return n, tot_ms, tot_flops
 
 
@@ -197,7 +248,7 @@ def bench_infer(args, model, xd, rank, world):
         'metric': '512x512 summary images/sec (forward only)', 'value': round(world * B * args.steps / dt, 2),
         'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': DTYPE_LABEL[eng.mfma], 'data': 'synthetic',
         'config': {'workload': 'UNet2DS forward-only, batch=%d 512x512 random fp32, nfb=32 (BASELINE.json configs[1])' % B,
                    'parallelism': 'replicas x%d' % world},
         'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': peak, 'unit': 'TFLOP/s',
@@ -244,7 +295,7 @@ def bench_tta(args, model, rank):
         'metric': '512x512 forwards/sec through UNet2DSummary.predict with 8x test-time augmentation',
         'value': round(19 * 8 * steps / dt, 2), 'unit': 'forwards/s', 'n_gpus': 1, 'steps': steps, 'warmup': max(1, args.warmup // 3),
         'ms_per_step': round(dt / steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': DTYPE_LABEL[model.engine.mfma], 'data': 'synthetic',
         'config': {'workload': 'UNet2DSummary.predict(augmentation=True), 19 synthetic 512x512 datasets x 8 TTA variants, '
                                'nfb=32, model file loaded per call as the reference does (BASELINE.json configs[4])',
                    'datasets_per_s': round(19 * steps / dt, 2), 'datasets_per_s_without_tta': round(19 * steps / dt_plain, 2),
@@ -345,6 +396,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=None,
                     help='per-GPU batch (default: 16 for train = BASELINE configs[2], 8 for infer = configs[1])')
+    ap.add_argument('--window', type=int, default=512,
+                    help='square window size (default 512 = the contract line).  --window 128 --batch 20 is the training '
+                         "configuration of the reference's example (examples/neurons/unet2ds_nf.py:36-40), --window 96 --batch 32 "
+                         "fit()'s default (unet_2d_summary.py:333-335)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--bn', default='local', choices=['local', 'sync'],
                     help="BatchNorm under data parallelism: per-rank statistics (default) or all-reduced ('sync')")
@@ -356,16 +411,20 @@ def main():
     if args.batch is None:
         args.batch = 8 if args.mode == 'infer' else BATCH_PER_GPU
 
+    global H, W
+    H = W = int(args.window)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args.gpus))         # before anything in this process touches the GPU
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     claim_stdout()
+    wd = Watchdog(int(os.environ.get('RANK', '0')))
+    wd.phase('import torch', 600)                 # the first import on a fresh box pages the image in: 1-2 minutes
 
     import torch
     from deep_calcium_amd import parallel
     from deep_calcium_amd.model import Model, Adam
-    from oracle import unet_numpy as on
 
+    wd.phase('process group rendezvous (%s)' % (os.environ.get('DC_DIST_BACKEND') or 'nccl'), 300)
     rank, world = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
@@ -375,39 +434,50 @@ def main():
     dev = torch.device('cuda', local)
 
     B = args.batch
+    wd.phase('model construction + first collective (parameter broadcast)', 300)
     model = Model((H, W), NFB, device=dev)
     model.compile(Adam(0.002), 'binary_crossentropy')
     eng = model.engine
     eng.bn_mode = args.bn
     parallel.broadcast_params(eng.pflat, eng.sflat)
     # synthetic shard of the global batch, resident in HBM (SURVEY 8d seeds, offset per rank)
-    x, y = on.synthetic_batch(B, H, W, seed_x=865 + 1000 * rank, seed_y=866 + 1000 * rank)
+    x, y = synthetic_batch(B, H, W, seed_x=865 + 1000 * rank, seed_y=866 + 1000 * rank)
     xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
 
     if args.mode == 'tta':
+        wd.phase('tta', 900)
         return bench_tta(args, model, rank)
     if args.mode == 'infer':
+        wd.phase('infer', 600)
         return bench_infer(args, model, xd, rank, world)
 
     timer = KernelTimer(eng.L)
     eng.L = timer
+    wd.phase('barrier before warm-up', 120)
     parallel.barrier()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        wd.tick('warm-up step %d' % i, 120 if i == 0 else None)      # the first step loads the code objects
         model.train_on_device_batch(xd, yd)
+    wd.tick('drain after warm-up')
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        wd.tick('timed step %d' % i)
         vals = model.train_on_device_batch(xd, yd)
+    wd.tick('drain after the timed steps')
     torch.cuda.synchronize()
+    t_rank = time.perf_counter() - t0             # this rank's own time, before it waits for the others
     parallel.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     parallel.all_reduce_max(tmax)
     dt = float(tmax.item())
+    per_rank_s = parallel.all_gather_floats(t_rank, dev)
+    wd.phase('roofline instrumentation steps', 180)
 
     # ---- roofline of the dominant kernel: 2 instrumented steps outside the timed region --------------------
     timer.enabled = True
@@ -416,10 +486,11 @@ def main():
         model.train_on_device_batch(xd, yd)
     torch.cuda.synchronize()
     n_launch, k_ms, k_flops = timer.summarize()
+    k_bytes = timer.last_bytes
     ar_exposed = [a.elapsed_time(b) for a, b in model.ar_events]
     model.ar_events = None
     ar_alone = None
-    if world > 1:                         # the whole 31 MB flat gradient in ONE blocking all-reduce, nothing else running
+    if parallel.exchange_active():        # the whole 31 MB flat gradient in ONE blocking all-reduce, nothing else running
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         parallel.all_reduce_sum(eng.gflat)
         torch.cuda.synchronize()
@@ -449,32 +520,40 @@ def main():
             'metric': '512x512 summary images/sec (train step)', 'value': round(world * B * args.steps / dt, 3),
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'UNet2DS train step (fwd+BCE+bwd+Keras-Adam), batch=%d 512x512 per GPU, nfb=32 '
-                                   '(BASELINE.json configs[2]; configs[3] at 8 GPUs)' % B,
+            'vs_baseline': None, 'dtype': DTYPE_LABEL[eng.mfma], 'data': 'synthetic',
+            'config': {'workload': 'UNet2DS train step (fwd+BCE+bwd+Keras-Adam), batch=%d %dx%d per GPU, nfb=32 (%s)' % (
+                                   B, H, W, 'BASELINE.json configs[2]; configs[3] at 8 GPUs' if (H, B) == (512, 16) else
+                                   "the reference's own training window, unet_2d_summary.py:333-335 / examples/neurons/unet2ds_nf.py:36-40"),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'bn': eng.bn_mode,
                        'contraction': 'fp32 operands split exactly into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 '
                                       'accumulate' if eng.mfma == 'f16x3' else 'fp32 MFMA',
                        'loss': float(vals[0]), 'shared_gpus': bool(shared_gpus),
-                       'dist_backend': (torch.distributed.get_backend() if world > 1 else None)},
+                       'dist_backend': (torch.distributed.get_backend() if parallel.is_dist() else None)},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
                          'kernel': kname, 'launches': n_launch,
                          'avg_launch_ms': round(k_ms / max(n_launch, 1), 4),
                          'algorithmic_flops_per_launch': round(k_flops / max(n_launch, 1)),
+                         'algorithmic_bytes_per_launch': round(k_bytes / max(n_launch, 1)),
+                         'traffic_over_algorithmic': round(traffic * max(n_launch, 1) / k_bytes, 3) if traffic and k_bytes else None,
                          'mfma_flops_per_algorithmic_flop': mfma_per_flop,
                          'matrix_pipe_frac': round(mfma_per_flop * achieved / peak, 4),
                          'achieved_without_concurrent_wgrad_stream': round(iso_flops / (iso_ms * 1e-3) / 1e12, 3) if iso_ms > 0 else None,
                          'streams': streams, 'traffic_note': traffic_note},
         }
-        if world > 1:
+        if parallel.exchange_active():
+            backend = torch.distributed.get_backend()
+            out['rccl_ranks'] = world if backend == 'nccl' else 0      # ranks whose gradients travelled over RCCL (0: gloo run)
             out['allreduce_ms'] = round(ar_alone, 4)
             out['allreduce_exposed_ms'] = round(sum(ar_exposed) / max(len(ar_exposed), 1), 4)
             out['allreduce_bytes'] = int(eng.n_train * 4)
             out['allreduce_buckets'] = 1 if os.environ.get('DC_AR_BUCKETS', '3') == '1' else 3
-        if world == 1 and not args.no_cpu_baseline:
+            out['per_rank_images_per_s'] = [round(B * args.steps / t, 2) for t in per_rank_s]
+        if world == 1 and not args.no_cpu_baseline and (H, B) == (512, 16):
+            wd.phase('cpu_baseline', 300)
             out['cpu_baseline'] = cpu_baseline()
         emit_json(json.dumps(out))
+    wd.done()
 
 
 if __name__ == '__main__':

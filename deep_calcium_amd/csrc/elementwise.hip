@@ -1386,6 +1386,17 @@ extern "C" int dc_fill(float* p, long n, float value, dc_stream_t stream) {
   return DC_OK;
 }
 
+__global__ void scale_kernel(float* p, long n, float s) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) p[i] *= s;
+}
+extern "C" int dc_scale_flat(float* p, long n, float s, dc_stream_t stream) {
+  DC_REQUIRE(p && n > 0, DC_EINVAL, "dc_scale_flat: bad arguments");
+  const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, s);
+  DC_CHECK_LAUNCH("dc_scale_flat");
+  return DC_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Test-time augmentation on the device (UNet2DSummary.predict(augmentation=True),
 // /root/reference/deepcalcium/models/neurons/unet_2d_summary.py:585-595 with the 8-entry table of

@@ -680,6 +680,23 @@ extern "C" int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* 
   return conv3x3_h_launch(p, (hipStream_t)stream);
 }
 
+// Which kernel a conv3x3 launch of this shape runs: > 0 (the pixel-tile count) when dc_conv3x3_fwd*_f16x3 (dgrad == 0;
+// with_stats: BatchNorm partials requested) / dc_conv3x3_dgrad*_f16x3 (dgrad != 0) is served by the persistent role-split
+// kernel of igemm_pp.hip.  Depends on the shape and DC_IGEMM_PP only -- not on the fusion knobs -- so the backward schedule
+// and bench.py's per-symbol timer can ask it.
+extern "C" int dc_conv3x3_pp_blocks(int N, int H, int W, int Cin, int Cout, int dgrad, int with_stats) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  float dummy = 1.f;
+  double dstat = 0.0;
+  IgemmParams p{};
+  p.N = N; p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W;
+  if (dgrad) { p.Cin = Cout; p.Ncols = Cin; p.inScale = &dummy; }
+  else { p.Cin = Cin; p.Ncols = Cout; p.stats = with_stats ? &dstat : nullptr; }
+  p.biasMod = p.Ncols; p.outLd = p.Ncols;
+  if (!dc_igemm_pp_serves(p)) return 0;
+  return N * dc_cdiv(W, 32) * dc_cdiv(H, p.Ncols <= 32 ? 16 : 8);
+}
+
 // Inference convolution whose output also feeds MaxPooling2D((2,2)): role-split kernel only
 // (dc_conv3x3_fwd_pool_blocks() == 0: use dc_conv3x3_fwd_f16x3 + dc_maxpool2x2_fwd).
 static IgemmParams fwd_pool_params(const float* x, const void* wp16, const float* bias, float* z, long z_ld, const float* scale,

@@ -284,7 +284,7 @@ class Model(object):
         slot['done'].synchronize()            # the step that last used this slot (two steps ago) has finished with it
         slot['xh'].numpy()[...] = xs
         slot['yh'].numpy()[...] = ys
-        with torch.cuda.stream(st['copy']):
+        with torch.cuda.device(eng.device), torch.cuda.stream(st['copy']):
             slot['xd'].copy_(slot['xh'], non_blocking=True)
             slot['yd'].copy_(slot['yh'], non_blocking=True)
             slot['ready'].record(st['copy'])
@@ -296,6 +296,12 @@ class Model(object):
         forward + BCE + backward + (RCCL all-reduce of the flat gradient and of the 8 metric sums) + Adam."""
         if self.optimizer is None:
             raise RuntimeError('compile() the model first')
+        # events, pinned copies and collectives below act on the CURRENT device's streams: make it the engine's
+        # (Model(device='cuda:1') while device 0 is current)
+        with torch.cuda.device(self.engine.device):
+            return self._train_on_device_batch(xd, yd, masks)
+
+    def _train_on_device_batch(self, xd, yd, masks):
         eng = self.engine
         eng.forward_train(xd, yd, masks)
         world = parallel.world_size()
@@ -305,7 +311,8 @@ class Model(object):
         # executing when the call returns, so the next step's launches queue up behind them with no idle gap.
         sums = eng._train_bufs(xd.shape[0])['sums']
         grad_scale = 1.0 / world
-        if world > 1:
+        dp = parallel.exchange_active()          # world > 1, or the one-rank RCCL rehearsal (DC_DIST_FORCE=1)
+        if dp:
             if sync:
                 # 'sync' = ONE device's step on the global batch: the dice losses' backward must see the GLOBAL sums
                 # (in place), and their per-pixel gradient carries no 1/count, so the summed gradient is already the
@@ -322,7 +329,7 @@ class Model(object):
         self._sums_host.copy_(sums, non_blocking=True)
         copied = torch.cuda.Event()
         copied.record()
-        if world > 1:
+        if dp:
             self._backward_allreduce()
         else:
             eng.backward()

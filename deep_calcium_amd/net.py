@@ -13,6 +13,7 @@ Memory plan (sized for 288 GB HBM: nothing is recomputed, nothing is pooled):
     channel halves of one `cat` buffer through the kernels' pixel-stride (ld) arguments;
   * training keeps z (pre-BN) and the block outputs for backward; inference folds BN into the conv epilogue.
 """
+import collections
 import os
 
 import numpy as np
@@ -82,18 +83,31 @@ def build_layer_table(nfb=32, drp=0.25, upsampling=False):
     return L
 
 
-_PINNED = {}
+_PINNED = collections.OrderedDict()      # key -> [pinned tensor, event of the last async H2D copy that read it | None]
+_PINNED_MAX_BYTES = 512 << 20
 
 
-def _pinned(tag, shape, dtype):
+def _pinned(tag, shape, dtype, entry=False):
     """Page-locked host buffers outlive engines: predict() builds a new engine per call (it loads a model file, as the
-    reference does) and pinning costs ~9 ms per buffer."""
+    reference does) and pinning costs ~9 ms per buffer.  Least-recently-used entries are dropped beyond 512 MB (every new
+    dataset count / window size / calling thread adds a key); torch's pinned allocator defers the actual release past any
+    copy still in flight.  entry=True returns the [tensor, last-H2D-event] cell itself, so the "has the previous copy out of
+    this buffer finished" guard survives the job (and the exception) that issued the copy."""
     import threading
     key = (tag, tuple(shape), dtype, threading.get_ident())      # one set per calling thread: no sharing between concurrent predict()s
-    t = _PINNED.get(key)
-    if t is None:
-        t = _PINNED[key] = torch.empty(tuple(shape), dtype=dtype).pin_memory()
-    return t
+    ent = _PINNED.get(key)
+    if ent is None:
+        ent = _PINNED[key] = [torch.empty(tuple(shape), dtype=dtype).pin_memory(), None]
+        total = sum(e[0].numel() * e[0].element_size() for e in _PINNED.values())
+        while total > _PINNED_MAX_BYTES and len(_PINNED) > 1:
+            k0 = next(iter(_PINNED))
+            if k0 == key:
+                break
+            old = _PINNED.pop(k0)
+            total -= old[0].numel() * old[0].element_size()
+    else:
+        _PINNED.move_to_end(key)
+    return ent if entry else ent[0]
 
 
 class _TtaJob(object):
@@ -121,8 +135,7 @@ class _TtaJob(object):
                                       x=torch.empty((K, H, W), dtype=torch.float32, device=dev),
                                       src=[torch.empty(n, dtype=torch.float32, device=dev) for _ in range(2)])
         self.m = m
-        self.host = [_pinned('tta_img%d' % k, (H, W), torch.float32) for k in range(2)]
-        self.slot_free = [None, None]
+        self.host = [_pinned('tta_img%d' % k, (H, W), torch.float32, entry=True) for k in range(2)]
         self.mask = torch.empty((self.count, n), dtype=torch.uint8, device=dev)
         self.mask_host = _pinned('tta_mask', (max(self.count, 1), n), torch.uint8)
         self.ovf = torch.zeros(max(self.count, 1), dtype=torch.float32, device=dev)
@@ -134,13 +147,14 @@ class _TtaJob(object):
         with torch.cuda.device(eng.device):
             L, st = eng.L, eng._stream()
             k = i & 1
-            if self.slot_free[k] is not None:
-                self.slot_free[k].synchronize()          # the H2D copy that last read this pinned slot has finished
-            self.host[k].numpy()[...] = img
-            m['src'][k].copy_(self.host[k].view(-1), non_blocking=True)
+            slot = self.host[k]
+            if slot[1] is not None:
+                slot[1].synchronize()                    # the H2D copy that last read this pinned slot (this job or an earlier one) has finished
+            slot[0].numpy()[...] = img
+            m['src'][k].copy_(slot[0].view(-1), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            self.slot_free[k] = ev
+            slot[1] = ev
             L.dc_gather_maps(_ptr(m['src'][k]), m['fwd'].data_ptr(), _ptr(m['x']), K, H * W, st)
             p = eng.forward_infer(m['x'])
             if eng.mfma == 'f16x3' and eng.range_guard and not eng.infer_measured:
@@ -742,7 +756,7 @@ class UNetEngine(object):
         Returns the uint8 mask (hs, ws).  Host traffic: 4*H*W bytes in, hs*ws bytes out (vs 8x both ways)."""
         K, H, W = len(augmentations), self.H, self.W
         n = H * W
-        key = ('tta', K, id(augmentations))
+        key = ('tta', K, tuple(name for name, _, _ in augmentations))
         m = self._bufs.get(key)
         if m is None:
             idx = np.arange(n, dtype=np.int32).reshape(1, H, W)
@@ -755,8 +769,7 @@ class UNetEngine(object):
                      src=torch.empty(n, dtype=torch.float32, device=self.device),
                      x=torch.empty((K, H, W), dtype=torch.float32, device=self.device),
                      mask=torch.empty(n, dtype=torch.uint8, device=self.device),
-                     host=torch.empty((H, W), dtype=torch.float32).pin_memory(),
-                     mask_host=torch.empty(n, dtype=torch.uint8).pin_memory())
+                     host=_pinned('tta1_img', (H, W), torch.float32), mask_host=_pinned('tta1_mask', (n,), torch.uint8))
             self._bufs[key] = m
         L, st = self.L, self._stream()
         m['host'].numpy()[...] = img
@@ -982,13 +995,13 @@ class UNetEngine(object):
         L.dc_reduce_partials_f64(_ptr(T['part_ws']), hb, 12, T['sums'].data_ptr(), st)
         return A['p']
 
-    @_on_device
     def grad_buckets(self):
         """gflat as three contiguous ranges in the order the backward completes them: decoder + head, bottleneck,
         encoder (flat layout = Keras get_weights order: encoder, bottleneck, decoder, head)."""
         o_ba, o_dec = self.by_name['ba'].off['k'][0], self.layers[10].off['k'][0]
         return [(o_dec, self.n_train), (o_ba, o_dec), (0, o_ba)]
 
+    @_on_device
     def backward(self, bucket_cb=None):
         """Backward of the last forward_train: fills gflat (same layout as pflat).  bucket_cb(lo, hi), if given, is called
         with the side (weight-gradient) stream current as soon as gflat[lo:hi] is complete on it -- data-parallel training
@@ -1120,7 +1133,7 @@ class UNetEngine(object):
             wpd = _ptr(self.wp_dgrad[l.name]) if dx_ptr is not None else None
             after = self.wgrad_after_dgrad
             if self.wgrad_order_hybrid:
-                after = f16 and l.kind == 'conv' and L.dc_conv3x3_dgrad_bnred_blocks(N, h, w, l.cin, l.cout) > 0
+                after = f16 and l.kind == 'conv' and L.dc_conv3x3_pp_blocks(N, h, w, l.cin, l.cout, 1, 0) > 0
             if dx_ptr is not None and after:
                 fused_next = launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16, red)
                 if two:

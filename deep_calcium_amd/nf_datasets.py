@@ -18,6 +18,7 @@ Host-side numpy; not part of the GPU path.
 import json
 import logging
 import os
+import shutil
 from glob import glob
 
 import numpy as np
@@ -83,7 +84,7 @@ def _download(name, datasets_dir, logger):
     except ImportError:
         raise IOError('%s/%s is missing and `requests` is not importable: unpack %s there' %
                       (datasets_dir, name, NAME_TO_URL[name]))
-    zip_path = '%s/%s.zip' % (datasets_dir, name)
+    zip_path = '%s/%s.zip.%d' % (datasets_dir, name, os.getpid())
     logger.info('Downloading %s.zip.' % name)
     try:
         download = requests.get(NAME_TO_URL[name])
@@ -93,9 +94,18 @@ def _download(name, datasets_dir, logger):
                       (datasets_dir, name, NAME_TO_URL[name], e))
     with open(zip_path, 'wb') as fp:
         fp.write(download.content)
+    # unpack next to the target and rename: nobody ever sees a half-extracted <datasets_dir>/<name>
+    stage = '%s/.%s.extract.%d' % (datasets_dir, name, os.getpid())
     with ZipFile(zip_path, 'r') as z:
-        z.extractall(datasets_dir)
+        z.extractall(stage)
     os.remove(zip_path)
+    inner = '%s/%s' % (stage, name)
+    try:
+        os.rename(inner if os.path.isdir(inner) else stage, '%s/%s' % (datasets_dir, name))
+    except OSError:
+        if not os.path.isdir('%s/%s' % (datasets_dir, name)):
+            raise
+    shutil.rmtree(stage, ignore_errors=True)
 
 
 def nf_load_hdf5(names, datasets_dir=None):
@@ -109,18 +119,29 @@ def nf_load_hdf5(names, datasets_dir=None):
     for name in dataset_names:
         url = NAME_TO_URL[name]          # KeyError for an unknown name, as in the reference (:72)
         del url
-        if os.path.exists('%s/%s' % (datasets_dir, name)):
-            logger.info('%s already downloaded.' % name)
-            continue
-        _download(name, datasets_dir, logger)
-
-    dataset_paths = []
-    for name in dataset_names:
-        ds_path = '%s/%s/dataset.hdf5' % (datasets_dir, name)
-        if not os.path.exists(ds_path):
-            logger.info('Populating %s.' % ds_path)
-            _populate(name, '%s/%s' % (datasets_dir, name), ds_path)
-        dataset_paths.append(ds_path)
+    # Under data-parallel fit() every rank calls this: rank 0 alone downloads / unpacks / builds, the others wait at the
+    # barrier and then find the finished files (a rank must never glob a directory another rank is still extracting).
+    from . import parallel
+    dataset_paths = ['%s/%s/dataset.hdf5' % (datasets_dir, name) for name in dataset_names]
+    err = None
+    if parallel.rank() == 0:
+        try:
+            for name, ds_path in zip(dataset_names, dataset_paths):
+                if os.path.exists('%s/%s' % (datasets_dir, name)):
+                    logger.info('%s already downloaded.' % name)
+                else:
+                    _download(name, datasets_dir, logger)
+                if not os.path.exists(ds_path):
+                    logger.info('Populating %s.' % ds_path)
+                    _populate(name, '%s/%s' % (datasets_dir, name), ds_path)
+        except Exception as e:           # still reach the barrier: the other ranks must not hang on a failed download
+            err = e
+    parallel.barrier()
+    if err is not None:
+        raise err
+    missing = [q for q in dataset_paths if not os.path.exists(q)]
+    if missing:
+        raise IOError('rank %d: %s missing after rank 0 built the datasets' % (parallel.rank(), ', '.join(missing)))
     return dataset_paths
 
 

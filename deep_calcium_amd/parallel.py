@@ -25,11 +25,28 @@ def rank():
     return dist.get_rank() if is_dist() else 0
 
 
+def forced():
+    """DC_DIST_FORCE=1: run the data-parallel code path -- process group, bucketed asynchronous gradient all-reduces issued
+    from the weight-gradient stream, metric-sum all-reduce -- even with ONE rank.  On the 1-GPU test box this is the only
+    way to put RCCL itself (backend 'nccl', a single-rank communicator) under the step's stream / event choreography."""
+    return os.environ.get('DC_DIST_FORCE', '0') == '1'
+
+
+def exchange_active():
+    """True when collectives are to be issued: a process group exists and (more than one rank, or DC_DIST_FORCE=1)."""
+    return is_dist() and (world_size() > 1 or forced())
+
+
 def init_from_env(backend=None):
-    """Initialise from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); no-op for a single process."""
+    """Initialise from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); no-op for a single process
+    (unless DC_DIST_FORCE=1: a one-rank group, see forced())."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
-    if ws <= 1 or is_dist():
+    if (ws <= 1 and not forced()) or is_dist():
         return rank(), world_size()
+    if ws <= 1:
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('MASTER_PORT', '29511')
     local = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
     # RCCL's intra-node transport needs dmabuf IPC (HSA_ENABLE_IPC_MODE_LEGACY=0).  The variable is read when the HSA
     # runtime initialises, i.e. at the first GPU call of the process: launchers (bench.py, torchrun wrappers) must export
@@ -58,32 +75,50 @@ def shard_slice(global_batch, r=None, ws=None):
 
 
 def all_reduce_sum(t):
-    if is_dist() and world_size() > 1:
+    if exchange_active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
 def all_reduce_max(t):
-    if is_dist() and world_size() > 1:
+    if exchange_active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
 
 
+def all_gather_floats(value, device=None):
+    """One float per rank -> list over ranks (bench.py: per-rank timings)."""
+    if not exchange_active():
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def barrier():
-    if is_dist() and world_size() > 1:
+    if exchange_active():
         dist.barrier()
 
 
 def sync_moving_stats(sflat):
-    """Average the BatchNorm moving statistics over ranks (they drift apart under local-BN data parallelism)."""
-    if is_dist() and world_size() > 1:
+    """Average the BatchNorm moving statistics over ranks (they drift apart under local-BN data parallelism): the sum is
+    the collective, the 1/G a libdcunet launch (no torch arithmetic on device tensors in the product path; a CPU tensor --
+    the gloo plumbing test -- is scaled in place)."""
+    if exchange_active():
         dist.all_reduce(sflat, op=dist.ReduceOp.SUM)
-        sflat.div_(world_size())
+        if sflat.is_cuda:
+            from ._lib import lib
+            with torch.cuda.device(sflat.device):
+                lib().dc_scale_flat(sflat.data_ptr(), sflat.numel(), 1.0 / world_size(),
+                                    torch.cuda.current_stream(sflat.device).cuda_stream)
+        else:
+            sflat.div_(world_size())
     return sflat
 
 
 def broadcast_params(*tensors, src=0):
-    if is_dist() and world_size() > 1:
+    if exchange_active():
         for t in tensors:
             dist.broadcast(t, src)
 

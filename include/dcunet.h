@@ -222,6 +222,11 @@ int dc_conv3x3_fwd_pool_f16x3(const float* x, const void* wp16, const float* bia
 /*   dc_conv3x3_dgrad_bnred_f16x3: dc_conv3x3_dgrad_f16x3 whose output dx IS the `da` of the BatchNorm layer in front
  *   (dense [N,H,W,Cin], no dropout, pre-BN tensor z of the same shape): rows = dc_conv3x3_dgrad_bnred_blocks(...) partial
  *   rows of bn_partial[rows][Cin][2]; rows == 0 -> shape not served, use dc_conv3x3_dgrad_f16x3 + dc_bn_bwd_reduce. */
+/* Kernel routing query (no launch): > 0 (the pixel-tile count) when a conv3x3 launch of this shape -- forward
+ * (dgrad == 0; with_stats != 0: BatchNorm partials requested) or data gradient (dgrad != 0) -- runs the persistent
+ * role-split kernel `igemm_pp_kernel` (64-column instantiation <2,2,*> when the GEMM column count, Cout forward / Cin
+ * data gradient, exceeds 32; <4,1,*> otherwise); 0: one of the 256-thread kernels.  Depends on shape and DC_IGEMM_PP only. */
+int dc_conv3x3_pp_blocks(int N, int H, int W, int Cin, int Cout, int dgrad, int with_stats);
 int dc_conv3x3_dgrad_bnred_blocks(int N, int H, int W, int Cin, int Cout);
 int dc_conv3x3_dgrad_bnred_f16x3(const float* dz, const void* wp16, float* dx, const float* dz_scale, const float* z,
                                  const float* mean, const float* invstd, const float* gamma, const float* beta,
@@ -322,6 +327,9 @@ int dc_tta_merge(const float* preds, const int* invmaps, int K, int H, int W, in
 
 /* misc */
 int dc_fill(float* p, long n, float value, dc_stream_t stream);
+/* p[i] *= s: the 1/G of the BatchNorm moving-statistics average over G data-parallel ranks (moving stats are
+ * "averaged ... at checkpoint"; the sum itself is the RCCL all-reduce) */
+int dc_scale_flat(float* p, long n, float s, dc_stream_t stream);
 /* timing helper: run `fn`-independent HIP event timing is done by the caller via hipEvent* through ctypes:
  * these wrap hipEventCreate/Record/Synchronize/ElapsedTime on the given stream (so bench.py measures on the
  * stream the kernels are launched on). */

@@ -182,10 +182,15 @@ def bn_infer(z, gamma, beta, mmean, mvar, eps=BN_EPS):
     return (z - mmean) / np.sqrt(mvar + eps) * gamma + beta
 
 
-def maxpool2x2_fwd(x):
-    """2x2/2 'valid' max pool; argmax = FIRST max in row-major window order (A.7)."""
+def maxpool2x2_fwd(x, forced_idx=None):
+    """2x2/2 'valid' max pool; argmax = FIRST max in row-major window order (A.7).
+    forced_idx (N,H/2,W/2,C) in 0..3: route through THESE window positions instead of the float64 argmax (see
+    UNetOracle `force`): a window whose top two values differ by less than fp32 rounding has no well-defined winner."""
     N, H, W, C = x.shape
     win = np.stack([x[:, 0::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 0::2], x[:, 1::2, 1::2]], axis=-1)
+    if forced_idx is not None:
+        idx = np.asarray(forced_idx, np.uint8)
+        return np.take_along_axis(win, idx[..., None].astype(np.intp), axis=-1)[..., 0], idx
     idx = win.argmax(axis=-1).astype(np.uint8)        # numpy argmax returns the first max
     return win.max(axis=-1), idx
 
@@ -267,9 +272,18 @@ def adam_keras(p, g, m, v, it, lr=0.002, b1=0.9, b2=0.999, eps=1e-8):
 # Whole network
 # ----------------------------------------------------------------------------
 class UNetOracle(object):
-    """Float64 forward/backward of unet() (unet_2d_summary.py:123-224) on a Keras-ordered weight list."""
+    """Float64 forward/backward of unet() (unet_2d_summary.py:123-224) on a Keras-ordered weight list.
 
-    def __init__(self, weights, nfb=32, drp=0.25, dtype=np.float64, upsampling=False):
+    force = {'gates': {layer: bool (N,h,w,C)}, 'pool': {lvl: uint8 (N,h/2,w/2,C)}} (either key optional) pins the two
+    DISCONTINUOUS decisions of the network -- which side of 0 a pre-activation falls (Activation('relu'),
+    unet_2d_summary.py:167,:159) and which element of a 2x2 window is the maximum (MaxPooling2D, :176) -- to the ones
+    another implementation took, the way explicit dropout masks pin Dropout.  With them pinned the function is smooth
+    in its arithmetic, so an fp32 implementation and this float64 one differ by rounding only and gradients can be held
+    to ~1e-4 instead of being compared in a loose norm (a pre-activation within fp32 rounding of 0 flips one gate per
+    10^5-10^6 elements and moves the affected gradient entries by O(1 %)).  A forced gate multiplies: a = y * gate."""
+
+    def __init__(self, weights, nfb=32, drp=0.25, dtype=np.float64, upsampling=False, force=None):
+        self.force = force or {}
         self.nfb = nfb
         self.upsampling = upsampling
         self.table = layer_table(nfb, upsampling)
@@ -297,13 +311,15 @@ class UNetOracle(object):
             y, bnc = bn_train_fwd(z, p[2], p[3])
         else:
             y, bnc = bn_infer(z, p[2], p[3], p[4], p[5]), None
-        a = np.maximum(y, 0)
+        fg = self.force.get('gates') if training else None
+        gate = np.asarray(fg[name], bool) if fg is not None else y > 0
+        a = np.where(gate, y, 0.0) if fg is not None else np.maximum(y, 0)
         keep = None
         if training and name in self.drop and self.drop[name] > 0:
             keep = 1.0 - self.drop[name]
             a = a * masks[name].astype(self.dtype) / keep      # A.8
         if cache is not None:
-            cache[name] = (x, bnc, y > 0, keep)
+            cache[name] = (x, bnc, gate, keep)
         return a
 
     def forward(self, x, training=False, masks=None, cache=None, taps=None):
@@ -318,7 +334,8 @@ class UNetOracle(object):
                 taps[tag + 'b'] = x
             if lvl < 4:
                 skips[lvl] = x                             # dropped-out tensor is the skip (:179-180)
-                x, idx = maxpool2x2_fwd(x)
+                fp = self.force.get('pool') if training else None
+                x, idx = maxpool2x2_fwd(x, fp[lvl] if fp is not None else None)
                 if cache is not None:
                     cache['p%d' % lvl] = idx
                 if taps is not None:

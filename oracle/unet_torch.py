@@ -26,7 +26,10 @@ def _to_t(w, dtype, requires_grad=False):
 
 
 class UNetTorch(object):
-    def __init__(self, weights, nfb=32, drp=0.25, dtype=torch.float64, requires_grad=True, upsampling=False):
+    def __init__(self, weights, nfb=32, drp=0.25, dtype=torch.float64, requires_grad=True, upsampling=False, force=None):
+        # force: see oracle.unet_numpy.UNetOracle -- ReLU gates {layer: bool NHWC} and pool indices {lvl: uint8 NHWC}
+        # taken from another implementation, applied in training mode (autograd then routes through exactly them)
+        self.force = force or {}
         self.upsampling = upsampling
         self.table = layer_table(nfb, upsampling)
         self.drop = dropout_rates(drp) if drp else {}
@@ -48,6 +51,10 @@ class UNetTorch(object):
         else:
             mu, var = mm.view(1, -1, 1, 1), mv.view(1, -1, 1, 1)
         y = (z - mu) / torch.sqrt(var + BN_EPS) * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+        fg = self.force.get('gates') if training else None
+        if fg is not None:
+            gate = torch.as_tensor(np.asarray(fg[name])).to(torch.bool).permute(0, 3, 1, 2)
+            return torch.where(gate, y, torch.zeros((), dtype=y.dtype))
         return F.relu(y)
 
     def _block(self, name, kind, x, training, masks, stats):
@@ -76,7 +83,14 @@ class UNetTorch(object):
                 skips[lvl] = x
                 if taps is not None:
                     taps['skip%d' % lvl] = x.detach()
-                x = F.max_pool2d(x, 2, 2)
+                fp = self.force.get('pool') if training else None
+                if fp is not None:
+                    n_, c_, h_, w_ = x.shape
+                    win = x.reshape(n_, c_, h_ // 2, 2, w_ // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n_, c_, h_ // 2, w_ // 2, 4)
+                    idx = torch.as_tensor(np.asarray(fp[lvl])).to(torch.int64).permute(0, 3, 1, 2)
+                    x = win.gather(-1, idx[..., None])[..., 0]
+                else:
+                    x = F.max_pool2d(x, 2, 2)
         for lvl in (3, 2, 1, 0):
             if self.upsampling:
                 x = F.interpolate(x, scale_factor=2, mode='nearest')

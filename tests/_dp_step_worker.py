@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deep_calcium_amd import parallel                      # noqa: E402
 from deep_calcium_amd.model import Model, Adam             # noqa: E402
 from oracle import unet_numpy as on                        # noqa: E402
+from _forced import device_decisions, grad_report          # noqa: E402
 
 
 def flat(G, ref):
@@ -36,6 +37,10 @@ def main():
         eng = model.engine
         res[buckets] = (vals, eng.gflat.cpu().numpy().copy(), eng.pflat.cpu().numpy().copy(),
                         {k: [g / world for g in v] for k, v in eng.grads().items()})
+        # the ReLU gates / pool indices THIS rank's shard step took (gamma / beta as they were before the Adam step)
+        dec = device_decisions(eng, NG // world, weights=Wt)
+    decs = [None] * world
+    torch.distributed.gather_object(dec, decs if rank == 0 else None, dst=0)
     # the RNG-dropout path: every rank must draw the bits ONE device would have drawn for its slice of the global batch
     seeds = [parallel.shard_drop_seed(12345, 1000, r) for r in range(world)]
     # numpy RNG broadcast: ranks start from different states, end on rank 0's
@@ -51,16 +56,17 @@ def main():
         ref = None
         for r in range(world):
             s_r = parallel.shard_slice(NG, r, world)
-            l_r, p_r, G_r, _ = on.UNetOracle(Wt, nfb).loss_and_grads(x[s_r], y[s_r], {k: v[s_r] for k, v in masks.items()})
+            # the oracle's shard step through rank r's own gates / pool routes: what is compared is rounding only
+            l_r, p_r, G_r, _ = on.UNetOracle(Wt, nfb, force=decs[r]).loss_and_grads(x[s_r], y[s_r], {k: v[s_r] for k, v in masks.items()})
             ref = G_r
-            gs.append(flat(G_r, G_r))
+            gs.append(G_r)
             ls.append(l_r)
-        fs = np.mean(gs, 0)
+        G_mean = {k: [np.mean([g[k][j] for g in gs], 0) for j in range(len(gs[0][k]))] for k in ref}
         vals, g3, p3, G3 = res['3']
         _, g1, p1, _ = res['1']
-        fg = flat(G3, ref)
+        worst, rel, cos = grad_report(G3, G_mean, 'DP local mode, %d ranks, forced gates: ' % world)
         out = dict(world=world, loss_err=abs(vals[0] - float(np.mean(ls))),
-                   grad_rel=float(np.linalg.norm(fg - fs) / np.linalg.norm(fs)),
+                   grad_rel=rel, grad_worst=worst,
                    buckets_bitwise_grad=bool(np.array_equal(g3, g1)), buckets_bitwise_params=bool(np.array_equal(p3, p1)),
                    seeds_distinct=len(set(seeds)) == world, rng_same=bool(lo.item() == hi.item()))
         json.dump(out, open(out_path, 'w'))

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deep_calcium_amd import parallel                      # noqa: E402
 from deep_calcium_amd.net import UNetEngine                # noqa: E402
 from oracle import unet_numpy as on                        # noqa: E402
+from _forced import device_decisions, grad_report          # noqa: E402
 
 
 def main():
@@ -34,31 +35,35 @@ def main():
         parallel.all_reduce_sum(sums)
         torch.cuda.synchronize()
         G = {k: [g / world for g in v] for k, v in eng.grads().items()}     # what Adam's grad_scale = 1/world applies
-        res[mode] = (p, float(sums[0].item()) / (NG * H * W), G, eng.get_weights())
+        decs = [None] * world             # every rank's ReLU gates / pool indices of this step, gathered on rank 0
+        torch.distributed.gather_object(device_decisions(eng, xd.shape[0]), decs if rank == 0 else None, dst=0)
+        res[mode] = (p, float(sums[0].item()) / (NG * H * W), G, eng.get_weights(), decs)
     if rank == 0:
-        orc = on.UNetOracle(Wt, nfb)
-        loss_ref, p_ref, G_ref, _ = orc.loss_and_grads(x, y, masks)
-        p, loss, G, Wn = res['sync']
-        fg = np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(G[n]) if not (j == 1 and n != 'out')]).astype(np.float64)
+        p, loss, G, Wn, decs = res['sync']
+        # 'sync' = ONE device's step on the whole batch: the oracle's batch-4 step through the ranks' gates, concatenated
+        whole = dict(gates={k: np.concatenate([d['gates'][k] for d in decs]) for k in decs[0]['gates']},
+                     pool={k: np.concatenate([d['pool'][k] for d in decs]) for k in decs[0]['pool']})
+        loss_ref, p_ref, G_ref, _ = on.UNetOracle(Wt, nfb, force=whole).loss_and_grads(x, y, masks)
+        worst, rel, cos = grad_report(G, G_ref, "'sync' BatchNorm, %d ranks, forced gates: " % world)
         fr = np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(G_ref[n]) if not (j == 1 and n != 'out')])
-        pl, lossl, Gl, _ = res['local']
+        pl, lossl, Gl, _, decl = res['local']
         fl = np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(Gl[n]) if not (j == 1 and n != 'out')]).astype(np.float64)
         # 'local' mode = G independent shard steps (each shard its own BatchNorm statistics), gradients averaged
         gs, ls, ps = [], [], []
         for r in range(world):
             s_r = parallel.shard_slice(NG, r, world)
-            l_r, p_r, G_r, _ = on.UNetOracle(Wt, nfb).loss_and_grads(x[s_r], y[s_r], {k: v[s_r] for k, v in masks.items()})
-            gs.append(np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(G_r[n]) if not (j == 1 and n != 'out')]))
+            l_r, p_r, G_r, _ = on.UNetOracle(Wt, nfb, force=decl[r]).loss_and_grads(x[s_r], y[s_r], {k: v[s_r] for k, v in masks.items()})
+            gs.append(G_r)
             ls.append(l_r)
             ps.append(p_r)
-        fs = np.mean(gs, 0)
+        G_mean = {k: [np.mean([g[k][j] for g in gs], 0) for j in range(len(gs[0][k]))] for k in G_ref}
+        worst_l, rel_l, _ = grad_report(Gl, G_mean, "'local' BatchNorm vs independent shards, forced gates: ")
         out = dict(world=world,
                    local_vs_shards_p_err=float(np.abs(pl - ps[0]).max()),
                    local_vs_shards_loss_err=abs(lossl - float(np.mean(ls))),
-                   local_vs_shards_grad_rel=float(np.linalg.norm(fl - fs) / np.linalg.norm(fs)),
+                   local_vs_shards_grad_rel=rel_l, local_vs_shards_grad_worst=worst_l,
                    p_err=float(np.abs(p - p_ref[sl]).max()), loss_err=abs(loss - loss_ref),
-                   grad_cos=float(fg.dot(fr) / (np.linalg.norm(fg) * np.linalg.norm(fr))),
-                   grad_rel=float(np.linalg.norm(fg - fr) / np.linalg.norm(fr)),
+                   grad_cos=cos, grad_rel=rel, grad_worst=worst,
                    # 'local' mode is a different function of the batch: it must NOT match the batch-4 oracle
                    local_p_err=float(np.abs(pl - p_ref[sl]).max()),
                    local_grad_rel=float(np.linalg.norm(fl - fr) / np.linalg.norm(fr)))

@@ -105,17 +105,18 @@ def test_fullsize_train_step_is_bit_reproducible(setup):
 def test_fullsize_window_train_step_vs_float64_torch_oracle(n):
     """One train-mode forward + backward on FULL 512x512 windows (nb_filters_base 32) against the float64 torch oracle
     (autograd): batch 2, and batch 16 = BASELINE.json configs[2] verbatim.  Probabilities and BCE loss within 1e-4, pool
-    argmax indices exact wherever the float64 maximum is unambiguous, gradients in rel-L2 / cosine (single ReLU-gate
-    flips between fp32 and float64 are legitimate discontinuities)."""
+    argmax indices exact wherever the float64 maximum is unambiguous, and GRADIENTS within 1e-4 -- per tensor
+    max|g - r| <= 1e-4 max|r|, whole gradient rel-L2 <= 1e-4 -- with the oracle routed through the device's own ReLU gates
+    and pool indices (tests/_forced.py; the network's only discontinuities, pinned like the dropout masks), so that what
+    is compared is rounding and nothing else.  Batch 2 also runs the oracle un-forced and prints how far a handful of
+    gate flips move the gradient (that comparison can only be held in loose norms)."""
     from deep_calcium_amd.net import UNetEngine
     from oracle.unet_torch import UNetTorch
+    from _forced import device_decisions, grad_report
     torch.cuda.empty_cache()
     Wt = on.init_weights(NFB, seed=77, randomize_bn=True)
     x, y = on.synthetic_batch(n, H, W)
     masks = on.make_drop_masks(NFB, n, H, W)
-    ref = UNetTorch(Wt, NFB, dtype=torch.float64)
-    taps = {}
-    loss_ref, p_ref, G_ref, _ = ref.loss_and_grads(x, y, masks, taps=taps)
     eng = UNetEngine((H, W), nb_filters_base=NFB, prop_dropout_base=0.25)
     eng.set_weights(Wt)
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
@@ -124,6 +125,9 @@ def test_fullsize_window_train_step_vs_float64_torch_oracle(n):
     loss = eng.read_sums()[0] / (n * H * W)
     eng.backward()
     G = eng.grads()
+    dec = device_decisions(eng, n)
+    taps = {}
+    loss_ref, p_ref, G_ref, _ = UNetTorch(Wt, NFB, dtype=torch.float64, force=dec).loss_and_grads(x, y, masks, taps=taps)
     assert np.abs(p - p_ref).max() < 1e-4
     assert abs(loss - loss_ref) < 1e-4
     # max-pool argmax (0..3, row-major in the 2x2 window, first maximum wins): bit-exact wherever the float64 oracle's
@@ -135,7 +139,7 @@ def test_fullsize_window_train_step_vs_float64_torch_oracle(n):
         top2 = win.topk(2, dim=-1).values
         clear = ((top2[..., 0] - top2[..., 1]) > 1e-4).numpy()
         ref_idx = win.argmax(dim=-1).numpy()
-        got = eng._acts(n)['idx%d' % lvl].cpu().numpy()
+        got = dec['pool'][lvl]
         assert clear.mean() > 0.3
         assert np.array_equal(got[clear], ref_idx[clear]), lvl
         # ties: wherever the kernel's OWN input window is all-equal (post-ReLU / dropped zeros) the index is 0
@@ -145,12 +149,14 @@ def test_fullsize_window_train_step_vs_float64_torch_oracle(n):
         assert flat0.mean() > 0.01 and (got[flat0] == 0).all(), lvl
         del t, win, top2, own, ow
     taps.clear()
-    fg = np.concatenate([g.ravel() for k in G_ref for j, g in enumerate(G[k]) if not (j == 1 and k != 'out')]).astype(np.float64)
-    fr = np.concatenate([np.asarray(g).ravel() for k in G_ref for j, g in enumerate(G_ref[k]) if not (j == 1 and k != 'out')])
-    assert fg.shape == fr.shape
-    cos = fg.dot(fr) / (np.linalg.norm(fg) * np.linalg.norm(fr))
-    rel = np.linalg.norm(fg - fr) / np.linalg.norm(fr)
-    assert cos > 0.9995 and rel < 0.05, (cos, rel)
+    worst, rel, cos = grad_report(G, G_ref, 'batch %d of 512x512, forced gates: ' % n)
+    assert worst < 1e-4 and rel < 1e-4, (worst, rel)
+    if n == 2:
+        del G_ref
+        loss_u, p_u, G_u, _ = UNetTorch(Wt, NFB, dtype=torch.float64).loss_and_grads(x, y, masks)
+        assert np.abs(p_u - p_ref).max() < 1e-6 and abs(loss_u - loss_ref) < 1e-7       # forcing moves the function by rounding only
+        w_u, rel_u, cos_u = grad_report(G, G_u, 'batch 2 of 512x512, UN-forced: ')
+        assert cos_u > 0.9995 and rel_u < 0.05, (cos_u, rel_u)
 
 
 def _tile_sums(a, TH, C):

@@ -34,6 +34,45 @@ def test_oracle_a_equals_oracle_b_whole_net():
         assert np.abs(wa - wb.reshape(wa.shape)).max() < 1e-7
 
 
+def test_forced_gates_and_pool_indices():
+    """UNetOracle / UNetTorch `force`: (i) forcing an oracle's OWN ReLU gates and pool indices changes nothing, bit for
+    bit; (ii) with a few gates and indices flipped -- what an fp32 implementation does where a pre-activation or a
+    window's top-two gap is within rounding of 0 -- the hand-derived backward (A) and autograd (B) still agree to
+    1e-10, and the gradient really moves (so an un-forced comparison of such an implementation needs loose norms)."""
+    nfb, N, H, W = 4, 2, 32, 32
+    Wt = on.init_weights(nfb, randomize_bn=True, dtype=np.float64)
+    x, y = on.synthetic_batch(N, H, W)
+    masks = on.make_drop_masks(nfb, N, H, W)
+    A0 = on.UNetOracle(Wt, nfb)
+    cache = {}
+    A0.forward(x, True, masks, cache=cache)
+    gates = {k: v[2].copy() for k, v in cache.items() if not k.startswith('p') and k != 'out'}
+    pool = {lvl: cache['p%d' % lvl].copy() for lvl in range(4)}
+    l0, p0, G0, _ = A0.loss_and_grads(x, y, masks)
+    l1, p1, G1, _ = on.UNetOracle(Wt, nfb, force=dict(gates=gates, pool=pool)).loss_and_grads(x, y, masks)
+    assert l0 == l1 and np.array_equal(p0, p1)
+    for k in G0:
+        for a, b in zip(G0[k], G1[k]):
+            assert np.array_equal(a, b), k
+    rs = np.random.RandomState(3)
+    for k in ('e0b', 'd1a', 'u2'):
+        flip = rs.random_sample(gates[k].shape) < 0.01
+        gates[k] = gates[k] ^ flip
+    pool[1] = ((pool[1] + (rs.random_sample(pool[1].shape) < 0.02)) % 4).astype(np.uint8)
+    force = dict(gates=gates, pool=pool)
+    la, pa, Ga, _ = on.UNetOracle(Wt, nfb, force=force).loss_and_grads(x, y, masks)
+    lb, pb, Gb, _ = UNetTorch(Wt, nfb, force=force).loss_and_grads(x, y, masks)
+    assert abs(la - lb) < 1e-12 and np.abs(pa - pb).max() < 1e-12
+    moved = 0.0
+    for k in Ga:
+        for a, b, c in zip(Ga[k], Gb[k], G0[k]):
+            assert np.abs(a.reshape(b.shape) - b).max() < 1e-10, k
+            moved = max(moved, np.abs(a - c).max())
+    assert moved > 1e-4
+    # inference never forces
+    assert np.array_equal(on.UNetOracle(Wt, nfb, force=force).forward(x), A0.forward(x))
+
+
 def test_finite_difference_head_bias():
     """Catches sub-gradient artefacts at p == 0.5 exactly (relu/abs formulations of the BCE are off by 0.5 there)."""
     nfb, N, H, W = 4, 1, 16, 16
