@@ -464,8 +464,11 @@ def main():
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    hang_at = int(os.environ.get('DC_BENCH_TEST_HANG', '-1'))     # test hook: this rank stops at that timed step
     for i in range(args.steps):
         wd.tick('timed step %d' % i)
+        if i == hang_at:
+            time.sleep(1e6)
         vals = model.train_on_device_batch(xd, yd)
     wd.tick('drain after the timed steps')
     torch.cuda.synchronize()

@@ -60,10 +60,7 @@ def training(dataset_name, model_path, checkpoints_dir, nb_steps=100, nb_epochs=
     """Train on neurofinder datasets (reference :23-44, same hyper-parameters; --nb_steps / --nb_epochs are additions
     for short runs, the defaults are the reference's 100 x 10)."""
     parallel.init_from_env()                       # no-op unless launched with torch.distributed.run
-    if parallel.rank() == 0:
-        nf_find_hdf5(dataset_name)                 # rank 0 builds missing dataset files, the others wait for them
-    parallel.barrier()
-    dspaths = nf_find_hdf5(dataset_name)
+    dspaths = nf_find_hdf5(dataset_name)           # every rank calls it: rank 0 builds missing dataset files, the others wait inside
     model = UNet2DSummary(cpdir=checkpoints_dir)
     return model.fit(
         dspaths,

@@ -72,13 +72,15 @@ def test_bench_one_rank_over_rccl_bucketed_async_path():
 
 
 def test_bench_watchdog_names_the_hung_phase():
-    """A rank that stops making progress exits 17 and says where (here: a 0.2 s per-step limit no step can meet)."""
-    env = dict(os.environ, DC_BENCH_WATCHDOG_S='0.2')
+    """A rank that stops making progress exits 17 and says where (DC_BENCH_TEST_HANG: the rank goes to sleep at timed step 2;
+    per-step limit 3 s instead of 30)."""
+    env = dict(os.environ, DC_BENCH_WATCHDOG_S='3', DC_BENCH_TEST_HANG='2')
     env.pop('WORLD_SIZE', None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '50', '--warmup', '1', '--no-cpu-baseline'],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '5', '--warmup', '1', '--no-cpu-baseline'],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 17, (r.returncode, r.stderr[-2000:])
-    assert 'watchdog: rank 0 made no progress in phase' in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert "watchdog: rank 0 made no progress in phase 'timed step 2'" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
 
 
 def test_example_train_under_torch_distributed_run(tmp_path):
@@ -95,7 +97,7 @@ def test_example_train_under_torch_distributed_run(tmp_path):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29547', os.path.join(ROOT, 'examples', 'neurons', 'unet2ds_nf.py'), 'train', name, '-c', cp,
            '--nb_steps', '5', '--nb_epochs', '2']        # (over gloo on ONE shared GPU every 31 MB gradient exchange costs ~0.5 s)
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert os.path.exists(root + '/dataset.hdf5')
     files = os.listdir(cp)

@@ -154,7 +154,7 @@ def test_fullsize_window_train_step_vs_float64_torch_oracle(n):
     if n == 2:
         del G_ref
         loss_u, p_u, G_u, _ = UNetTorch(Wt, NFB, dtype=torch.float64).loss_and_grads(x, y, masks)
-        assert np.abs(p_u - p_ref).max() < 1e-6 and abs(loss_u - loss_ref) < 1e-7       # forcing moves the function by rounding only
+        assert np.abs(p_u - p_ref).max() < 1e-5 and abs(loss_u - loss_ref) < 1e-6       # forcing moves the function by rounding only
         w_u, rel_u, cos_u = grad_report(G, G_u, 'batch 2 of 512x512, UN-forced: ')
         assert cos_u > 0.9995 and rel_u < 0.05, (cos_u, rel_u)
 

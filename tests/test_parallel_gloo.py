@@ -89,3 +89,36 @@ def test_shard_slice_contract():
     assert parallel.shard_slice(16, 0, 1) == slice(0, 16)
     with pytest.raises(ValueError):
         parallel.shard_slice(10, 0, 4)
+
+
+def _dataset_worker(rank, world, port, ds_dir, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from deep_calcium_amd import parallel
+    from deep_calcium_amd.nf_datasets import nf_load_hdf5
+    parallel.init_from_env(backend='gloo')
+    paths = nf_load_hdf5('neurofinder.01.00,neurofinder.02.00', datasets_dir=ds_dir)      # EVERY rank calls it
+    leftovers = [f for n in ('neurofinder.01.00', 'neurofinder.02.00') for f in os.listdir('%s/%s' % (ds_dir, n)) if 'partial' in f]
+    with open(os.path.join(out_dir, 'r%d.txt' % rank), 'w') as fp:
+        fp.write('\n'.join(paths + ['%d' % os.path.getsize(p) for p in paths] + ['leftovers=%d' % len(leftovers)]))
+    parallel.barrier()
+    dist.destroy_process_group()
+
+
+def test_dataset_build_under_two_ranks(tmp_path):
+    """fit() under data parallelism: every rank calls nf_load_hdf5; rank 0 alone builds dataset.hdf5 from the unpacked
+    directory, the others wait at the barrier inside and then see the finished file (never a half-extracted directory or
+    a truncated file), and the call returns on all ranks (no rank-0-only call sites with a barrier inside)."""
+    from _nf_dirs import make_neurofinder_dir
+    from deep_calcium_amd import hdf5_min
+    ds_dir = str(tmp_path / 'neurons_nf')
+    for k, name in enumerate(('neurofinder.01.00', 'neurofinder.02.00')):
+        make_neurofinder_dir(ds_dir, name, hw=(64, 64), neurons=6, frames=3, seed=3 + k)
+    world = 2
+    mp.spawn(_dataset_worker, args=(world, _free_port(), ds_dir, str(tmp_path)), nprocs=world, join=True)
+    a, b = [open(str(tmp_path / ('r%d.txt' % r))).read() for r in range(world)]
+    assert a == b and a.endswith('leftovers=0')
+    for line in a.splitlines()[:2]:
+        f = hdf5_min.File(line)
+        assert f['series/raw'].shape == (3, 64, 64) and f['masks/raw'].shape == (6, 64, 64)
