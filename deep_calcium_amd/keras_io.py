@@ -94,6 +94,53 @@ def keras_layer_sequence(nfb=32, drp=0.25, upsampling=False, window=(128, 128)):
 
 
 # ---- reading ------------------------------------------------------------------------------------------------------------
+def _base(name):
+    """'conv2d_transpose_17' -> 'conv2d_transpose' (Keras numbers layers per session: a model built second is conv2d_24...)."""
+    head, _, tail = name.rpartition('_')
+    return head if head and tail.isdigit() else name
+
+
+def check_keras_layout(path, layer_names, weight_names, shapes):
+    """First contact with a file this build did not write (the released unet2ds_model.hdf5, unet_2d_summary.py:28) must not
+    be a silent mis-map: the arrays are taken in (layer_names, weight_names) order and would land on whatever layer the flat
+    buffer has at that position.  So the file's WEIGHTED layers are checked against the UNet2DS graph (unet_2d_summary.py:
+    169-222) one by one -- layer kind (the name's base: conv2d / batch_normalization / conv2d_transpose; the per-session
+    numbering is free), the weights' names (kernel, bias / gamma, beta, moving_mean, moving_variance, in that order) and
+    their shapes -- and the first difference raises, naming the layer and what was expected there.  Weightless layers
+    (Activation, Dropout, MaxPooling2D, Lambda ...) carry nothing to map and are not compared."""
+    got = [(ln, wn, sh) for ln, wn, sh in zip(layer_names, weight_names, shapes) if len(wn)]
+    if not got:
+        raise ValueError('%s: no layer with weights' % path)
+    first = got[0][2][0] if got[0][2] else ()
+    if len(first) != 4 or tuple(first[:3]) != (3, 3, 1):
+        raise ValueError('%s: first weighted layer %r should hold the (3,3,1,nfb) kernel of the first Conv2D, found shapes %r'
+                         % (path, got[0][0], got[0][2]))
+    nfb = int(first[-1])
+    n_arrays = sum(len(wn) for _, wn, _ in got)
+    ups = n_arrays == 110
+    want = [(n, cls, ws) for n, cls, _, ws in keras_layer_sequence(nfb, 0.25, ups) if ws]
+    for k in range(max(len(got), len(want))):
+        if k >= len(got):
+            raise ValueError('%s: the file ends after %d weighted layers; the UNet2DS graph continues with %s %r'
+                             % (path, len(got), want[k][1], want[k][0]))
+        ln, wn, sh = got[k]
+        if k >= len(want):
+            raise ValueError('%s: unexpected extra weighted layer %r (%s) after the %d of the UNet2DS graph'
+                             % (path, ln, ', '.join(wn), len(want)))
+        en, ecls, ews = want[k]
+        if _base(ln) != _base(en):
+            raise ValueError('%s: weighted layer %d is %r where the UNet2DS graph (nb_filters_base %d, %s) has a %s (%r)'
+                             % (path, k, ln, nfb, 'UpSampling2D' if ups else 'Conv2DTranspose', ecls, en))
+        leaf = [w.rsplit('/', 1)[-1].split(':')[0] for w in wn]
+        eleaf = [sfx.split(':')[0] for sfx, _ in ews]
+        if leaf != eleaf:
+            raise ValueError('%s: layer %r lists weights %r where %s has %r (in this order)' % (path, ln, list(wn), ecls, eleaf))
+        for w, a, (sfx, es) in zip(wn, sh, ews):
+            if tuple(a) != tuple(es):
+                raise ValueError('%s: %r has shape %r, the UNet2DS graph has %r there (%s of %r)' % (path, w, tuple(a), tuple(es), sfx, en))
+    return nfb, ups
+
+
 def read_keras_model(path):
     """-> dict(weights=[...get_weights() order], config=dict(window_shape, nb_filters_base, prop_dropout_base,
     upsampling_or_transpose), optimizer=None | dict(config=..., iterations, m=[...], v=[...]), loss=str | None)."""
@@ -102,10 +149,16 @@ def read_keras_model(path):
     if 'layer_names' not in g.attrs:
         raise ValueError('%s: no layer_names attribute -- not a Keras model / weights file' % path)
     weights = []
+    lnames, wnames, shapes = [], [], []
     for lname in np.atleast_1d(g.attrs['layer_names']):
         lg = g[_s(lname)]
-        for wname in np.atleast_1d(lg.attrs.get('weight_names', [])):
-            weights.append(np.asarray(lg[_s(wname)].read(), dtype=np.float32))
+        names = [_s(w) for w in np.atleast_1d(lg.attrs.get('weight_names', []))]
+        arrs = [np.asarray(lg[w].read(), dtype=np.float32) for w in names]
+        weights += arrs
+        lnames.append(_s(lname))
+        wnames.append(names)
+        shapes.append([a.shape for a in arrs])
+    check_keras_layout(path, lnames, wnames, shapes)
     if len(weights) not in (134, 110):
         raise ValueError('%s: expected 134 (Conv2DTranspose) or 110 (UpSampling2D) weight arrays of a UNet2DS model, found %d'
                          % (path, len(weights)))

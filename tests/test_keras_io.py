@@ -139,3 +139,47 @@ def test_unsupported_files_fail_loudly(tmp_path):
         big = hdf5_min.Writer()
         big.attrs['model_config'] = b'x' * 70000          # v1 object-header messages stop at 64 KiB, as in h5py
         big.save(str(tmp_path / 'big.hdf5'))
+
+
+def test_layout_check_names_the_first_difference():
+    """keras_io.check_keras_layout: a genuine Keras file is mapped by position, so its weighted layers are verified against
+    the UNet2DS graph and the FIRST difference raises with the layer's name (never a silent mis-map)."""
+    from deep_calcium_amd import keras_io
+    seq = keras_io.keras_layer_sequence(8)
+
+    def lists(mut=None, renumber=0):
+        ln, wn, sh = [], [], []
+        for n, cls, _, ws in seq:
+            if renumber:                                  # a model built second in a session: conv2d_24 ...
+                head, _, tail = n.rpartition('_')
+                n = '%s_%d' % (head, int(tail) + renumber)
+            ln.append(n)
+            wn.append(['%s/%s' % (n, sfx) for sfx, _ in ws])
+            sh.append([s for _, s in ws])
+        if mut:
+            mut(ln, wn, sh)
+        return ln, wn, sh
+    assert keras_io.check_keras_layout('f', *lists()) == (8, False)
+    assert keras_io.check_keras_layout('f', *lists(renumber=23)) == (8, False)
+    k_bn = [i for i, (n, *_) in enumerate(seq) if n == 'batch_normalization_3'][0]
+
+    def swap(ln, wn, sh):
+        wn[k_bn][0], wn[k_bn][1] = wn[k_bn][1], wn[k_bn][0]
+    with pytest.raises(ValueError, match=r"batch_normalization_3.*\['gamma', 'beta', 'moving_mean', 'moving_variance'\]"):
+        keras_io.check_keras_layout('f', *lists(swap))
+
+    def drop(ln, wn, sh):
+        del ln[k_bn], wn[k_bn], sh[k_bn]
+    with pytest.raises(ValueError, match=r"is 'conv2d_4' where the UNet2DS graph .* has a BatchNormalization \('batch_normalization_3'\)"):
+        keras_io.check_keras_layout('f', *lists(drop))
+
+    def reshape(ln, wn, sh):
+        k = [i for i, (n, *_) in enumerate(seq) if n == 'conv2d_transpose_2'][0]
+        sh[k][0] = sh[k][0][:2] + (sh[k][0][3], sh[k][0][2])          # (2,2,Cin,Cout) instead of Keras' (2,2,Cout,Cin)
+    with pytest.raises(ValueError, match=r"conv2d_transpose_2/kernel:0' has shape"):
+        keras_io.check_keras_layout('f', *lists(reshape))
+
+    def truncate(ln, wn, sh):
+        del ln[-2:], wn[-2:], sh[-2:]
+    with pytest.raises(ValueError, match='the file ends after 44 weighted layers'):
+        keras_io.check_keras_layout('f', *lists(truncate))
