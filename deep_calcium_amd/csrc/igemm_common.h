@@ -1,6 +1,13 @@
 // Parameter block shared by the fp32 and the split-fp16 implicit-GEMM convolution kernels.
 #pragma once
 #include "common.h"
+#include <stdlib.h>
+
+// DC_TILE_WALK = 0 | 1 (default 1): see IgemmParams::walk
+static inline int dc_tile_walk() {
+  static const int v = getenv("DC_TILE_WALK") ? atoi(getenv("DC_TILE_WALK")) : 1;
+  return v;
+}
 
 struct IgemmParams {
   const float* in;
@@ -13,6 +20,11 @@ struct IgemmParams {
   int N, Hin, Win, Cin;
   int Hout, Wout, Ncols;
   int tilesX, tilesY;
+  // Order in which the workgroups walk the pixel tiles (speed only; the BatchNorm-partial index stays the row-major tile
+  // id): 0 = x fastest; 1 = y fastest -- consecutive positions are VERTICALLY adjacent tiles, whose halo'd input patches
+  // share KH - 1 full-width rows (2 of 10 / 18 rows for the 8- / 16-row tiles) against KW - 1 of TW + 2 columns (2 of 34)
+  // for horizontal neighbours: what one XCD's workgroups fetch side by side / back to back overlaps more.  dc_tile_walk().
+  int walk;
   int relu;
   int scatterCo;  // 0 = dense NHWC output; >0 = Conv2DTranspose scatter with Co = scatterCo
   int biasMod;    // bias index = n % biasMod

@@ -113,12 +113,12 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   const int nblk = (p.Ncols + BN - 1) / BN, total = (int)gridDim.x;
   const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3, qq = total >> 3, rr = total & 7;
   const int work = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + seq;
-  const int tile_id = work / nblk;
-  int t = tile_id;
-  const int tx = t % p.tilesX; t /= p.tilesX;
-  const int ty = t % p.tilesY;
-  const int img = t / p.tilesY;
-  const int n0 = (work - tile_id * nblk) * BN;
+  const int wpos = work / nblk;                                // position in the walk over the pixel tiles
+  int tx, ty, img;
+  if (p.walk) { ty = wpos % p.tilesY; const int t = wpos / p.tilesY; tx = t % p.tilesX; img = t / p.tilesX; }
+  else { tx = wpos % p.tilesX; const int t = wpos / p.tilesX; ty = t % p.tilesY; img = t / p.tilesY; }
+  const int tile_id = (img * p.tilesY + ty) * p.tilesX + tx;     // index of the BatchNorm partials: row-major whatever the walk
+  const int n0 = (work - wpos * nblk) * BN;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
   const int Cin8 = (p.Cin + 7) >> 3;
@@ -441,6 +441,7 @@ static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name) {
   if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES + 8 * 1024, name)) return rc;
   p.tilesX = dc_cdiv(p.Wout, TW);
   p.tilesY = dc_cdiv(p.Hout, Cfg::TH);
+  p.walk = dc_tile_walk();
   dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY * dc_cdiv(p.Ncols, Cfg::BN)));
   const int lds = Cfg::LDS_BYTES + (p.inSc ? 8 * ((p.Cin + 3) & ~3) : 0);
   DC_REQUIRE(lds <= Cfg::LDS_BYTES + 8 * 1024, DC_EUNSUP, "%s: Cin=%d too large for the BN-on-load table", name, p.Cin);

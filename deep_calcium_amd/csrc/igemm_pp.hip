@@ -133,12 +133,12 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
   auto decode = [&](int j) __attribute__((always_inline)) {
     Item it;
     const int work = xstart + seq + j * nx;
-    it.tile_id = work / nblk;
-    it.n0 = (work - it.tile_id * nblk) * BN;
-    int t = it.tile_id;
-    const int tx = t % p.tilesX; t /= p.tilesX;
-    const int ty = t % p.tilesY;
-    it.img = t / p.tilesY;
+    const int wpos = work / nblk;                               // position in the walk over the pixel tiles
+    it.n0 = (work - wpos * nblk) * BN;
+    int tx, ty;
+    if (p.walk) { ty = wpos % p.tilesY; const int t = wpos / p.tilesY; tx = t % p.tilesX; it.img = t / p.tilesX; }
+    else { tx = wpos % p.tilesX; const int t = wpos / p.tilesX; ty = t % p.tilesY; it.img = t / p.tilesY; }
+    it.tile_id = (it.img * p.tilesY + ty) * p.tilesX + tx;      // BatchNorm-partial index: row-major whatever the walk
     it.oy0 = ty * TH; it.ox0 = tx * TW;
     return it;
   };
@@ -639,6 +639,7 @@ static int pp_launch(IgemmParams p, hipStream_t st, const char* name) {
   if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), lds, name)) return rc;
   p.tilesX = dc_cdiv(p.Wout, pp::TW);
   p.tilesY = dc_cdiv(p.Hout, C::TH);
+  p.walk = dc_tile_walk();
   static int cus[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;

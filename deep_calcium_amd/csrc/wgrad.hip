@@ -149,7 +149,7 @@ static int wgrad_launch(const float* A, const float* B, float* dw, float* ws, in
   static DcLdsAttr lds_attr;      // one per template instantiation; per-device inside
   if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES, name)) return rc;
   WgradPlan pl = wgrad_plan<KH, KW, S, PAD, TW, RW, WM, WN>(N, Hb, Wb, Cm, Cn);
-  WgradParams p;
+  WgradParams p{};
   p.A = A; p.B = B; p.slabs = ws;
   p.N = N; p.Ha = Ha; p.Wa = Wa; p.Cm = Cm; p.Hb = Hb; p.Wb = Wb; p.Cn = Cn;
   p.tilesX = pl.tilesX; p.tilesY = pl.tilesY; p.tilesTotal = pl.tilesTotal; p.tilesPerSplit = pl.tilesPerSplit;

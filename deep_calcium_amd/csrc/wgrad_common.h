@@ -8,6 +8,7 @@ struct WgradParams {
   float* slabs;
   int N, Ha, Wa, Cm, Hb, Wb, Cn;
   int tilesX, tilesY, tilesTotal, tilesPerSplit;
+  int walk;   // 1: a workgroup's consecutive tiles are vertically adjacent (their halo'd x tiles share KH - 1 rows); 0: x fastest
 };
 
 // Epilogue shared by both kernels: the WK waves of a CTA that own the same (m,n) block first add their

@@ -24,6 +24,7 @@
 //     LDS at the end, one slab per CTA goes to HBM and dc_reduce_partials adds the slabs in a fixed order
 //     (bit-reproducible, no atomics).
 #include "wgrad_common.h"
+#include <stdlib.h>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -147,10 +148,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
     // ma / mb: per-load 'inside the image' bits, needed only when BN + ReLU is applied on load (0 must stay 0)
     auto request = [&](int tile, f32x4 (&ra)[NA], f32x4 (&rb)[NB], unsigned& ma, unsigned& mb) {
       ma = 0u; mb = 0u;
-      int t = tile;
-      const int tx = t % p.tilesX; t /= p.tilesX;
-      const int ty = t % p.tilesY;
-      const int img = t / p.tilesY;
+      int tx, ty, img;
+      if (p.walk) { ty = tile % p.tilesY; const int t = tile / p.tilesY; tx = t % p.tilesX; img = t / p.tilesX; }
+      else { tx = tile % p.tilesX; const int t = tile / p.tilesX; ty = t % p.tilesY; img = t / p.tilesY; }
       const int py0 = ty * TH, px0 = tx * TW;
       const int ay0 = py0 * S - PAD, ax0 = px0 * S - PAD;
       const __amdgpu_buffer_rsrc_t rsA = dc_make_rsrc(p.A + (long)img * p.Ha * p.Wa * p.Cm, (unsigned)(p.Ha * p.Wa * p.Cm) * 4u);
@@ -353,6 +353,8 @@ static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, 
   p.A = A; p.B = B; p.slabs = ws;
   p.N = N; p.Ha = Ha; p.Wa = Wa; p.Cm = Cm; p.Hb = Hb; p.Wb = Wb; p.Cn = Cn;
   p.tilesX = pl.tilesX; p.tilesY = pl.tilesY; p.tilesTotal = pl.tilesTotal; p.tilesPerSplit = pl.tilesPerSplit;
+  static const int walk = getenv("DC_TILE_WALK") ? atoi(getenv("DC_TILE_WALK")) : 1;
+  p.walk = walk;
   hp.aScale = aScale; hp.bScale = bScale;
   // the activation operand is the UNscaled one: A for conv3x3 (A_SCALED = false), B for convT2x2
   hp.aSc = A_SCALED ? nullptr : xSc; hp.aSh = A_SCALED ? nullptr : xSh;
