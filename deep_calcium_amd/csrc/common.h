@@ -149,6 +149,28 @@ __device__ __forceinline__ float dc_block_guard_scale(const float* __restrict__ 
   __syncthreads();
   return dc_pow2_guard(m);
 }
+// Gradient operands: the power of two that brings max|dz| to [target/2, target] (dc_bn_bwd_apply emits one max per block).
+// dc_pow2_from_absmax is THE formula (dc_pow2_scale_from_absmax / dc_bn_bwd_apply_finalize and the data-gradient kernels that
+// derive the scale themselves evaluate it on the same maximum: same scale, and a power of two is exact either way).
+__device__ __forceinline__ float dc_pow2_from_absmax(float m, float target) {
+  float e = (m > 0.f && isfinite(m)) ? floorf(log2f(target / m)) : 0.f;
+  e = fminf(fmaxf(e, -100.f), 100.f);
+  return exp2f(e);
+}
+// Block-cooperative (every thread calls it; two barriers; tmp = 16 floats of LDS): max over part[0..n) -> the scale.
+__device__ __forceinline__ float dc_block_absmax_scale(const float* __restrict__ part, int n, float target, float* tmp) {
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, part[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) tmp[wave] = m;
+  __syncthreads();
+  m = tmp[0];
+  for (int w = 1; w < nw; ++w) m = fmaxf(m, tmp[w]);
+  __syncthreads();
+  return dc_pow2_from_absmax(m, target);
+}
 // running max |v| per channel (inference: the measured bound of a folded-BN activation); order-independent.
 // Thousands of workgroups fold into the same few addresses: read first and skip the atomic unless it would raise the
 // value (a stale cached read only costs a redundant atomic; after the first workgroups nearly every call is a read).

@@ -445,12 +445,7 @@ __global__ void pow2_scale_kernel(const float* __restrict__ partial, int n, floa
     if (threadIdx.x < s) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    m = sm[0];
-    float e = (m > 0.f && isfinite(m)) ? floorf(log2f(target / m)) : 0.f;
-    e = fminf(fmaxf(e, -100.f), 100.f);
-    scale[0] = exp2f(e);
-  }
+  if (threadIdx.x == 0) scale[0] = dc_pow2_from_absmax(sm[0], target);
 }
 extern "C" int dc_pow2_scale_from_absmax(const float* partial, int n, float target, float* scale, dc_stream_t stream) {
   DC_REQUIRE(partial && scale && n > 0 && target > 0.f, DC_EINVAL, "dc_pow2_scale_from_absmax: bad arguments");
@@ -488,12 +483,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_finalize_kernel(const float*
     if (tid < k) smf[tid] = fmaxf(smf[tid], smf[tid + k]);
     __syncthreads();
   }
-  if (tid == 0) {
-    m = smf[0];
-    float e = (m > 0.f && isfinite(m)) ? floorf(log2f(target / m)) : 0.f;
-    e = fminf(fmaxf(e, -100.f), 100.f);
-    scale[0] = exp2f(e);
-  }
+  if (tid == 0) scale[0] = dc_pow2_from_absmax(smf[0], target);
 }
 extern "C" int dc_bn_bwd_apply_finalize(const float* dbias_partial, const float* absmax_partial, int blocks, int C,
                                         float target, float* dbias, float* scale, dc_stream_t stream) {

@@ -30,6 +30,11 @@ struct IgemmParams {
   int biasMod;    // bias index = n % biasMod
   long outLd;     // pixel stride of the output tensor in floats
   const float* inScale;  // f16x3 only: device scalar (power of two) applied to the input before the fp16 split
+  // f16x3 data gradients, instead of inScale: the per-block max |dz| array dc_bn_bwd_apply wrote (inAbsmaxN entries); every
+  // workgroup derives the power of two itself (dc_block_absmax_scale, target 1024), so no finalize launch sits between the
+  // BatchNorm-backward apply pass and the data gradient
+  const float* inAbsmax;
+  int inAbsmaxN;
   // f16x3 only: per-input-channel BatchNorm affine of a NON-materialised activation.  `in` then holds the producer's
   // pre-BN tensor z and the operand relu(fmaf(z, inSc[c], inSh[c])) is formed while it is staged (padding stays 0).
   const float* inSc;

@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   // range guard of an activation tensor (common.h dc_block_guard_scale; its barriers also publish the table).
   if (bnin)
     for (int i = tid; i < p.Cin; i += 256) { lds_sc[i] = p.inSc[i]; lds_sc[Cinp + i] = p.inSh[i]; }
-  const float in_scale = (p.inScale ? *p.inScale : 1.f) *
+  const float in_scale = (p.inAbsmax ? dc_block_absmax_scale(p.inAbsmax, p.inAbsmaxN, 1024.f, reinterpret_cast<float*>(smem))
+                                     : (p.inScale ? *p.inScale : 1.f)) *
                          dc_block_guard_scale(p.inAbound, p.Cin, reinterpret_cast<float*>(smem), p.inAboundLd);
   if (bnin && p.inAbound == nullptr) __syncthreads();
   DC_TRACE();            // 2: first loads issued, tables / guard done
@@ -670,12 +671,20 @@ extern "C" int dc_convT2x2_fwd_bnin_f16x3(const float* z_in, const float* in_sc,
   return convT_fwd_h_launch(p, (hipStream_t)stream);
 }
 
-extern "C" int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale, int N, int H,
+static int check_absmax(const char* fn, const float* in_scale, const float* in_absmax, int n) {
+  DC_REQUIRE(!(in_scale && in_absmax), DC_EINVAL, "%s: pass dz_scale OR dz_absmax, not both", fn);
+  DC_REQUIRE(in_absmax == nullptr || (n > 0 && n <= 65536), DC_EINVAL, "%s: dz_absmax_n=%d out of range", fn, n);
+  return DC_OK;
+}
+extern "C" int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
+                                      const float* in_absmax, int in_absmax_n, int N, int H,
                                       int W, int Cin, int Cout, dc_stream_t stream) {
   int rc = check_h("dc_conv3x3_dgrad_f16x3", dz, wp16, dx, N, H, W, Cout, Cin);
   if (rc) return rc;
+  if ((rc = check_absmax("dc_conv3x3_dgrad_f16x3", in_scale, in_absmax, in_absmax_n))) return rc;
   IgemmParams p{};
   p.in = dz; p.wp = reinterpret_cast<const float*>(wp16); p.out = dx; p.inScale = in_scale;
+  p.inAbsmax = in_absmax; p.inAbsmaxN = in_absmax_n;
   p.N = N; p.Hin = H; p.Win = W; p.Cin = Cout; p.Hout = H; p.Wout = W; p.Ncols = Cin;
   p.biasMod = Cin; p.outLd = Cin;
   return conv3x3_h_launch(p, (hipStream_t)stream);
@@ -748,13 +757,15 @@ extern "C" int dc_conv3x3_dgrad_bnred_blocks(int N, int H, int W, int Cin, int C
   return N * dc_cdiv(W, 32) * dc_cdiv(H, Cin <= 32 ? 16 : 8);
 }
 extern "C" int dc_conv3x3_dgrad_bnred_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
-                                            const float* z, const float* mean, const float* invstd, const float* gamma,
+                                            const float* in_absmax, int in_absmax_n, const float* z, const float* mean, const float* invstd, const float* gamma,
                                             const float* beta, float* bn_partial, int N, int H, int W, int Cin, int Cout,
                                             dc_stream_t stream) {
   int rc = check_h("dc_conv3x3_dgrad_bnred_f16x3", dz, wp16, dx, N, H, W, Cout, Cin);
   if (rc) return rc;
   DC_REQUIRE(z && mean && invstd && gamma && beta && bn_partial, DC_EINVAL, "dc_conv3x3_dgrad_bnred_f16x3: null pointer");
+  if ((rc = check_absmax("dc_conv3x3_dgrad_bnred_f16x3", in_scale, in_absmax, in_absmax_n))) return rc;
   IgemmParams p = dgrad_bnred_params(dz, wp16, dx, in_scale, N, H, W, Cin, Cout);
+  p.inAbsmax = in_absmax; p.inAbsmaxN = in_absmax_n;
   p.bnZ = z; p.bnMean = mean; p.bnInvstd = invstd; p.bnGamma = gamma; p.bnBeta = beta; p.bnPartial = bn_partial;
   DC_REQUIRE(dc_conv3x3_dgrad_bnred_blocks(N, H, W, Cin, Cout) > 0, DC_EUNSUP,
              "dc_conv3x3_dgrad_bnred_f16x3: shape not served (dc_conv3x3_dgrad_bnred_blocks() == 0): use the two-pass path");
@@ -780,12 +791,15 @@ extern "C" int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const flo
   return convT_fwd_h_launch(p, (hipStream_t)stream);
 }
 
-extern "C" int dc_convT2x2_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale, int N, int H,
+extern "C" int dc_convT2x2_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
+                                       const float* in_absmax, int in_absmax_n, int N, int H,
                                        int W, int Cin, int Cout, dc_stream_t stream) {
   int rc = check_h("dc_convT2x2_dgrad_f16x3", dz, wp16, dx, N, H, W, Cout, Cin);
   if (rc) return rc;
+  if ((rc = check_absmax("dc_convT2x2_dgrad_f16x3", in_scale, in_absmax, in_absmax_n))) return rc;
   IgemmParams p{};
   p.in = dz; p.wp = reinterpret_cast<const float*>(wp16); p.out = dx; p.inScale = in_scale;
+  p.inAbsmax = in_absmax; p.inAbsmaxN = in_absmax_n;
   p.N = N; p.Hin = 2 * H; p.Win = 2 * W; p.Cin = Cout; p.Hout = H; p.Wout = W; p.Ncols = Cin;
   p.biasMod = Cin; p.outLd = Cin;
   return convT_dgrad_h_launch(p, (hipStream_t)stream);

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
       lds_sc[EP_COLS + i] = p.bnInvstd[i];
     }
   }
-  const float in_scale = (p.inScale ? *p.inScale : 1.f) * dc_block_guard_scale(p.inAbound, p.Cin, tmp, p.inAboundLd);
+  const float in_scale = (p.inAbsmax ? dc_block_absmax_scale(p.inAbsmax, p.inAbsmaxN, 1024.f, tmp) : (p.inScale ? *p.inScale : 1.f)) * dc_block_guard_scale(p.inAbound, p.Cin, tmp, p.inAboundLd);
   if (p.inAbound == nullptr) __syncthreads();                 // (the guard's own barriers publish the tables otherwise)
 
   if (role == 2) {

@@ -214,6 +214,9 @@ class UNetEngine(object):
         self.conv_pool = os.environ.get('DC_CONV_POOL', '1') == '1'
         # data gradients served by the role-split kernel also emit the BatchNorm-backward sums of the layer they feed
         self.dgrad_bnred = os.environ.get('DC_DGRAD_BNRED', '1') == '1'
+        # the finalize launch behind the BatchNorm-backward apply pass (conv-bias gradient + power-of-two scale of dz) runs on
+        # the weight-gradient stream; the data gradient derives the scale itself from the per-block maxima
+        self.finalize_side = self.mfma == 'f16x3' and os.environ.get('DC_FINALIZE_SIDE', '1') == '1'
         self._head_bwd_done = False
         # fp16 range guard of the activation operands (A/B knob; the weights' pack-time scale is unconditional)
         self.range_guard = os.environ.get('DC_RANGE_GUARD', '1') == '1'
@@ -824,7 +827,12 @@ class UNetEngine(object):
         T['part_ws'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['part_ws2'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['head_gpart'] = torch.empty(hb * (nfb + 4), dtype=torch.float32, device=dev)
-        T['absmax'] = torch.empty(4096, dtype=torch.float32, device=dev)
+        # per dz buffer: the apply pass' per-block max |dz| and conv-bias-gradient partials (read by the finalize launch on the
+        # weight-gradient stream and by the data gradient: they rotate with the dz buffer they describe)
+        T['absmax'] = [torch.empty(4096, dtype=torch.float32, device=dev) for _ in range(self.dz_bufs)]
+        dpart = max(L.dc_bn_bwd_blocks(N * self._hw(l.lvl)[0] * self._hw(l.lvl)[1], l.cout) * l.cout
+                    for l in self.layers if l.kind != 'head')
+        T['dbias_part'] = [torch.empty(dpart, dtype=torch.float32, device=dev) for _ in range(self.dz_bufs)]
         T['dz_scale'] = torch.ones(self.dz_bufs * 4, dtype=torch.float32, device=dev)      # one (16-B aligned) scalar per dz buffer
         T['red_tmp'] = torch.empty(32 * 1024, dtype=torch.float32, device=dev)
         T['wgrad_ws'] = torch.empty(ws_floats, dtype=torch.float32, device=dev)
@@ -1057,24 +1065,24 @@ class UNetEngine(object):
             side.wait_stream(main)        # everything queued so far (forward, head) precedes the first wgrad
         self._dz_turn = getattr(self, '_dz_turn', 0)
 
-        def launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16, red=None):
+        def launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16, red=None, amax=None, amax_n=0):
             """red = the BatchNorm layer whose `da` this data gradient writes (dense, no dropout): when the role-split
             kernel serves the shape its epilogue also emits that layer's backward sums -> (partial ptr, rows)."""
             if l.kind == 'conv':
                 if f16 and red is not None:
                     rows = L.dc_conv3x3_dgrad_bnred_blocks(N, h, w, l.cin, l.cout)
                     if rows > 0:
-                        L.dc_conv3x3_dgrad_bnred_f16x3(dz, wpd, dx_ptr, scale, _ptr(T['z_' + red.name]), self.stat_ptr(red, 0),
+                        L.dc_conv3x3_dgrad_bnred_f16x3(dz, wpd, dx_ptr, scale, amax, amax_n, _ptr(T['z_' + red.name]), self.stat_ptr(red, 0),
                                                        self.stat_ptr(red, 1), self.pview(self.pflat, red, 'gamma'),
                                                        self.pview(self.pflat, red, 'beta'), _ptr(T['part_ws']), N, h, w,
                                                        l.cin, l.cout, st)
                         return (_ptr(T['part_ws']), rows)
                 if f16:
-                    L.dc_conv3x3_dgrad_f16x3(dz, wpd, dx_ptr, scale, N, h, w, l.cin, l.cout, st)
+                    L.dc_conv3x3_dgrad_f16x3(dz, wpd, dx_ptr, scale, amax, amax_n, N, h, w, l.cin, l.cout, st)
                 else:
                     L.dc_conv3x3_dgrad(dz, wpd, dx_ptr, N, h, w, l.cin, l.cout, st)
             elif f16:
-                L.dc_convT2x2_dgrad_f16x3(dz, wpd, dx_ptr, scale, N, h // 2, w // 2, l.cin, l.cout, st)
+                L.dc_convT2x2_dgrad_f16x3(dz, wpd, dx_ptr, scale, amax, amax_n, N, h // 2, w // 2, l.cin, l.cout, st)
             else:
                 L.dc_convT2x2_dgrad(dz, wpd, dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
             return None
@@ -1107,6 +1115,7 @@ class UNetEngine(object):
                 L.dc_bn_bwd_finalize(_ptr(T['part_ws']), blocks, l.cout, dgamma, dbeta, st)
             if two and self._dz_free[k] is not None:
                 main.wait_event(self._dz_free[k])       # the wgrad that last read this dz buffer has finished
+            dpart, amaxp = _ptr(T['dbias_part'][k]), _ptr(T['absmax'][k])
             if sync:
                 # (dgamma, dbeta) are adjacent in gflat and stay the rank-LOCAL sums there (the end-of-step all-reduce
                 # of gflat makes them global exactly once); the apply pass needs the GLOBAL sums now: all-reduce a
@@ -1116,16 +1125,23 @@ class UNetEngine(object):
                 gg.copy_(self.gflat[g0:g0 + 2 * l.cout])
                 parallel.all_reduce_sum(gg)
                 L.dc_bn_bwd_apply_count(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed,
-                                        _ptr(gg), _ptr(gg, l.cout), dz, _ptr(T['part_ws2']), _ptr(T['absmax']), pixels,
+                                        _ptr(gg), _ptr(gg, l.cout), dz, dpart, amaxp, pixels,
                                         float(world * pixels), l.cout, st)
             else:
                 L.dc_bn_bwd_apply(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed, dgamma, dbeta,
-                                  dz, _ptr(T['part_ws2']), _ptr(T['absmax']), pixels, l.cout, st)
+                                  dz, dpart, amaxp, pixels, l.cout, st)
             f16 = self.mfma == 'f16x3'
             # one launch: conv-bias gradient (column sums of the dz partials) + -- f16x3 -- the exact power-of-two scale
-            # that brings max|dz| to [512, 1024] before the fp16 split
-            L.dc_bn_bwd_apply_finalize(_ptr(T['part_ws2']), _ptr(T['absmax']) if f16 else None, blocks, l.cout, 1024.0,
-                                       self.pview(self.gflat, l, 'b'), scale if f16 else None, st)
+            # that brings max|dz| to [512, 1024] before the fp16 split.  Nothing on the critical path needs its outputs when
+            # the data gradient derives the scale from the per-block maxima itself (finalize_side): it then runs on the
+            # weight-gradient stream, in front of the weight gradient that reads the scale.
+            def finalize(stream):
+                L.dc_bn_bwd_apply_finalize(dpart, amaxp if f16 else None, blocks, l.cout, 1024.0,
+                                           self.pview(self.gflat, l, 'b'), scale if f16 else None, stream)
+            side_fin = self.finalize_side and f16
+            if not side_fin:
+                finalize(st)
+            d_scale, d_amax, d_amax_n = (None, amaxp, blocks) if side_fin else (scale, None, 0)
             if two:
                 ready = torch.cuda.Event()
                 ready.record(main)
@@ -1135,13 +1151,15 @@ class UNetEngine(object):
             if self.wgrad_order_hybrid:
                 after = f16 and l.kind == 'conv' and L.dc_conv3x3_pp_blocks(N, h, w, l.cin, l.cout, 1, 0) > 0
             if dx_ptr is not None and after:
-                fused_next = launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16, red)
+                fused_next = launch_dgrad(l, dz, wpd, dx_ptr, d_scale, h, w, f16, red, d_amax, d_amax_n)
                 if two:
                     ready = torch.cuda.Event()
                     ready.record(main)
             # ---- side stream: weight gradient of this block -------------------------------------------------------
             if two:
                 side.wait_event(ready)
+            if side_fin:
+                finalize(sw)
             dk, ws = self.pview(self.gflat, l, 'k'), _ptr(T['wgrad_ws'])
             if bsrc is not None and l.kind == 'conv':
                 L.dc_conv3x3_wgrad_bnin_f16x3(bsrc[0], bsrc[1][0], bsrc[1][1], self._ab_in(l), dz, dk, ws, scale, N, h, w,
@@ -1162,7 +1180,7 @@ class UNetEngine(object):
                 self._dz_free[k] = torch.cuda.Event()
                 self._dz_free[k].record(side)
             if dx_ptr is not None and not after:
-                fused_next = launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16, red)
+                fused_next = launch_dgrad(l, dz, wpd, dx_ptr, d_scale, h, w, f16, red, d_amax, d_amax_n)
             return fused_next
 
         def red_of(la):          # dgrad-fused BatchNorm-backward sums: dense da of a dropout-free layer only

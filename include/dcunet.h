@@ -100,12 +100,18 @@ int dc_pack_weights_f16x3_batch(const long* jobs_dev, int njobs, int total_block
 int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, double* stats,
                          const float* scale, const float* shift, int relu, const float* in_abound, long in_abound_ld,
                          float* out_absmax, long out_absmax_ld, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
-int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
+/* data gradients: the power-of-two scale of dz comes EITHER as a device scalar (dz_scale, from dc_pow2_scale_from_absmax /
+ * dc_bn_bwd_apply_finalize; nullable = 1) OR as the per-block max |dz| array dc_bn_bwd_apply wrote (dz_absmax[dz_absmax_n]):
+ * every workgroup then derives the same power of two itself (target 1024), and no finalize launch sits between the
+ * BatchNorm-backward apply pass and the data gradient.  Pass at most one of the two. */
+int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* dz_scale,
+                           const float* dz_absmax, int dz_absmax_n,
                            int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, double* stats,
                           const float* scale, const float* shift, int relu, const float* in_abound, long in_abound_ld,
                           float* out_absmax, long out_absmax_ld, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
-int dc_convT2x2_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
+int dc_convT2x2_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* dz_scale,
+                            const float* dz_absmax, int dz_absmax_n,
                             int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 /* weight gradients: same workspace (dc_*_wgrad_ws_floats) and fixed-order slab reduction as the fp32 entry points;
  * dz_scale = device scalar from dc_pow2_scale_from_absmax (nullable). */
@@ -228,7 +234,8 @@ int dc_conv3x3_fwd_pool_f16x3(const float* x, const void* wp16, const float* bia
  * data gradient, exceeds 32; <4,1,*> otherwise); 0: one of the 256-thread kernels.  Depends on shape and DC_IGEMM_PP only. */
 int dc_conv3x3_pp_blocks(int N, int H, int W, int Cin, int Cout, int dgrad, int with_stats);
 int dc_conv3x3_dgrad_bnred_blocks(int N, int H, int W, int Cin, int Cout);
-int dc_conv3x3_dgrad_bnred_f16x3(const float* dz, const void* wp16, float* dx, const float* dz_scale, const float* z,
+int dc_conv3x3_dgrad_bnred_f16x3(const float* dz, const void* wp16, float* dx, const float* dz_scale,
+                                 const float* dz_absmax, int dz_absmax_n, const float* z,
                                  const float* mean, const float* invstd, const float* gamma, const float* beta,
                                  float* bn_partial, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 int dc_head_bwd_bnin_bnred(const float* z_in, const float* in_scale, const float* in_shift, const float* p,

@@ -225,7 +225,7 @@ def test_dgrad_bn_backward_sums_per_tile_at_batch_16(HW, Cin, Cout):
     outs = []
     for _ in range(3):
         part = torch.full((rows * Cin * 2,), float('nan'), device='cuda')
-        L.dc_conv3x3_dgrad_bnred_f16x3(dz.data_ptr(), wpd.data_ptr(), dx.data_ptr(), scale.data_ptr(), z.data_ptr(), mu.data_ptr(),
+        L.dc_conv3x3_dgrad_bnred_f16x3(dz.data_ptr(), wpd.data_ptr(), dx.data_ptr(), scale.data_ptr(), None, 0, z.data_ptr(), mu.data_ptr(),
                                        isd.data_ptr(), ga.data_ptr(), be.data_ptr(), part.data_ptr(), Nb, HW, HW, Cin, Cout, None)
         torch.cuda.synchronize()
         outs.append(part.cpu().numpy().reshape(rows, Cin, 2))

@@ -143,9 +143,19 @@ def test_conv3x3_f16x3_fwd_dgrad(dclib, N, H, W, Ci, Co):
     scl = torch.empty(1, device='cuda')
     L.dc_pow2_scale_from_absmax(amax.data_ptr(), 1, 1024.0, scl.data_ptr(), None)
     dx = torch.full((N, H, W, Ci), float('nan'), device='cuda')
-    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
+    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), scl.data_ptr(), None, 0, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert rel_err(dx.cpu().numpy(), dx_ref) < 2e-5
+    # the scale derived IN the kernel from per-block maxima (what dc_bn_bwd_apply leaves behind; the true maximum sits in
+    # one of 37 entries, the others are smaller): same power of two, same bits
+    part = np.full(37, np.abs(dz).max() * 0.3, np.float32)
+    part[11] = np.abs(dz).max()
+    dxa = torch.full((N, H, W, Ci), float('nan'), device='cuda')
+    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dxa.data_ptr(), None, dev(part).data_ptr(), 37, N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dxa)
+    with pytest.raises(Exception, match='not both'):
+        L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dxa.data_ptr(), scl.data_ptr(), dev(part).data_ptr(), 37, N, H, W, Ci, Co, None)
     ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, H, W, Ci, Co), device='cuda')
     dw = torch.full((3, 3, Ci, Co), float('nan'), device='cuda')
     L.dc_conv3x3_wgrad_f16x3(dev(x).data_ptr(), dev(dz).data_ptr(), dw.data_ptr(), ws.data_ptr(), scl.data_ptr(),
@@ -154,7 +164,7 @@ def test_conv3x3_f16x3_fwd_dgrad(dclib, N, H, W, Ci, Co):
     _, dK_ref, _ = on.conv3x3_bwd(x.astype(np.float64), K.astype(np.float64), dz.astype(np.float64))
     assert rel_err(dw.cpu().numpy(), dK_ref) < 2e-5
     # without the scale the same input underflows fp16 and the result is garbage-level: the scale is load-bearing
-    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, N, H, W, Ci, Co, None)
+    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, None, 0, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert rel_err(dx.cpu().numpy(), dx_ref) > 1e-3
 
@@ -370,13 +380,19 @@ def test_convT2x2(dclib, N, H, W, Ci, Co):
     torch.cuda.synchronize()
     assert torch.equal(zi, z2)
     dx2 = torch.full((N, H, W, Ci), float('nan'), device='cuda')
-    L.dc_convT2x2_dgrad_f16x3(dev(dzs).data_ptr(), wpd16.data_ptr(), dx2.data_ptr(), scl.data_ptr(), N, H, W, Ci, Co, None)
+    L.dc_convT2x2_dgrad_f16x3(dev(dzs).data_ptr(), wpd16.data_ptr(), dx2.data_ptr(), scl.data_ptr(), None, 0, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert rel_err(z2.cpu().numpy(), z_ref) < 2e-5
     assert np.array_equal(amx.cpu().numpy(), np.abs(z2.cpu().numpy()).max((0, 1, 2)))
     st2 = stats2.cpu().numpy().reshape(tiles, 4, Co, 2).astype(np.float64).sum((0, 1))
     assert np.allclose(st2[:, 1], (z_ref ** 2).sum((0, 1, 2)), rtol=1e-4)
     assert rel_err(dx2.cpu().numpy(), dx_ref * 1e-7) < 2e-5
+    part = np.full(5, np.abs(dzs).max() * 0.5, np.float32)
+    part[4] = np.abs(dzs).max()
+    dx3 = torch.full((N, H, W, Ci), float('nan'), device='cuda')
+    L.dc_convT2x2_dgrad_f16x3(dev(dzs).data_ptr(), wpd16.data_ptr(), dx3.data_ptr(), None, dev(part).data_ptr(), 5, N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert torch.equal(dx2, dx3)                     # scale derived in the kernel from per-block maxima: same bits
     dw2 = torch.full((2, 2, Co, Ci), float('nan'), device='cuda')
     L.dc_convT2x2_wgrad_f16x3(dev(x).data_ptr(), dev(dzs).data_ptr(), dw2.data_ptr(), ws.data_ptr(), scl.data_ptr(),
                               None, N, H, W, Ci, Co, None)
@@ -550,13 +566,21 @@ def test_dgrad_with_fused_bn_backward_sums(dclib, N, H, W, Cin, Cout):
     ga = dev((rs.standard_normal(Cin)).astype(np.float32)); be = dev((rs.standard_normal(Cin) * 0.3).astype(np.float32))
     scale = torch.full((4,), 4.0, device='cuda')
     dx0 = torch.full((N, H, W, Cin), float('nan'), device='cuda'); dx1 = torch.full_like(dx0, float('nan'))
-    L.dc_conv3x3_dgrad_f16x3(dz.data_ptr(), wpd.data_ptr(), dx0.data_ptr(), scale.data_ptr(), N, H, W, Cin, Cout, None)
+    L.dc_conv3x3_dgrad_f16x3(dz.data_ptr(), wpd.data_ptr(), dx0.data_ptr(), scale.data_ptr(), None, 0, N, H, W, Cin, Cout, None)
     part = torch.full((rows * Cin * 2,), float('nan'), device='cuda')
-    L.dc_conv3x3_dgrad_bnred_f16x3(dz.data_ptr(), wpd.data_ptr(), dx1.data_ptr(), scale.data_ptr(), z.data_ptr(), mu.data_ptr(),
+    L.dc_conv3x3_dgrad_bnred_f16x3(dz.data_ptr(), wpd.data_ptr(), dx1.data_ptr(), scale.data_ptr(), None, 0, z.data_ptr(), mu.data_ptr(),
                                    isd.data_ptr(), ga.data_ptr(), be.data_ptr(), part.data_ptr(), N, H, W, Cin, Cout, None)
     torch.cuda.synchronize()
     assert np.array_equal(dx0.cpu().numpy(), dx1.cpu().numpy())
     assert np.isfinite(part.cpu().numpy()).all()
+    # the same launch with the power of two derived in the kernel from per-block maxima (max 255.9 -> scale 4): same bits
+    amax_part = torch.full((19,), 100.0, device='cuda')
+    amax_part[7] = 255.9
+    dx2, part2 = torch.full_like(dx0, float('nan')), torch.full_like(part, float('nan'))
+    L.dc_conv3x3_dgrad_bnred_f16x3(dz.data_ptr(), wpd.data_ptr(), dx2.data_ptr(), None, amax_part.data_ptr(), 19, z.data_ptr(), mu.data_ptr(),
+                                   isd.data_ptr(), ga.data_ptr(), be.data_ptr(), part2.data_ptr(), N, H, W, Cin, Cout, None)
+    torch.cuda.synchronize()
+    assert torch.equal(dx1, dx2) and torch.equal(part, part2)
     pixels = N * H * W
     todo = [(part, rows)]
     if Cin & (Cin - 1) == 0:             # (the two-pass kernel takes power-of-two channel counts only)

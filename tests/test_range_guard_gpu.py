@@ -61,7 +61,7 @@ def test_kernel_magnitude_does_not_matter(dclib, wscale):
     dx = torch.full((N, H, W, Ci), float('nan'), device='cuda')
     L.dc_conv3x3_fwd_f16x3(dev(x).data_ptr(), wp.data_ptr(), None, z.data_ptr(), Co, None, None, None, 0, None, 0, None, 0,
                            N, H, W, Ci, Co, None)
-    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, N, H, W, Ci, Co, None)
+    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, None, 0, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert rel_err(z.cpu().numpy(), z_ref) < 2e-5
     assert rel_err(dx.cpu().numpy(), dx_ref) < 2e-5
