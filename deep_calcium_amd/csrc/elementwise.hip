@@ -14,6 +14,8 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 // CU at its 90 VGPRs) -- no second, partly filled round beside the weight-gradient stream (2 048: -1.7 % end to end,
 // 1 024: -0.8 %, 4 096: -3.9 %; DC_EW_BLOCKS to re-measure)
 static const int kMaxBlocks = getenv("DC_EW_BLOCKS") ? atoi(getenv("DC_EW_BLOCKS")) : 1280;
+// the BatchNorm-backward passes (reduce / apply) run BESIDE the weight-gradient kernel of the side stream: their own cap
+static const int kMaxBwdBlocks = getenv("DC_EW_BWD_BLOCKS") ? atoi(getenv("DC_EW_BWD_BLOCKS")) : kMaxBlocks;
 __device__ __forceinline__ void bn_affine4(const f32x4& mu, const f32x4& is, const f32x4& ga, const f32x4& be, f32x4& sc,
                                            f32x4& sh) {
 #pragma unroll
@@ -34,11 +36,12 @@ static int chan_check(const char* fn, int C) {
   DC_REQUIRE(C >= 4 && C <= 1024 && dc_is_pow2(C), DC_EUNSUP, "%s: C=%d must be a power of two in [4,1024]", fn, C);
   return DC_OK;
 }
-static int ew_blocks(long pixels, int C) {
+static int ew_blocks(long pixels, int C, int cap = kMaxBlocks) {
   const int PPB = 256 / (C / 4);
   long b = (pixels + PPB - 1) / PPB;
-  return (int)(b > kMaxBlocks ? kMaxBlocks : (b < 1 ? 1 : b));
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
+static int ew_bwd_blocks(long pixels, int C) { return ew_blocks(pixels, C, kMaxBwdBlocks); }
 
 // ------------------------------------------------------------------------------------------------
 // BN statistics finalize: one block per channel, double accumulation over all partials.
@@ -47,16 +50,20 @@ static int ew_blocks(long pixels, int C) {
 __device__ __forceinline__ float bn_abound(float gamma, float beta, double count, float inv_keep) {
   return (fabsf(gamma) * (float)sqrt(count) + fabsf(beta)) * inv_keep;
 }
-__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ partial, int parts, int groups,
-                                                               int C, double count, float eps, float momentum,
-                                                               float* mean, float* invstd, float* mmean, float* mvar,
-                                                               const float* gamma, const float* beta, float* scale,
-                                                               float* shift, float* abound) {
-  __shared__ double sh1[256], sh2[256];
+// One block per channel; T threads stride over the (tile, group) partials of that channel (16-byte reads C*16 bytes apart:
+// latency-bound, so the 512^2 / 256^2 layers -- thousands of tiles -- take 1024 threads: 11.8 -> ~4 us on the forward's
+// critical path, 22 launches per step); fixed-shape tree => bit-reproducible.
+template <int T>
+__global__ __launch_bounds__(T) void bn_stats_finalize_kernel(const double* __restrict__ partial, int parts, int groups,
+                                                             int C, double count, float eps, float momentum,
+                                                             float* mean, float* invstd, float* mmean, float* mvar,
+                                                             const float* gamma, const float* beta, float* scale,
+                                                             float* shift, float* abound) {
+  __shared__ double sh1[T], sh2[T];
   const int c = blockIdx.x, tid = threadIdx.x;
   const int Ct = groups * C;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = tid; i < parts * groups; i += 256) {
+  for (int i = tid; i < parts * groups; i += T) {
     const int pt = i / groups, g = i - pt * groups;
     const double* src = partial + ((long)pt * Ct + g * C + c) * 2;
     s1 += src[0];
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
   }
   sh1[tid] = s1; sh2[tid] = s2;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = T / 2; s > 0; s >>= 1) {
     if (tid < s) { sh1[tid] += sh1[tid + s]; sh2[tid] += sh2[tid + s]; }
     __syncthreads();
   }
@@ -89,9 +96,14 @@ extern "C" int dc_bn_stats_finalize(const double* partial, int parts, int groups
                                     dc_stream_t stream) {
   DC_REQUIRE(partial && mean && invstd, DC_EINVAL, "dc_bn_stats_finalize: null pointer");
   DC_REQUIRE(parts > 0 && groups > 0 && C > 0 && count > 0, DC_EINVAL, "dc_bn_stats_finalize: bad sizes");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C,
-                     count, eps, momentum, mean, invstd, moving_mean, moving_var, (const float*)nullptr,
-                     (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  if ((long)parts * groups > 1024)
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<1024>, dim3(C), dim3(1024), 0, (hipStream_t)stream, partial, parts, groups, C,
+                       count, eps, momentum, mean, invstd, moving_mean, moving_var, (const float*)nullptr,
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  else
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C,
+                       count, eps, momentum, mean, invstd, moving_mean, moving_var, (const float*)nullptr,
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   DC_CHECK_LAUNCH("dc_bn_stats_finalize");
   return DC_OK;
 }
@@ -103,8 +115,12 @@ extern "C" int dc_bn_stats_finalize_affine(const double* partial, int parts, int
   DC_REQUIRE(partial && mean && invstd && gamma && beta && scale && shift, DC_EINVAL,
              "dc_bn_stats_finalize_affine: null pointer");
   DC_REQUIRE(parts > 0 && groups > 0 && C > 0 && count > 0, DC_EINVAL, "dc_bn_stats_finalize_affine: bad sizes");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C,
-                     count, eps, momentum, mean, invstd, moving_mean, moving_var, gamma, beta, scale, shift, abound);
+  if ((long)parts * groups > 1024)
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<1024>, dim3(C), dim3(1024), 0, (hipStream_t)stream, partial, parts, groups, C,
+                       count, eps, momentum, mean, invstd, moving_mean, moving_var, gamma, beta, scale, shift, abound);
+  else
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C,
+                       count, eps, momentum, mean, invstd, moving_mean, moving_var, gamma, beta, scale, shift, abound);
   DC_CHECK_LAUNCH("dc_bn_stats_finalize_affine");
   return DC_OK;
 }
@@ -496,7 +512,7 @@ extern "C" int dc_bn_bwd_apply_finalize(const float* dbias_partial, const float*
   return DC_OK;
 }
 
-extern "C" int dc_bn_bwd_blocks(long pixels, int C) { return ew_blocks(pixels, C); }
+extern "C" int dc_bn_bwd_blocks(long pixels, int C) { return ew_bwd_blocks(pixels, C); }
 
 extern "C" int dc_bn_bwd_reduce(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
                                 const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
@@ -508,7 +524,7 @@ extern "C" int dc_bn_bwd_reduce(const float* da, long da_ld, const float* z, con
   BnParams p{};
   p.da = da; p.da_ld = da_ld; p.z = z; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
   p.mask = mask; p.keep = keep; p.seed = seed; p.partial = partial; p.pixels = pixels; p.C = C;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ew_blocks(pixels, C)), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ew_bwd_blocks(pixels, C)), dim3(256), 0, (hipStream_t)stream, p);
   DC_CHECK_LAUNCH("dc_bn_bwd_reduce");
   return DC_OK;
 }
@@ -545,7 +561,7 @@ static int bn_bwd_apply_impl(const float* da, long da_ld, const float* z, const 
   p.da = da; p.da_ld = da_ld; p.z = z; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
   p.mask = mask; p.keep = keep; p.seed = seed; p.dgamma = dgamma; p.dbeta = dbeta; p.out = dz; p.out_ld = C;
   p.partial = dbias_partial; p.absmax = absmax_partial; p.pixels = pixels; p.C = C; p.count = count;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(pixels, C)), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_bwd_blocks(pixels, C)), dim3(256), 0, (hipStream_t)stream, p);
   DC_CHECK_LAUNCH("dc_bn_bwd_apply");
   return DC_OK;
 }

@@ -216,7 +216,11 @@ class UNetEngine(object):
         self.dgrad_bnred = os.environ.get('DC_DGRAD_BNRED', '1') == '1'
         # the finalize launch behind the BatchNorm-backward apply pass (conv-bias gradient + power-of-two scale of dz) runs on
         # the weight-gradient stream; the data gradient derives the scale itself from the per-block maxima
-        self.finalize_side = self.mfma == 'f16x3' and os.environ.get('DC_FINALIZE_SIDE', '1') == '1'
+        # DC_FINALIZE_SIDE = auto (default) | 1 | 0.  Measured (same box): at the reference's own training windows (128^2 x 20,
+        # launch-latency bound) it takes one launch per block off the critical path, +1.3 %; at 512^2 x 16 the backward's critical
+        # chain is data gradient -> weight gradient -> next data gradient (both own their CUs; the BatchNorm passes hide under
+        # the weight gradient), so a launch in front of the weight gradient lengthens it: -0.7 %.  auto: small steps only.
+        self.finalize_side = os.environ.get('DC_FINALIZE_SIDE', 'auto') if self.mfma == 'f16x3' else '0'
         self._head_bwd_done = False
         # fp16 range guard of the activation operands (A/B knob; the weights' pack-time scale is unconditional)
         self.range_guard = os.environ.get('DC_RANGE_GUARD', '1') == '1'
@@ -1138,7 +1142,7 @@ class UNetEngine(object):
             def finalize(stream):
                 L.dc_bn_bwd_apply_finalize(dpart, amaxp if f16 else None, blocks, l.cout, 1024.0,
                                            self.pview(self.gflat, l, 'b'), scale if f16 else None, stream)
-            side_fin = self.finalize_side and f16
+            side_fin = f16 and (self.finalize_side == '1' or (self.finalize_side == 'auto' and N * self.H * self.W <= (1 << 20)))
             if not side_fin:
                 finalize(st)
             d_scale, d_amax, d_amax_n = (None, amaxp, blocks) if side_fin else (scale, None, 0)
