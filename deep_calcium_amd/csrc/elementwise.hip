@@ -15,6 +15,7 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 // 1 024: -0.8 %, 4 096: -3.9 %; DC_EW_BLOCKS to re-measure)
 static const int kMaxBlocks = getenv("DC_EW_BLOCKS") ? atoi(getenv("DC_EW_BLOCKS")) : 1280;
 // the BatchNorm-backward passes (reduce / apply) run BESIDE the weight-gradient kernel of the side stream: their own cap
+static const bool kWideStatsFinalize = !(getenv("DC_STATS_FINALIZE_WIDE") && atoi(getenv("DC_STATS_FINALIZE_WIDE")) == 0);
 static const int kMaxBwdBlocks = getenv("DC_EW_BWD_BLOCKS") ? atoi(getenv("DC_EW_BWD_BLOCKS")) : kMaxBlocks;
 __device__ __forceinline__ void bn_affine4(const f32x4& mu, const f32x4& is, const f32x4& ga, const f32x4& be, f32x4& sc,
                                            f32x4& sh) {
@@ -96,7 +97,7 @@ extern "C" int dc_bn_stats_finalize(const double* partial, int parts, int groups
                                     dc_stream_t stream) {
   DC_REQUIRE(partial && mean && invstd, DC_EINVAL, "dc_bn_stats_finalize: null pointer");
   DC_REQUIRE(parts > 0 && groups > 0 && C > 0 && count > 0, DC_EINVAL, "dc_bn_stats_finalize: bad sizes");
-  if ((long)parts * groups > 1024)
+  if (kWideStatsFinalize && (long)parts * groups > 1024)
     hipLaunchKernelGGL(bn_stats_finalize_kernel<1024>, dim3(C), dim3(1024), 0, (hipStream_t)stream, partial, parts, groups, C,
                        count, eps, momentum, mean, invstd, moving_mean, moving_var, (const float*)nullptr,
                        (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
@@ -115,7 +116,7 @@ extern "C" int dc_bn_stats_finalize_affine(const double* partial, int parts, int
   DC_REQUIRE(partial && mean && invstd && gamma && beta && scale && shift, DC_EINVAL,
              "dc_bn_stats_finalize_affine: null pointer");
   DC_REQUIRE(parts > 0 && groups > 0 && C > 0 && count > 0, DC_EINVAL, "dc_bn_stats_finalize_affine: bad sizes");
-  if ((long)parts * groups > 1024)
+  if (kWideStatsFinalize && (long)parts * groups > 1024)
     hipLaunchKernelGGL(bn_stats_finalize_kernel<1024>, dim3(C), dim3(1024), 0, (hipStream_t)stream, partial, parts, groups, C,
                        count, eps, momentum, mean, invstd, moving_mean, moving_var, gamma, beta, scale, shift, abound);
   else
