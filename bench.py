@@ -520,7 +520,8 @@ def main():
         kname, peak, mfma_per_flop = KernelTimer.KERNELS[eng.mfma]
         traffic, traffic_note = pmc_traffic(kname)
         out = {
-            'metric': '512x512 summary images/sec (train step)', 'value': round(world * B * args.steps / dt, 3),
+            'metric': ('512x512 summary images/sec (train step)' if H == 512 else '%dx%d training windows/sec (train step)' % (H, W)),
+            'value': round(world * B * args.steps / dt, 3),
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': DTYPE_LABEL[eng.mfma], 'data': 'synthetic',
