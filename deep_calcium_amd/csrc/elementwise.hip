@@ -15,7 +15,7 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 // 1 024: -0.8 %, 4 096: -3.9 %; DC_EW_BLOCKS to re-measure)
 static const int kMaxBlocks = getenv("DC_EW_BLOCKS") ? atoi(getenv("DC_EW_BLOCKS")) : 1280;
 // the BatchNorm-backward passes (reduce / apply) run BESIDE the weight-gradient kernel of the side stream: their own cap
-static const bool kWideStatsFinalize = !(getenv("DC_STATS_FINALIZE_WIDE") && atoi(getenv("DC_STATS_FINALIZE_WIDE")) == 0);
+// (measured flat between 768 and 1280 workgroups, -0.7 % at 512 and at 1792)
 static const int kMaxBwdBlocks = getenv("DC_EW_BWD_BLOCKS") ? atoi(getenv("DC_EW_BWD_BLOCKS")) : kMaxBlocks;
 __device__ __forceinline__ void bn_affine4(const f32x4& mu, const f32x4& is, const f32x4& ga, const f32x4& be, f32x4& sc,
                                            f32x4& sh) {
@@ -51,20 +51,16 @@ static int ew_bwd_blocks(long pixels, int C) { return ew_blocks(pixels, C, kMaxB
 __device__ __forceinline__ float bn_abound(float gamma, float beta, double count, float inv_keep) {
   return (fabsf(gamma) * (float)sqrt(count) + fabsf(beta)) * inv_keep;
 }
-// One block per channel; T threads stride over the (tile, group) partials of that channel (16-byte reads C*16 bytes apart:
-// latency-bound, so the 512^2 / 256^2 layers -- thousands of tiles -- take 1024 threads: 11.8 -> ~4 us on the forward's
-// critical path, 22 launches per step); fixed-shape tree => bit-reproducible.
-template <int T>
-__global__ __launch_bounds__(T) void bn_stats_finalize_kernel(const double* __restrict__ partial, int parts, int groups,
-                                                             int C, double count, float eps, float momentum,
-                                                             float* mean, float* invstd, float* mmean, float* mvar,
-                                                             const float* gamma, const float* beta, float* scale,
-                                                             float* shift, float* abound) {
-  __shared__ double sh1[T], sh2[T];
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ partial, int parts, int groups,
+                                                               int C, double count, float eps, float momentum,
+                                                               float* mean, float* invstd, float* mmean, float* mvar,
+                                                               const float* gamma, const float* beta, float* scale,
+                                                               float* shift, float* abound) {
+  __shared__ double sh1[256], sh2[256];
   const int c = blockIdx.x, tid = threadIdx.x;
   const int Ct = groups * C;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = tid; i < parts * groups; i += T) {
+  for (int i = tid; i < parts * groups; i += 256) {
     const int pt = i / groups, g = i - pt * groups;
     const double* src = partial + ((long)pt * Ct + g * C + c) * 2;
     s1 += src[0];
@@ -72,7 +68,7 @@ __global__ __launch_bounds__(T) void bn_stats_finalize_kernel(const double* __re
   }
   sh1[tid] = s1; sh2[tid] = s2;
   __syncthreads();
-  for (int s = T / 2; s > 0; s >>= 1) {
+  for (int s = 128; s > 0; s >>= 1) {
     if (tid < s) { sh1[tid] += sh1[tid + s]; sh2[tid] += sh2[tid + s]; }
     __syncthreads();
   }
@@ -97,14 +93,9 @@ extern "C" int dc_bn_stats_finalize(const double* partial, int parts, int groups
                                     dc_stream_t stream) {
   DC_REQUIRE(partial && mean && invstd, DC_EINVAL, "dc_bn_stats_finalize: null pointer");
   DC_REQUIRE(parts > 0 && groups > 0 && C > 0 && count > 0, DC_EINVAL, "dc_bn_stats_finalize: bad sizes");
-  if (kWideStatsFinalize && (long)parts * groups > 1024)
-    hipLaunchKernelGGL(bn_stats_finalize_kernel<1024>, dim3(C), dim3(1024), 0, (hipStream_t)stream, partial, parts, groups, C,
-                       count, eps, momentum, mean, invstd, moving_mean, moving_var, (const float*)nullptr,
-                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
-  else
-    hipLaunchKernelGGL(bn_stats_finalize_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C,
-                       count, eps, momentum, mean, invstd, moving_mean, moving_var, (const float*)nullptr,
-                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C,
+                     count, eps, momentum, mean, invstd, moving_mean, moving_var, (const float*)nullptr,
+                     (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   DC_CHECK_LAUNCH("dc_bn_stats_finalize");
   return DC_OK;
 }
@@ -116,12 +107,8 @@ extern "C" int dc_bn_stats_finalize_affine(const double* partial, int parts, int
   DC_REQUIRE(partial && mean && invstd && gamma && beta && scale && shift, DC_EINVAL,
              "dc_bn_stats_finalize_affine: null pointer");
   DC_REQUIRE(parts > 0 && groups > 0 && C > 0 && count > 0, DC_EINVAL, "dc_bn_stats_finalize_affine: bad sizes");
-  if (kWideStatsFinalize && (long)parts * groups > 1024)
-    hipLaunchKernelGGL(bn_stats_finalize_kernel<1024>, dim3(C), dim3(1024), 0, (hipStream_t)stream, partial, parts, groups, C,
-                       count, eps, momentum, mean, invstd, moving_mean, moving_var, gamma, beta, scale, shift, abound);
-  else
-    hipLaunchKernelGGL(bn_stats_finalize_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C,
-                       count, eps, momentum, mean, invstd, moving_mean, moving_var, gamma, beta, scale, shift, abound);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, parts, groups, C,
+                     count, eps, momentum, mean, invstd, moving_mean, moving_var, gamma, beta, scale, shift, abound);
   DC_CHECK_LAUNCH("dc_bn_stats_finalize_affine");
   return DC_OK;
 }

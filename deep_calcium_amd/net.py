@@ -201,6 +201,9 @@ class UNetEngine(object):
         self.wgrad_after_dgrad = _order == '1'
         self.wgrad_order_hybrid = _order == '2'
         self.dz_bufs = int(os.environ.get('DC_DZ_BUFS', '3'))
+        # levels whose weight gradients run on the MAIN stream (no overlap): at 512^2 the weight-gradient kernels are
+        # HBM-bound themselves, so beside an HBM-bound BatchNorm pass the two only share the bandwidth (and lose some)
+        self.wgrad_main_lvls = frozenset(int(v) for v in os.environ.get('DC_WGRAD_MAIN_LVLS', '').split(',') if v != '')
         # BN + ReLU on load: activations that only feed a conv / conv-transpose / the head (no dropout, pool or
         # skip) are never written; their consumers take (z, scale, shift) instead.  f16x3 kernels only.
         self.bnin = self.mfma == 'f16x3' and os.environ.get('DC_BNIN', '1') == '1'
@@ -1068,6 +1071,7 @@ class UNetEngine(object):
         if two:
             side.wait_stream(main)        # everything queued so far (forward, head) precedes the first wgrad
         self._dz_turn = getattr(self, '_dz_turn', 0)
+        self._last_side_w = None
 
         def launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16, red=None, amax=None, amax_n=0):
             """red = the BatchNorm layer whose `da` this data gradient writes (dense, no dropout): when the role-split
@@ -1146,7 +1150,8 @@ class UNetEngine(object):
             if not side_fin:
                 finalize(st)
             d_scale, d_amax, d_amax_n = (None, amaxp, blocks) if side_fin else (scale, None, 0)
-            if two:
+            on_main = two and l.lvl in self.wgrad_main_lvls       # this block's weight gradient stays on the main stream
+            if two and not on_main:
                 ready = torch.cuda.Event()
                 ready.record(main)
             # ---- main stream first: the data gradient feeds the next block ---------------------------------------
@@ -1156,11 +1161,16 @@ class UNetEngine(object):
                 after = f16 and l.kind == 'conv' and L.dc_conv3x3_pp_blocks(N, h, w, l.cin, l.cout, 1, 0) > 0
             if dx_ptr is not None and after:
                 fused_next = launch_dgrad(l, dz, wpd, dx_ptr, d_scale, h, w, f16, red, d_amax, d_amax_n)
-                if two:
+                if two and not on_main:
                     ready = torch.cuda.Event()
                     ready.record(main)
             # ---- side stream: weight gradient of this block -------------------------------------------------------
-            if two:
+            sw = side.cuda_stream
+            if on_main:
+                sw = st
+                if self._last_side_w is not None:
+                    main.wait_event(self._last_side_w)      # the shared slab workspace: one weight gradient at a time
+            elif two:
                 side.wait_event(ready)
             if side_fin:
                 finalize(sw)
@@ -1180,9 +1190,12 @@ class UNetEngine(object):
                 L.dc_convT2x2_wgrad_f16x3(x_in, dz, dk, ws, scale, self._ab_in(l), N, h // 2, w // 2, l.cin, l.cout, sw)
             else:
                 L.dc_convT2x2_wgrad(x_in, dz, dk, ws, N, h // 2, w // 2, l.cin, l.cout, sw)
-            if two:
+            if two and not on_main:
                 self._dz_free[k] = torch.cuda.Event()
                 self._dz_free[k].record(side)
+                self._last_side_w = self._dz_free[k]
+            elif two:
+                self._dz_free[k] = None                     # main-stream order protects the dz buffer
             if dx_ptr is not None and not after:
                 fused_next = launch_dgrad(l, dz, wpd, dx_ptr, d_scale, h, w, f16, red, d_amax, d_amax_n)
             return fused_next

@@ -2,7 +2,7 @@
 backward, how the matrix kernels -- data gradients (main queue) and weight gradients (side queue) -- and the BatchNorm
 passes interleave: matrix-kernel coverage of the span, dgrad/wgrad overlap, and where the BatchNorm passes sit.
 
-    python scripts/backward_chain.py gpurun_out/<dir>/p_kernel_trace.csv
+    python scripts/backward_chain.py gpurun_out/<dir>/p_kernel_trace.csv [step index, default 3]
 """
 import csv
 import re
@@ -39,7 +39,9 @@ for r in rows:
     r['s'], r['e'], r['k'] = int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name'])
 rows.sort(key=lambda r: r['s'])
 adam = [i for i, r in enumerate(rows) if r['k'].startswith('adam_kernel')]
-a0, a1 = adam[-3], adam[-2]
+# bench.py's LAST two steps run with one stream (roofline instrumentation): take a step of the timed region
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+a0, a1 = adam[k], adam[k + 1]
 step = rows[a0 + 1:a1 + 1]
 head = [i for i, r in enumerate(step) if r['k'].startswith('head_fwd_bwd') or r['k'].startswith('head_bwd')]
 bwd = step[head[0]:]

@@ -38,8 +38,13 @@ def main():
     sq, _ = read_counters(root + '/SQ_VALU_MFMA_BUSY_CYCLES/p_counter_collection.csv')
     # un-instrumented durations: the --kernel-trace --stats pass
     dur = collections.defaultdict(list)
-    for r in csv.DictReader(open(root + '/trace/p_kernel_trace.csv')):
-        dur[short(r['Kernel_Name'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    import os
+    if os.path.exists(root + '/trace/p_kernel_trace.csv'):
+        for r in csv.DictReader(open(root + '/trace/p_kernel_trace.csv')):
+            dur[short(r['Kernel_Name'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    else:       # only the --stats summary of that pass was kept: calls x average duration
+        for r in csv.DictReader(open(root + '/trace/p_kernel_stats.csv')):
+            dur[short(r['Name'])] = [float(r['AverageNs'])] * int(r['Calls'])
     steps_trace = None
     rows = []
     for k, d in dur.items():

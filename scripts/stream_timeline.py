@@ -24,7 +24,9 @@ rows.sort(key=lambda r: r['s'])
 adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
 if len(adam) < 3:
     raise SystemExit('need at least 3 optimizer steps in the trace')
-a0, a1 = adam[-3], adam[-2]
+# (bench.py's last two steps run single-stream for the roofline instrumentation: default to a step of the timed region)
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+a0, a1 = adam[k], adam[k + 1]
 step = rows[a0 + 1:a1 + 1]
 t0, t1 = rows[a0]['e'], rows[a1]['e']
 print('step wall %.3f ms, %d launches' % ((t1 - t0) / 1e6, len(step)))
