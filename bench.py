@@ -557,6 +557,8 @@ def main():
             wd.phase('cpu_baseline', 300)
             out['cpu_baseline'] = cpu_baseline()
         emit_json(json.dumps(out))
+    wd.phase('process group shutdown', 120)
+    parallel.shutdown()
     wd.done()
 
 

@@ -398,7 +398,12 @@ class Model(object):
                         except queue.Full:
                             continue
             except Exception as e:      # surfaced on the consumer side
-                q.put(e)
+                while not stop.is_set():
+                    try:
+                        q.put(e, timeout=0.1)
+                        break
+                    except queue.Full:
+                        continue
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
@@ -437,6 +442,15 @@ class Model(object):
                     break
         finally:
             stop.set()
+            # the generator thread must be gone before the interpreter can exit: a daemon thread still inside native code
+            # (numpy, a queue wait) when Python finalises is unwound by force -- 'terminate called without an active
+            # exception', SIGABRT after a run that had finished fine (seen once in ~10 runs of the 2-rank example)
+            try:
+                while True:
+                    q.get_nowait()
+            except queue.Empty:
+                pass
+            th.join(timeout=30)
             for cb in cbs:
                 cb.on_train_end({})
         return self.history

@@ -59,7 +59,20 @@ def init_from_env(backend=None):
     # DC_DIST_BACKEND=gloo lets several ranks share ONE GPU (functional testing of the N>1 path on a 1-GPU box)
     backend = backend or os.environ.get('DC_DIST_BACKEND') or ('nccl' if use_cuda else 'gloo')
     dist.init_process_group(backend)
+    import atexit
+    atexit.register(shutdown)          # a process group alive at interpreter exit can abort in its threads' destructors
     return rank(), world_size()
+
+
+def shutdown():
+    """Tear the process group down (idempotent; registered at exit by init_from_env): without it the backend's worker
+    threads are destroyed while still joinable when the interpreter exits -- 'terminate called without an active exception',
+    SIGABRT after a run that had finished fine."""
+    if is_dist():
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 def shard_slice(global_batch, r=None, ws=None):
