@@ -46,7 +46,12 @@ def init_from_env(backend=None):
     if ws <= 1:
         os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('RANK', '0')
-        os.environ.setdefault('MASTER_PORT', '29511')
+        if 'MASTER_PORT' not in os.environ:       # a one-rank group needs no agreed port: take a free one
+            import socket
+            sk = socket.socket()
+            sk.bind(('127.0.0.1', 0))
+            os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
+            sk.close()
     local = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
     # RCCL's intra-node transport needs dmabuf IPC (HSA_ENABLE_IPC_MODE_LEGACY=0).  The variable is read when the HSA
     # runtime initialises, i.e. at the first GPU call of the process: launchers (bench.py, torchrun wrappers) must export
