@@ -215,8 +215,11 @@ def _scaled_weights(nfb, kscale, gscale, seed=31):
     return out
 
 
-@pytest.mark.parametrize('kscale,gscale', [(2.0 ** -12, 1.0), (2.0 ** 8, 1.0), (1.0, 3e4), (2.0 ** -10, 1e4)])
-def test_train_step_with_extreme_weights_matches_oracle(kscale, gscale):
+# per-tensor gradient bound (rel-L2 and max-abs / max) with the oracle's gates forced: 1e-3 under these scalings -- except
+# kernels x 2^-12 alone: the pre-BN variance (~1e-8) sits far below BatchNorm's eps = 1e-3, xhat is ~1e-3 and dgamma = sum dy * xhat
+# cancels to ~1e-2 of its terms, so fp32 rounding shows at the percent level in that one quantity (d0b's dgamma: 1.6e-2)
+@pytest.mark.parametrize('kscale,gscale,GRAD_REL', [(2.0 ** -12, 1.0, 0.05), (2.0 ** 8, 1.0, 1e-3), (1.0, 3e4, 1e-3), (2.0 ** -10, 1e4, 1e-3)])
+def test_train_step_with_extreme_weights_matches_oracle(kscale, gscale, GRAD_REL):
     """set_weights() with kernels x 2^-12 / x 2^8 and gamma, beta x 3e4 (activations ~1e5 > 65504): one training forward
     + backward against the float64 oracle -- probabilities and loss at 1e-4, gradients in rel-L2 -- and nothing is inf."""
     from deep_calcium_amd.net import UNetEngine
@@ -224,7 +227,7 @@ def test_train_step_with_extreme_weights_matches_oracle(kscale, gscale):
     Wt = _scaled_weights(nfb, kscale, gscale)
     x, y = on.synthetic_batch(N, H, W)
     masks = on.make_drop_masks(nfb, N, H, W)
-    loss_ref, p_ref, G_ref, _ = on.UNetOracle(Wt, nfb).loss_and_grads(x, y, masks)
+    from _forced import device_decisions, grad_report
     eng = UNetEngine((H, W), nb_filters_base=nfb)
     eng.set_weights(Wt)
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
@@ -232,6 +235,8 @@ def test_train_step_with_extreme_weights_matches_oracle(kscale, gscale):
     loss = eng.read_sums()[0] / p.size
     eng.backward()
     G = eng.grads()
+    # the oracle through the device's own ReLU gates / pool indices (tests/_forced.py): what is compared is rounding
+    loss_ref, p_ref, G_ref, _ = on.UNetOracle(Wt, nfb, force=device_decisions(eng, N)).loss_and_grads(x, y, masks)
     assert np.isfinite(p).all() and np.isfinite(eng.gflat.cpu().numpy()).all()
     if gscale > 1:
         assert max(float(eng.activation(n, N).abs().max()) for n in ('e0b', 'e1a', 'd1a')) > 65504      # really beyond fp16
@@ -244,8 +249,10 @@ def test_train_step_with_extreme_weights_matches_oracle(kscale, gscale):
         for j, g in enumerate(G_ref[n]):
             if keep(n, j) and np.linalg.norm(g) > 0:
                 rel = np.linalg.norm(G[n][j].astype(np.float64) - g) / np.linalg.norm(g)
-                assert rel < 0.05, (n, j, rel)
-    assert fg.dot(fr) / (np.linalg.norm(fg) * np.linalg.norm(fr)) > 0.999
+                assert rel < GRAD_REL, (n, j, rel)
+    worst, rel_all, _ = grad_report(G, G_ref, 'extreme weights k x %g, gamma x %g, forced gates: ' % (kscale, gscale))
+    assert worst < GRAD_REL, worst
+    assert fg.dot(fr) / (np.linalg.norm(fg) * np.linalg.norm(fr)) > (0.999 if GRAD_REL > 1e-3 else 0.999999)
 
 
 @pytest.mark.parametrize('xscale', [1e4, 1e-4])
