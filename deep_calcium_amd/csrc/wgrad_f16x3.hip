@@ -43,9 +43,6 @@ struct WgradHParams {
   // fp16 range guard of the ACTIVATION operand (common.h dc_block_guard_scale): its per-channel magnitude bound
   // (xChannels floats, nullable).  The gradient operand brings its scale in aScale / bScale.
   const float* xAbound; int xChannels;
-  // instead of the gradient operand's device scalar: dc_bn_bwd_apply's per-block max |dz| array -- every workgroup derives
-  // the power of two itself (dc_block_absmax_scale, target 1024): no finalize launch between the apply pass and this kernel
-  const float* gAbsmax; int gAbsmaxN;
 };
 
 // WM x WNW waves tile the CTA's (m, n) block, each wave covering 32 m x (32*NBW) n; the remaining
@@ -115,11 +112,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
   // operand scales (powers of two, undone in the epilogue): the gradient operand's device scalar, the activation
   // operand's range guard -- every wave needs them (producers to split, consumers to un-scale)
   const float x_scale = dc_block_guard_scale(hp.xAbound, hp.xChannels, reinterpret_cast<float*>(smem));
-  const float* g_ptr = A_SCALED ? hp.aScale : hp.bScale;
-  const float g_scale = hp.gAbsmax ? dc_block_absmax_scale(hp.gAbsmax, hp.gAbsmaxN, 1024.f, reinterpret_cast<float*>(smem))
-                                   : (g_ptr ? *g_ptr : 1.f);
-  const float a_scale = A_SCALED ? g_scale : x_scale;
-  const float b_scale = A_SCALED ? x_scale : g_scale;
+  const float a_scale = A_SCALED ? (hp.aScale ? *hp.aScale : 1.f) : x_scale;
+  const float b_scale = A_SCALED ? x_scale : (hp.bScale ? *hp.bScale : 1.f);
   // XCD-aware rasterisation (speed only): ids b and b+8 share an L2, so each XCD walks a contiguous range of
   // (pixel split, channel block) pairs with the channel block fastest -- the CTAs that stream the same pixel range
   // for different (m,n) blocks run side by side on one L2.
@@ -347,7 +341,6 @@ static long wgrad_h_ws(int N, int Hb, int Wb, int Cm, int Cn) {
 
 template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW, bool A_SCALED>
 static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, const float* aScale, const float* bScale,
-                          const float* gAbsmax, int gAbsmaxN,
                           const float* xSc, const float* xSh, const float* xAbound, int N, int Ha, int Wa, int Hb, int Wb, int Cm, int Cn,
                           hipStream_t st, const char* name) {
   using Cfg = WgradHCfg<KH, KW, S, PAD, TW, RW, WM, WNW, NBW>;
@@ -362,7 +355,7 @@ static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, 
   p.tilesX = pl.tilesX; p.tilesY = pl.tilesY; p.tilesTotal = pl.tilesTotal; p.tilesPerSplit = pl.tilesPerSplit;
   static const int walk = getenv("DC_TILE_WALK") ? atoi(getenv("DC_TILE_WALK")) : 1;
   p.walk = walk;
-  hp.aScale = aScale; hp.bScale = bScale; hp.gAbsmax = gAbsmax; hp.gAbsmaxN = gAbsmaxN;
+  hp.aScale = aScale; hp.bScale = bScale;
   // the activation operand is the UNscaled one: A for conv3x3 (A_SCALED = false), B for convT2x2
   hp.aSc = A_SCALED ? nullptr : xSc; hp.aSh = A_SCALED ? nullptr : xSh;
   hp.bSc = A_SCALED ? xSc : nullptr; hp.bSh = A_SCALED ? xSh : nullptr;
@@ -412,16 +405,14 @@ static int check_h(const char* fn, const void* a, const void* b, const void* c, 
 }
 
 static int conv_h_impl(const float* x, const float* xSc, const float* xSh, const float* xAb, const float* dz, float* dw,
-                       float* ws, const float* dzScale, int N, int H, int W, int Cin, int Cout, hipStream_t st,
-                       const float* dzAbsmax = nullptr, int dzAbsmaxN = 0) {
+                       float* ws, const float* dzScale, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
   const float* none = nullptr;
-  CONV_H_DISPATCH(wgrad_h_launch, , false>(x, dz, dw, ws, none, dzScale, dzAbsmax, dzAbsmaxN, xSc, xSh, xAb, N, H, W, H, W, Cin, Cout, st, "conv3x3_wgrad_f16x3"))
+  CONV_H_DISPATCH(wgrad_h_launch, , false>(x, dz, dw, ws, none, dzScale, xSc, xSh, xAb, N, H, W, H, W, Cin, Cout, st, "conv3x3_wgrad_f16x3"))
 }
 static int convT_h_impl(const float* x, const float* xSc, const float* xSh, const float* xAb, const float* dz, float* dw,
-                        float* ws, const float* dzScale, int N, int H, int W, int Cin, int Cout, hipStream_t st,
-                        const float* dzAbsmax = nullptr, int dzAbsmaxN = 0) {
+                        float* ws, const float* dzScale, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
   const float* none = nullptr;
-  CONVT_H_DISPATCH(wgrad_h_launch, , true>(dz, x, dw, ws, dzScale, none, dzAbsmax, dzAbsmaxN, xSc, xSh, xAb, N, 2 * H, 2 * W, H, W, Cout, Cin, st, "convT2x2_wgrad_f16x3"))
+  CONVT_H_DISPATCH(wgrad_h_launch, , true>(dz, x, dw, ws, dzScale, none, xSc, xSh, xAb, N, 2 * H, 2 * W, H, W, Cout, Cin, st, "convT2x2_wgrad_f16x3"))
 }
 
 // same workspace (dc_*_wgrad_ws_floats) as the fp32 entry points; dz_scale = device scalar from
@@ -464,27 +455,4 @@ extern "C" int dc_convT2x2_wgrad_bnin_f16x3(const float* z_in, const float* in_s
   DC_REQUIRE(in_sc && in_sh && dc_aligned16(in_sc) && dc_aligned16(in_sh), DC_EINVAL,
              "dc_convT2x2_wgrad_bnin_f16x3: scale/shift must be non-null and 16-byte aligned");
   return convT_h_impl(z_in, in_sc, in_sh, in_abound, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
-}
-
-// Weight gradients that derive the power-of-two scale of dz themselves from dc_bn_bwd_apply's per-block maxima
-// (dz_absmax[dz_absmax_n], target 1024: the same power of two dc_bn_bwd_apply_finalize would have written).  One entry point
-// per layer kind covers both operand forms: in_sc / in_sh nullable (null: x_or_z is the materialised activation).
-extern "C" int dc_conv3x3_wgrad_amax_f16x3(const float* x_or_z, const float* in_sc, const float* in_sh, const float* in_abound,
-                                           const float* dz, float* dw, float* ws, const float* dz_absmax, int dz_absmax_n,
-                                           int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
-  int rc = check_h("dc_conv3x3_wgrad_amax_f16x3", x_or_z, dz, dw, ws, N, H, W, Cin, Cout);
-  if (rc) return rc;
-  DC_REQUIRE((in_sc == nullptr) == (in_sh == nullptr), DC_EINVAL, "dc_conv3x3_wgrad_amax_f16x3: in_scale and in_shift go together");
-  DC_REQUIRE(dz_absmax && dz_absmax_n > 0 && dz_absmax_n <= 65536, DC_EINVAL, "dc_conv3x3_wgrad_amax_f16x3: bad dz_absmax");
-  DC_REQUIRE(Cin > 1, DC_EUNSUP, "dc_conv3x3_wgrad_amax_f16x3: the 1-channel first layer takes dc_conv3x3_wgrad_f16x3");
-  return conv_h_impl(x_or_z, in_sc, in_sh, in_abound, dz, dw, ws, nullptr, N, H, W, Cin, Cout, (hipStream_t)stream, dz_absmax, dz_absmax_n);
-}
-extern "C" int dc_convT2x2_wgrad_amax_f16x3(const float* x_or_z, const float* in_sc, const float* in_sh, const float* in_abound,
-                                            const float* dz, float* dw, float* ws, const float* dz_absmax, int dz_absmax_n,
-                                            int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
-  int rc = check_h("dc_convT2x2_wgrad_amax_f16x3", x_or_z, dz, dw, ws, N, H, W, Cin, Cout);
-  if (rc) return rc;
-  DC_REQUIRE((in_sc == nullptr) == (in_sh == nullptr), DC_EINVAL, "dc_convT2x2_wgrad_amax_f16x3: in_scale and in_shift go together");
-  DC_REQUIRE(dz_absmax && dz_absmax_n > 0 && dz_absmax_n <= 65536, DC_EINVAL, "dc_convT2x2_wgrad_amax_f16x3: bad dz_absmax");
-  return convT_h_impl(x_or_z, in_sc, in_sh, in_abound, dz, dw, ws, nullptr, N, H, W, Cin, Cout, (hipStream_t)stream, dz_absmax, dz_absmax_n);
 }

@@ -219,8 +219,7 @@ class UNetEngine(object):
         self.dgrad_bnred = os.environ.get('DC_DGRAD_BNRED', '1') == '1'
         # the finalize launch behind the BatchNorm-backward apply pass (conv-bias gradient + power-of-two scale of dz) runs on
         # the weight-gradient stream; the data gradient derives the scale itself from the per-block maxima
-        # DC_FINALIZE_SIDE = auto (default) | 2 | 1 | 0 (1: in front of the weight gradient, which reads the scalar; 2: behind
-        # it, the weight gradient derives the scale itself as well).  Measured (same box): at the reference's own training windows (128^2 x 20,
+        # DC_FINALIZE_SIDE = auto (default) | 1 | 0.  Measured (same box): at the reference's own training windows (128^2 x 20,
         # launch-latency bound) it takes one launch per block off the critical path, +1.3 %; at 512^2 x 16 the backward's critical
         # chain is data gradient -> weight gradient -> next data gradient (both own their CUs; the BatchNorm passes hide under
         # the weight gradient), so a launch in front of the weight gradient lengthens it: -0.7 %.  auto: small steps only.
@@ -1147,12 +1146,7 @@ class UNetEngine(object):
             def finalize(stream):
                 L.dc_bn_bwd_apply_finalize(dpart, amaxp if f16 else None, blocks, l.cout, 1024.0,
                                            self.pview(self.gflat, l, 'b'), scale if f16 else None, stream)
-            fs = self.finalize_side
-            if fs == 'auto':
-                fs = '2' if N * self.H * self.W <= (1 << 20) else '0'
-            side_fin = f16 and fs in ('1', '2')
-            # '2': the weight gradient derives the scale from the per-block maxima too and the finalize launch runs BEHIND it
-            w_amax = side_fin and fs == '2' and not (l.kind == 'conv' and l.cin == 1)
+            side_fin = f16 and (self.finalize_side == '1' or (self.finalize_side == 'auto' and N * self.H * self.W <= (1 << 20)))
             if not side_fin:
                 finalize(st)
             d_scale, d_amax, d_amax_n = (None, amaxp, blocks) if side_fin else (scale, None, 0)
@@ -1178,19 +1172,10 @@ class UNetEngine(object):
                     main.wait_event(self._last_side_w)      # the shared slab workspace: one weight gradient at a time
             elif two:
                 side.wait_event(ready)
-            if side_fin and not w_amax:
+            if side_fin:
                 finalize(sw)
             dk, ws = self.pview(self.gflat, l, 'k'), _ptr(T['wgrad_ws'])
-            if w_amax:
-                xin, sc_in, sh_in = (bsrc[0], bsrc[1][0], bsrc[1][1]) if bsrc is not None else (x_in, None, None)
-                if l.kind == 'conv':
-                    L.dc_conv3x3_wgrad_amax_f16x3(xin, sc_in, sh_in, self._ab_in(l), dz, dk, ws, amaxp, blocks, N, h, w,
-                                                  l.cin, l.cout, sw)
-                else:
-                    L.dc_convT2x2_wgrad_amax_f16x3(xin, sc_in, sh_in, self._ab_in(l), dz, dk, ws, amaxp, blocks, N,
-                                                   h // 2, w // 2, l.cin, l.cout, sw)
-                finalize(sw)
-            elif bsrc is not None and l.kind == 'conv':
+            if bsrc is not None and l.kind == 'conv':
                 L.dc_conv3x3_wgrad_bnin_f16x3(bsrc[0], bsrc[1][0], bsrc[1][1], self._ab_in(l), dz, dk, ws, scale, N, h, w,
                                               l.cin, l.cout, sw)
             elif bsrc is not None:

@@ -113,15 +113,6 @@ int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const float* bias, f
 int dc_convT2x2_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* dz_scale,
                             const float* dz_absmax, int dz_absmax_n,
                             int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
-/* weight gradients that derive the power-of-two scale of dz themselves from dc_bn_bwd_apply's per-block maxima (as the data
- * gradients do with dz_absmax): in_scale / in_shift nullable -- null: x_or_z is the materialised layer input, else the
- * producer's pre-BN tensor and BN + ReLU are applied on load (the *_bnin forms).  Cin > 1. */
-int dc_conv3x3_wgrad_amax_f16x3(const float* x_or_z, const float* in_scale, const float* in_shift, const float* in_abound,
-                                const float* dz, float* dw, float* ws, const float* dz_absmax, int dz_absmax_n,
-                                int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
-int dc_convT2x2_wgrad_amax_f16x3(const float* x_or_z, const float* in_scale, const float* in_shift, const float* in_abound,
-                                 const float* dz, float* dw, float* ws, const float* dz_absmax, int dz_absmax_n,
-                                 int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 /* weight gradients: same workspace (dc_*_wgrad_ws_floats) and fixed-order slab reduction as the fp32 entry points;
  * dz_scale = device scalar from dc_pow2_scale_from_absmax (nullable). */
 int dc_conv3x3_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,
