@@ -122,3 +122,21 @@ def test_dataset_build_under_two_ranks(tmp_path):
     for line in a.splitlines()[:2]:
         f = hdf5_min.File(line)
         assert f['series/raw'].shape == (3, 64, 64) and f['masks/raw'].shape == (6, 64, 64)
+
+
+def test_bench_watchdog_exits_17_and_names_the_phase():
+    """bench.py's per-rank hang detector on its own (no GPU): a phase that outlives its deadline ends the process with
+    exit code 17 and one line naming rank and phase; a phase that is ticked in time does not."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; wd = bench.Watchdog(3)\n"
+            "for i in range(4):\n"
+            "    wd.tick('step %%d' %% i); time.sleep(0.2)\n"
+            "wd.phase('stuck collective'); time.sleep(30)\n" % root)
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, DC_BENCH_WATCHDOG_S='1.0'), capture_output=True, text=True, timeout=60)
+    assert r.returncode == 17, (r.returncode, r.stderr)
+    assert "rank 3 made no progress in phase 'stuck collective'" in r.stderr
+    ok = subprocess.run([sys.executable, '-c', code.replace("time.sleep(30)", "wd.done(); time.sleep(2.5)")],
+                        env=dict(os.environ, DC_BENCH_WATCHDOG_S='1.0'), capture_output=True, text=True, timeout=60)
+    assert ok.returncode == 0, ok.stderr
