@@ -329,13 +329,12 @@ class Model(object):
         self._sums_host.copy_(sums, non_blocking=True)
         copied = torch.cuda.Event()
         copied.record()
-        tail = not dp and os.environ.get('DC_TAIL_OVERLAP', '1') == '1'
         if dp:
             self._backward_allreduce()
         else:
-            eng.backward(join=not tail)   # tail: adam_step joins the weight-gradient stream (after most of its own work)
+            eng.backward(join=False)      # adam_step joins the weight-gradient stream (after most of its own work)
         o = self.optimizer
-        eng.adam_step(o.lr, o.beta_1, o.beta_2, o.epsilon, grad_scale=grad_scale, tail_overlap=tail)
+        eng.adam_step(o.lr, o.beta_1, o.beta_2, o.epsilon, grad_scale=grad_scale, tail_overlap=not dp)
         copied.synchronize()
         m = metrics_from_sums(self._sums_host.numpy().copy(), float(world * xd.shape[0] * xd.shape[1] * xd.shape[2]), self.loss)
         return [m[k] for k in self.metrics_names]
