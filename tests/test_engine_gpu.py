@@ -214,8 +214,7 @@ def test_determinism_same_input_twice(mfma):
 def test_adam_and_repack_beside_the_last_weight_gradient_is_bit_identical(H, nfb):
     """adam_step(tail_overlap=True) after backward(join=False): every parameter but the first layer's kernel is updated and
     every kernel-side weight layout re-packed while the side stream still runs the first layer's weight gradient.  Same
-    arithmetic on disjoint ranges: parameters, Adam moments and everything computed from the re-packed weights equal the plain
-    order bit for bit over 3 steps."""
+    arithmetic on disjoint ranges: parameters, Adam moments and packed weights equal the plain order bit for bit over 3 steps."""
     N = 2
     x, y = on.synthetic_batch(N, H, H)
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
@@ -233,10 +232,7 @@ def test_adam_and_repack_beside_the_last_weight_gradient_is_bit_identical(H, nfb
                 eng.backward()
                 eng.adam_step(0.002)
                 eng.repack()
-        # the packed kernel-side layouts are compared through what they produce (their padding / trailer slots are never
-        # written): one more training forward + backward on them, and an inference forward
-        p_train = eng.forward_train(xd, yd, None, update_moving=False).clone()
-        eng.backward()
         torch.cuda.synchronize()
-        outs.append([eng.pflat.clone(), eng.mflat.clone(), eng.vflat.clone(), p_train, eng.gflat.clone(), eng.forward_infer(xd).clone()])
+        outs.append([eng.pflat.clone(), eng.mflat.clone(), eng.vflat.clone()] + [eng.wp_fwd[k].clone() for k in sorted(eng.wp_fwd)]
+                    + [eng.wp_dgrad[k].clone() for k in sorted(eng.wp_dgrad)])
     assert all(torch.equal(a, b) for a, b in zip(*outs))
