@@ -332,9 +332,9 @@ class Model(object):
         if dp:
             self._backward_allreduce()
         else:
-            eng.backward(join=False)      # adam_step joins the weight-gradient stream (after most of its own work)
+            eng.backward()
         o = self.optimizer
-        eng.adam_step(o.lr, o.beta_1, o.beta_2, o.epsilon, grad_scale=grad_scale, tail_overlap=not dp)
+        eng.adam_step(o.lr, o.beta_1, o.beta_2, o.epsilon, grad_scale=grad_scale)
         copied.synchronize()
         m = metrics_from_sums(self._sums_host.numpy().copy(), float(world * xd.shape[0] * xd.shape[1] * xd.shape[2]), self.loss)
         return [m[k] for k in self.metrics_names]

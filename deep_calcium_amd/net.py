@@ -1017,13 +1017,11 @@ class UNetEngine(object):
         return [(o_dec, self.n_train), (o_ba, o_dec), (0, o_ba)]
 
     @_on_device
-    def backward(self, bucket_cb=None, join=True):
+    def backward(self, bucket_cb=None):
         """Backward of the last forward_train: fills gflat (same layout as pflat).  bucket_cb(lo, hi), if given, is called
         with the side (weight-gradient) stream current as soon as gflat[lo:hi] is complete on it -- data-parallel training
         starts that range's all-reduce there, so it overlaps with the rest of the backward (grad_buckets()[:2]; the last
-        range is complete when backward() returns).  join=False leaves the side stream un-joined (adam_step(tail_overlap=True)
-        joins it: the optimizer step and the weight re-pack of every layer but the first then run while the side stream
-        is still busy with the LAST weight gradient -- the first layer's, which nothing but its own 288 parameters needs)."""
+        range is complete when backward() returns)."""
         N, masks, step_seed, x_dev, y_dev = self._last
         L, st = self.L, self._stream()
         A, T = self._acts(N), self._train_bufs(N)
@@ -1074,7 +1072,6 @@ class UNetEngine(object):
             side.wait_stream(main)        # everything queued so far (forward, head) precedes the first wgrad
         self._dz_turn = getattr(self, '_dz_turn', 0)
         self._last_side_w = None
-        self._pre_last_w = None
 
         def launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16, red=None, amax=None, amax_n=0):
             """red = the BatchNorm layer whose `da` this data gradient writes (dense, no dropout): when the role-split
@@ -1177,11 +1174,6 @@ class UNetEngine(object):
                 side.wait_event(ready)
             if side_fin:
                 finalize(sw)
-            if two and not on_main and l.kind == 'conv' and l.cin == 1:
-                # the step's last weight gradient: everything in front of it on the side stream (every other layer's weight
-                # gradient, this layer's conv-bias gradient when its finalize runs there) is what all OTHER parameters wait for
-                self._pre_last_w = torch.cuda.Event()
-                self._pre_last_w.record(side)
             dk, ws = self.pview(self.gflat, l, 'k'), _ptr(T['wgrad_ws'])
             if bsrc is not None and l.kind == 'conv':
                 L.dc_conv3x3_wgrad_bnin_f16x3(bsrc[0], bsrc[1][0], bsrc[1][1], self._ab_in(l), dz, dk, ws, scale, N, h, w,
@@ -1271,9 +1263,8 @@ class UNetEngine(object):
             else:
                 block_bwd(la, _ptr(A['pool%d' % (lvl - 1)]), _ptr(g), c, _ptr(other), fused=fa)
                 g, other = other, g
-        if two and join:
+        if two:
             main.wait_stream(side)        # gflat is complete once both streams have drained
-            self._pre_last_w = None
 
     def _join_side(self):
         side = getattr(self, '_side_stream', None)
@@ -1281,36 +1272,14 @@ class UNetEngine(object):
             torch.cuda.current_stream(self.device).wait_stream(side)
 
     @_on_device
-    def adam_step(self, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-8, grad_scale=1.0, tail_overlap=False):
-        """Keras-2.0.6 Adam over the flat buffers; `iterations` counts completed steps.
-        tail_overlap (after backward(join=False)): the update of every parameter except the first layer's kernel and the
-        re-pack of all kernel-side weight layouts (the first layer has none) are launched as soon as the side stream has
-        passed the point where the first layer's weight gradient starts; only that kernel's 9*nfb parameters wait for the
-        join.  Same launches' arithmetic on disjoint ranges of the flat buffers: bit-identical to the single launch."""
+    def adam_step(self, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-8, grad_scale=1.0):
+        """Keras-2.0.6 Adam over the flat buffers; `iterations` counts completed steps."""
         t = self.iterations + 1
         lr_t = lr * np.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t)
-        st = self._stream()
-
-        def adam(lo, hi):
-            self.L.dc_adam_step_flat(_ptr(self.pflat, lo), _ptr(self.gflat, lo), _ptr(self.mflat, lo), _ptr(self.vflat, lo),
-                                     hi - lo, float(lr_t), beta_1, beta_2, epsilon, float(grad_scale), st)
-        main = torch.cuda.current_stream(self.device)
-        ev = getattr(self, '_pre_last_w', None)
-        l0 = self.layers[0]
-        n0 = int(np.prod(l0.kshape))                      # the first layer's kernel sits at the start of the flat buffers
-        if tail_overlap and ev is not None and l0.off['k'][0] == 0 and n0 % 4 == 0 and l0.name not in self.wp_fwd:
-            main.wait_event(ev)
-            adam(n0, self.n_train)
-            self._packed_dirty = True
-            self.repack()
-            self._join_side()
-            adam(0, n0)
-        else:
-            self._join_side()
-            adam(0, self.n_train)
-            self._packed_dirty = True
-        self._pre_last_w = None
+        self.L.dc_adam_step_flat(_ptr(self.pflat), _ptr(self.gflat), _ptr(self.mflat), _ptr(self.vflat),
+                                 self.n_train, float(lr_t), beta_1, beta_2, epsilon, float(grad_scale), self._stream())
         self.iterations = t
+        self._packed_dirty = True
         self._fold_dirty = True
 
     def read_sums(self):

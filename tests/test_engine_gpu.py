@@ -208,31 +208,3 @@ def test_determinism_same_input_twice(mfma):
         torch.cuda.synchronize()
         outs.append(eng.gflat.cpu().numpy().copy())
     assert np.array_equal(outs[0], outs[1])
-
-
-@pytest.mark.parametrize('H,nfb', [(32, 8), (64, 32)])
-def test_adam_and_repack_beside_the_last_weight_gradient_is_bit_identical(H, nfb):
-    """adam_step(tail_overlap=True) after backward(join=False): every parameter but the first layer's kernel is updated and
-    every kernel-side weight layout re-packed while the side stream still runs the first layer's weight gradient.  Same
-    arithmetic on disjoint ranges: parameters, Adam moments and packed weights equal the plain order bit for bit over 3 steps."""
-    N = 2
-    x, y = on.synthetic_batch(N, H, H)
-    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
-    outs = []
-    for overlap in (False, True):
-        eng, _ = make_engine(H, H, nfb, seed=11)
-        for _ in range(3):
-            eng.forward_train(xd, yd, None)                      # hash dropout: the same bits in both runs
-            if overlap:
-                eng.backward(join=False)
-                assert eng.streams == 1 or eng._pre_last_w is not None
-                eng.adam_step(0.002, tail_overlap=True)
-                assert not eng._packed_dirty                      # the re-pack has been issued inside adam_step
-            else:
-                eng.backward()
-                eng.adam_step(0.002)
-                eng.repack()
-        torch.cuda.synchronize()
-        outs.append([eng.pflat.clone(), eng.mflat.clone(), eng.vflat.clone()] + [eng.wp_fwd[k].clone() for k in sorted(eng.wp_fwd)]
-                    + [eng.wp_dgrad[k].clone() for k in sorted(eng.wp_dgrad)])
-    assert all(torch.equal(a, b) for a, b in zip(*outs))
