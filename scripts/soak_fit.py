@@ -1,0 +1,39 @@
+"""Soak: the example's own training configuration (128x128 windows, batch 20, 100 steps per epoch, validation at 512x512 every
+epoch) for a few epochs on a synthetic Neurofinder directory; reports steps/s per epoch, device / host memory growth and the loss.
+    python scripts/soak_fit.py [epochs=3] [steps=100]"""
+import os, resource, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+import numpy as np
+import torch
+from _nf_dirs import make_neurofinder_dir
+from deep_calcium_amd import UNet2DSummary
+from deep_calcium_amd.nf_datasets import nf_load_hdf5
+from deep_calcium_amd.model import Callback
+
+epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+tmp = tempfile.mkdtemp(prefix='dc_soak_')
+for k, name in enumerate(('neurofinder.01.00', 'neurofinder.02.00')):
+    make_neurofinder_dir(tmp, name, seed=5 + k)
+paths = nf_load_hdf5('neurofinder.01.00,neurofinder.02.00', datasets_dir=tmp)
+
+
+class Probe(Callback):
+    def on_epoch_begin(self, epoch, logs=None):
+        self.t = time.time()
+
+    def on_epoch_end(self, epoch, logs=None):
+        torch.cuda.synchronize()
+        print('epoch %d: %.1f steps/s incl. validation, loss %.4f F1 %.3f val_nf_f1 %.3f | device %.2f GB allocated, %.2f GB reserved, host RSS %.2f GB'
+              % (epoch, steps / (time.time() - self.t), logs['loss'], logs['F1'], logs.get('val_nf_f1_mean', float('nan')),
+                 torch.cuda.memory_allocated() / 2 ** 30, torch.cuda.memory_reserved() / 2 ** 30,
+                 resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20), flush=True)
+
+
+np.random.seed(865)
+model = UNet2DSummary(cpdir=os.path.join(tmp, 'cp'))
+hist, _ = model.fit(paths, shape_trn=(128, 128), shape_val=(512, 512), batch_size_trn=20, nb_steps_trn=steps, nb_epochs=epochs,
+                    keras_callbacks=[Probe()], prop_trn=0.75, prop_val=0.25)
+print('loss per epoch', ['%.4f' % v for v in hist['loss']])
+assert hist['loss'][-1] < hist['loss'][0]
