@@ -220,9 +220,9 @@ class UNetEngine(object):
         # the finalize launch behind the BatchNorm-backward apply pass (conv-bias gradient + power-of-two scale of dz) runs on
         # the weight-gradient stream; the data gradient derives the scale itself from the per-block maxima
         # DC_FINALIZE_SIDE = auto (default) | 1 | 0.  Measured (same box): at the reference's own training windows (128^2 x 20,
-        # launch-latency bound) it takes one launch per block off the critical path, +1.3 %; at 512^2 x 16 the backward's critical
-        # chain is data gradient -> weight gradient -> next data gradient (both own their CUs; the BatchNorm passes hide under
-        # the weight gradient), so a launch in front of the weight gradient lengthens it: -0.7 %.  auto: small steps only.
+        # launch-latency bound) it takes one launch per block off the main queue, +1.3 %; at 512^2 x 16 it costs 0.7 %: the
+        # weight gradient starts ~8 us later behind the finalize launch, and the NEXT data gradient cannot start before that
+        # weight gradient has released the CUs (the two kernels cannot share one).  auto: small steps only.
         self.finalize_side = os.environ.get('DC_FINALIZE_SIDE', 'auto') if self.mfma == 'f16x3' else '0'
         self._head_bwd_done = False
         # fp16 range guard of the activation operands (A/B knob; the weights' pack-time scale is unconditional)
