@@ -519,6 +519,8 @@ def main():
         achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         kname, peak, mfma_per_flop = KernelTimer.KERNELS[eng.mfma]
         traffic, traffic_note = pmc_traffic(kname)
+        if (H, B) != (512, 16):
+            traffic, traffic_note = None, 'the committed PMC passes were taken at batch 16 of 512x512
         out = {
             'metric': ('512x512 summary images/sec (train step)' if H == 512 else '%dx%d training windows/sec (train step)' % (H, W)),
             'value': round(world * B * args.steps / dt, 3),
@@ -527,7 +529,8 @@ def main():
             'vs_baseline': None, 'dtype': DTYPE_LABEL[eng.mfma], 'data': 'synthetic',
             'config': {'workload': 'UNet2DS train step (fwd+BCE+bwd+Keras-Adam), batch=%d %dx%d per GPU, nfb=32 (%s)' % (
                                    B, H, W, 'BASELINE.json configs[2]; configs[3] at 8 GPUs' if (H, B) == (512, 16) else
-                                   "the reference's own training window, unet_2d_summary.py:333-335 / examples/neurons/unet2ds_nf.py:36-40"),
+                                   ('the shape of BASELINE.json configs[2] at another batch' if H == 512 else
+                                    "the reference's own training window, unet_2d_summary.py:333-335 / examples/neurons/unet2ds_nf.py:36-40")),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'bn': eng.bn_mode,
                        'contraction': 'fp32 operands split exactly into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 '
                                       'accumulate' if eng.mfma == 'f16x3' else 'fp32 MFMA',
