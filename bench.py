@@ -520,7 +520,7 @@ def main():
         kname, peak, mfma_per_flop = KernelTimer.KERNELS[eng.mfma]
         traffic, traffic_note = pmc_traffic(kname)
         if (H, B) != (512, 16):
-            traffic, traffic_note = None, 'the committed PMC passes were taken at batch 16 of 512x512
+            traffic, traffic_note = None, 'the committed PMC passes were taken at batch 16 of 512x512'
         out = {
             'metric': ('512x512 summary images/sec (train step)' if H == 512 else '%dx%d training windows/sec (train step)' % (H, W)),
             'value': round(world * B * args.steps / dt, 3),
