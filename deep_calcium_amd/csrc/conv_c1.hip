@@ -125,13 +125,37 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(C1Params p) {
   c1_finish(p, a, tid, q, pl, C4, PPB);
 }
 
-// dW[tap][co] partial per block = sum_p x[p+tap] * dz[p][co]
+// "dz on load" (dcunet.h, dc_bn_bwd_finalize_dzin): dz = fmaf(A, [fmaf(z,sc,sh) > 0] * da, fmaf(D, z - mu, E)), this
+// thread's channel quad of the table dz_coef[7][Cout] in registers
+struct C1Dz {
+  f32x4 sc, sh, mu, A, D, E;
+  __device__ __forceinline__ void load(const float* __restrict__ coef, int Cout, int q) {
+    sc = ld4(coef + 4 * q); sh = ld4(coef + Cout + 4 * q); mu = ld4(coef + 2 * Cout + 4 * q);
+    A = ld4(coef + 3 * Cout + 4 * q); D = ld4(coef + 4 * Cout + 4 * q); E = ld4(coef + 5 * Cout + 4 * q);
+  }
+  __device__ __forceinline__ f32x4 dz(const f32x4& da, const f32x4& z) const {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float y = __builtin_fmaf(z[e], sc[e], sh[e]);
+      const float dy = y > 0.f ? da[e] : 0.f;
+      v[e] = __builtin_fmaf(A[e], dy, __builtin_fmaf(D[e], z[e] - mu[e], E[e]));
+    }
+    return v;
+  }
+};
+
+// dW[tap][co] partial per block = sum_p x[p+tap] * dz[p][co]   (DZIN: `dz` holds da, dz is formed from (da, zt, coef))
+template <bool DZIN>
 __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                             float* __restrict__ partial, int N, int H, int W, int Cout,
-                                                            long pixels) {
+                                                            long pixels, const float* __restrict__ zt,
+                                                            const float* __restrict__ coef) {
   __shared__ f32x4 sm[256];
   const int C4 = Cout >> 2, PPB = 256 / C4;
   const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
+  C1Dz cz;
+  if constexpr (DZIN) cz.load(coef, Cout, q);
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[9];
 #pragma unroll
@@ -142,7 +166,8 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
     const int rem = (int)(pix - img * HW);
     const int y = rem / W, xq = rem - y * W;
     const float* xi = x + img * HW;
-    const f32x4 g = ld4(dz + pix * Cout + 4 * q);
+    f32x4 g = ld4(dz + pix * Cout + 4 * q);
+    if constexpr (DZIN) g = cz.dz(g, ld4(zt + pix * Cout + 4 * q));
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       const int yy = y + dy - 1;
@@ -240,12 +265,16 @@ __global__ __launch_bounds__(256) void conv_c1_fwd4_kernel(C1Params p) {
   c1_finish(p, a, tid, q, pl, C4, PPB);
 }
 
+template <bool DZIN>
 __global__ __launch_bounds__(256) void conv_c1_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                              float* __restrict__ partial, int N, int H, int W, int Cout,
-                                                             long pixels) {
+                                                             long pixels, const float* __restrict__ zt,
+                                                             const float* __restrict__ coef) {
   __shared__ f32x4 sm[256];
   const int C4 = Cout >> 2, PPB = 256 / C4;
   const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
+  C1Dz cz;
+  if constexpr (DZIN) cz.load(coef, Cout, q);
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[9];
 #pragma unroll
@@ -261,6 +290,13 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad4_kernel(const float* __rest
     f32x4 gz[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) gz[i] = ld4(dz + (pix0 + i) * Cout + 4 * q);
+    if constexpr (DZIN) {
+      f32x4 zz[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) zz[i] = ld4(zt + (pix0 + i) * Cout + 4 * q);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gz[i] = cz.dz(gz[i], zz[i]);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -327,9 +363,25 @@ int dc_conv3x3_c1_wgrad(const float* x, const float* dz, float* dw, float* ws, i
   const long pixels = (long)N * H * W;
   const int blocks = c1_blocks(pixels, Cout);
   const bool fast = (W % 4 == 0) && dc_aligned16(x) && pixels < (1L << 31);
-  hipLaunchKernelGGL(fast ? conv_c1_wgrad4_kernel : conv_c1_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, dz, ws, N, H, W,
-                     Cout, pixels);
+  const float* none = nullptr;
+  hipLaunchKernelGGL(fast ? conv_c1_wgrad4_kernel<false> : conv_c1_wgrad_kernel<false>, dim3(blocks), dim3(256), 0, st, x, dz,
+                     ws, N, H, W, Cout, pixels, none, none);
   DC_CHECK_LAUNCH("dc_conv3x3_wgrad(Cin=1)");
+  const long L = 9L * Cout;
+  return dc_reduce_partials(ws, blocks, L, 1.0f, dw, ws + (long)blocks * L, (dc_stream_t)st);
+}
+
+// first layer's weight gradient with dz formed on load from (da, z, dz_coef)  (dc_conv3x3_wgrad_dzin_f16x3, Cin == 1)
+int dc_conv3x3_c1_wgrad_dzin(const float* x, const float* da, const float* z, const float* dz_coef, float* dw, float* ws,
+                             int N, int H, int W, int Cout, hipStream_t st) {
+  int rc = check_c1("dc_conv3x3_wgrad_dzin(Cin=1)", N, H, W, Cout);
+  if (rc) return rc;
+  const long pixels = (long)N * H * W;
+  const int blocks = c1_blocks(pixels, Cout);
+  const bool fast = (W % 4 == 0) && dc_aligned16(x) && pixels < (1L << 31);
+  hipLaunchKernelGGL(fast ? conv_c1_wgrad4_kernel<true> : conv_c1_wgrad_kernel<true>, dim3(blocks), dim3(256), 0, st, x, da,
+                     ws, N, H, W, Cout, pixels, z, dz_coef);
+  DC_CHECK_LAUNCH("dc_conv3x3_wgrad_dzin(Cin=1)");
   const long L = 9L * Cout;
   return dc_reduce_partials(ws, blocks, L, 1.0f, dw, ws + (long)blocks * L, (dc_stream_t)st);
 }

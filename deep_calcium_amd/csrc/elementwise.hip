@@ -201,6 +201,7 @@ struct BnParams {
   float* out; long out_ld;
   float* partial;
   float* absmax;   // bn_bwd_apply: per-block max |dz| (nullable)
+  float* amax_c;   // pass-1 producers: per-(block, channel) max |dy| [blocks][C] (nullable) -- dc_bn_bwd_finalize_dzin
   long pixels; int C;
   double count;   // elements per channel the statistics were taken over (> pixels in 'sync' data parallelism)
 };
@@ -351,6 +352,19 @@ __device__ __forceinline__ void bn_bwd_elem(const BnParams& p, long pix, int q, 
   bn_bwd_math(p, pix, q, z, da, mu, is, sc, sh, drop, inv_keep, dy, xh);
 }
 
+__device__ __forceinline__ f32x4 absmax4(const f32x4& m, const f32x4& v) {
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = fmaxf(m[e], fabsf(v[e]));
+  return r;
+}
+__device__ __forceinline__ f32x4 max4(const f32x4& a, const f32x4& b) {
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = fmaxf(a[e], b[e]);
+  return r;
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnParams p) {
   __shared__ f32x4 sm1[256], sm2[256];
   const int C4 = p.C >> 2, PPB = 256 / C4;
@@ -358,7 +372,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnParams p) {
   const f32x4 mu = ld4(p.mean + 4 * q), is = ld4(p.invstd + 4 * q), ga = ld4(p.gamma + 4 * q), be = ld4(p.beta + 4 * q);
   const bool drop = p.keep < 1.f;
   const float inv_keep = drop ? 1.f / p.keep : 1.f;
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, am = {0.f, 0.f, 0.f, 0.f};
   f32x4 sc, sh;
   bn_affine4(mu, is, ga, be, sc, sh);
   auto finish = [&](long pix, const f32x4& z, const f32x4& da) {
@@ -366,6 +380,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnParams p) {
     bn_bwd_math(p, pix, q, z, da, mu, is, sc, sh, drop, inv_keep, dy, xh);
     s1 += dy;
     s2 += dy * xh;
+    am = absmax4(am, dy);
   };
   const long stride = (long)gridDim.x * PPB;
   long pix = (long)blockIdx.x * PPB + pl;
@@ -384,6 +399,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnParams p) {
     float* dst = p.partial + ((long)blockIdx.x * p.C + 4 * q) * 2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { dst[2 * e] = s1[e]; dst[2 * e + 1] = s2[e]; }
+  }
+  if (p.amax_c) {
+    __syncthreads();
+    sm1[tid] = am;
+    __syncthreads();
+    if (pl == 0) {
+      for (int k = 1; k < PPB; ++k) am = max4(am, sm1[k * C4 + q]);
+      st4(p.amax_c + (long)blockIdx.x * p.C + 4 * q, am);
+    }
   }
 }
 
@@ -504,14 +528,14 @@ extern "C" int dc_bn_bwd_blocks(long pixels, int C) { return ew_bwd_blocks(pixel
 
 extern "C" int dc_bn_bwd_reduce(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
                                 const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
-                                float* partial, long pixels, int C, dc_stream_t stream) {
+                                float* partial, float* amax_partial, long pixels, int C, dc_stream_t stream) {
   DC_REQUIRE(da && z && mean && invstd && gamma && beta && partial, DC_EINVAL, "dc_bn_bwd_reduce: null pointer");
   DC_REQUIRE(pixels > 0 && da_ld >= C && da_ld % 4 == 0 && keep > 0.f, DC_EINVAL, "dc_bn_bwd_reduce: bad sizes");
   int rc = chan_check("dc_bn_bwd_reduce", C);
   if (rc) return rc;
   BnParams p{};
   p.da = da; p.da_ld = da_ld; p.z = z; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
-  p.mask = mask; p.keep = keep; p.seed = seed; p.partial = partial; p.pixels = pixels; p.C = C;
+  p.mask = mask; p.keep = keep; p.seed = seed; p.partial = partial; p.amax_c = amax_partial; p.pixels = pixels; p.C = C;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ew_bwd_blocks(pixels, C)), dim3(256), 0, (hipStream_t)stream, p);
   DC_CHECK_LAUNCH("dc_bn_bwd_reduce");
   return DC_OK;
@@ -576,6 +600,72 @@ extern "C" int dc_bn_bwd_finalize(const float* partial, int P, int C, float* dga
   DC_REQUIRE(partial && dgamma && dbeta && P > 0 && C > 0, DC_EINVAL, "dc_bn_bwd_finalize: bad arguments");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, P, C, dgamma, dbeta);
   DC_CHECK_LAUNCH("dc_bn_bwd_finalize");
+  return DC_OK;
+}
+
+// "dz on load": instead of materialising dz = gamma*invstd*(dy - mean(dy) - xhat*mean(dy*xhat)) with dc_bn_bwd_apply, the
+// data- and weight-gradient kernels of a Dropout-free block form it from (da, z) while they stage their operands:
+//   dy = [fmaf(z, sc, sh) > 0] * da ;  dz = fmaf(A, dy, fmaf(D, z - mu, E))
+// This launch is dc_bn_bwd_finalize (partial != NULL; with partial == NULL dgamma / dbeta are INPUTS: the all-reduced
+// sums of 'sync' BatchNorm) plus the per-channel table those kernels read: dz_coef[DC_DZ_COEF_ROWS][C] =
+//   0 sc, 1 sh (dc_bn_affine: the forward's gate expression), 2 mu, 3 A = gamma*invstd, 4 D = -A*invstd*dgamma/count,
+//   5 E = -A*dbeta/count, 6 bound >= max |dz_c| = |A| (max|dy_c| + |dbeta|/count + sqrt(count) |dgamma|/count)
+// (|xhat| <= sqrt(count) for ANY data).  The consumers' fp16 range guard scales by the power of two that brings the
+// largest bound into [2^14, 2^15) (dc_block_guard_scale): no overflow whatever the data, and an element keeps its full
+// 22-bit split down to 2^-12 of the bound.  amax_partial[P][C]: per-row max |dy_c| from the kernel that wrote da.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_dzin_kernel(const float* __restrict__ partial,
+                                                                  const float* __restrict__ amax_partial, int P, int C,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, double count,
+                                                                  float* dgamma, float* dbeta, float* __restrict__ coef,
+                                                                  float* __restrict__ dbias) {
+  __shared__ double sh1[256], sh2[256];
+  __shared__ float shm[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  float am = 0.f;
+  for (int i = tid; i < P; i += 256) {
+    if (partial) {
+      s1 += (double)partial[((long)i * C + c) * 2];
+      s2 += (double)partial[((long)i * C + c) * 2 + 1];
+    }
+    am = fmaxf(am, amax_partial[(long)i * C + c]);
+  }
+  sh1[tid] = s1; sh2[tid] = s2; shm[tid] = am;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { sh1[tid] += sh1[tid + s]; sh2[tid] += sh2[tid + s]; shm[tid] = fmaxf(shm[tid], shm[tid + s]); }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float db, dg;
+    if (partial) { db = (float)sh1[0]; dg = (float)sh2[0]; dbeta[c] = db; dgamma[c] = dg; }
+    else { db = dbeta[c]; dg = dgamma[c]; }
+    const float mu = mean[c], is = invstd[c], ga = gamma[c];
+    const float invM = (float)(1.0 / count);
+    const float mdy = db * invM, mdyx = dg * invM, gs = ga * is;      // dc_bn_bwd_apply's own constants
+    float sc, sh;
+    dc_bn_affine(mu, is, ga, beta[c], sc, sh);
+    coef[c] = sc;
+    coef[C + c] = sh;
+    coef[2 * C + c] = mu;
+    coef[3 * C + c] = gs;
+    coef[4 * C + c] = -(gs * is) * mdyx;
+    coef[5 * C + c] = -gs * mdy;
+    coef[6 * C + c] = fabsf(gs) * (shm[0] + fabsf(mdy) + fabsf(mdyx) * (float)sqrt(count));
+    if (dbias) dbias[c] = 0.f;      // sum_p dz_c = A (sum dy - dbeta - (dgamma/M) sum xhat) = 0 exactly
+  }
+}
+extern "C" int dc_bn_bwd_finalize_dzin(const float* partial, const float* amax_partial, int P, int C, const float* mean,
+                                       const float* invstd, const float* gamma, const float* beta, double count,
+                                       float* dgamma, float* dbeta, float* dz_coef, float* dbias, dc_stream_t stream) {
+  DC_REQUIRE(amax_partial && mean && invstd && gamma && beta && dgamma && dbeta && dz_coef && P > 0 && C > 0 && count >= 1.0,
+             DC_EINVAL, "dc_bn_bwd_finalize_dzin: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_dzin_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, amax_partial, P, C,
+                     mean, invstd, gamma, beta, count, dgamma, dbeta, dz_coef, dbias);
+  DC_CHECK_LAUNCH("dc_bn_bwd_finalize_dzin");
   return DC_OK;
 }
 
@@ -648,7 +738,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bnred_kernel(const float* __r
   bn_affine4(mu, is, ga, be, sc, sh);
   const bool drop = p.keep < 1.f;
   const float inv_keep = drop ? 1.f / p.keep : 1.f;
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, am = {0.f, 0.f, 0.f, 0.f};
   const long total = (long)N * h2 * w2 * C4;
   for (long i = blockIdx.x * 256L + tid; i < total; i += gridDim.x * 256L) {
     long r = i / C4;
@@ -676,6 +766,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bnred_kernel(const float* __r
       for (int e = 0; e < 4; ++e) d[e] = (yv[e] > 0.f) ? d[e] : 0.f;
       s1 += d;
       s2 += d * xh;
+      am = absmax4(am, d);
     }
   }
   sm1[tid] = s1; sm2[tid] = s2;
@@ -685,6 +776,15 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bnred_kernel(const float* __r
     float* dst = p.partial + ((long)blockIdx.x * C + 4 * q) * 2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { dst[2 * e] = s1[e]; dst[2 * e + 1] = s2[e]; }
+  }
+  if (p.amax_c) {
+    __syncthreads();
+    sm1[tid] = am;
+    __syncthreads();
+    if (pl == 0) {
+      for (int k = 1; k < PPB; ++k) am = max4(am, sm1[k * C4 + q]);
+      st4(p.amax_c + (long)blockIdx.x * C + 4 * q, am);
+    }
   }
 }
 
@@ -723,7 +823,7 @@ extern "C" int dc_maxpool2x2_bwd_blocks(int N, int H, int W, int C) { return poo
 extern "C" int dc_maxpool2x2_bwd_bnred(const float* dy, const uint8_t* idx, const float* skip, long skip_ld, float* dx,
                                        const float* z, const float* mean, const float* invstd, const float* gamma,
                                        const float* beta, const uint8_t* mask, float keep, uint64_t seed,
-                                       float* bn_partial, int N, int H, int W, int C, dc_stream_t stream) {
+                                       float* bn_partial, float* amax_partial, int N, int H, int W, int C, dc_stream_t stream) {
   DC_REQUIRE(dy && idx && dx && z && mean && invstd && gamma && beta && bn_partial && keep > 0.f, DC_EINVAL,
              "dc_maxpool2x2_bwd_bnred: bad arguments");
   DC_REQUIRE(!skip || (skip_ld >= C && skip_ld % 4 == 0), DC_EINVAL, "dc_maxpool2x2_bwd_bnred: bad skip_ld");
@@ -733,7 +833,7 @@ extern "C" int dc_maxpool2x2_bwd_bnred(const float* dy, const uint8_t* idx, cons
   if (rc) return rc;
   BnParams p{};
   p.z = z; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.mask = mask; p.keep = keep;
-  p.seed = seed; p.partial = bn_partial; p.C = C;
+  p.seed = seed; p.partial = bn_partial; p.amax_c = amax_partial; p.C = C;
   hipLaunchKernelGGL(maxpool_bwd_bnred_kernel, dim3(pool_bwd_blocks(N, H, W, C)), dim3(256), 0, (hipStream_t)stream, dy,
                      idx, skip, skip_ld, dx, N, H, W, p);
   DC_CHECK_LAUNCH("dc_maxpool2x2_bwd_bnred");
@@ -935,7 +1035,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                       int C, int loss_kind, const double* __restrict__ sums,
                                                       const float* __restrict__ in_sc, const float* __restrict__ in_sh,
                                                       const float* __restrict__ bn_mean,
-                                                      const float* __restrict__ bn_invstd, float* __restrict__ bn_partial) {
+                                                      const float* __restrict__ bn_invstd, float* __restrict__ bn_partial,
+                                                      float* __restrict__ amax_partial) {
   __shared__ f32x4 sm[256];
   __shared__ float sms[256];
   const int C4 = C >> 2, PPB = 256 / C4;
@@ -958,7 +1059,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   if (loss_kind == 3) { I = (float)sums[5]; D = (float)(sums[7] + sums[6] + 1e-7); }
   const float invD2 = 1.f / (D * D);
   f32x4 sa = {0.f, 0.f, 0.f, 0.f};
-  float ss = 0.f;
+  float ss = 0.f, smax = 0.f;     // smax: max |dL/dlogit| of this thread's pixels (da = kd * s: max |da_c| = |kd_c| * smax)
   for (long pix = (long)blockIdx.x * PPB + pl; pix < pixels; pix += (long)gridDim.x * PPB) {
     const float pr = p[pix], yt = (float)y[pix];
     float s;
@@ -990,6 +1091,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     }
     st4(da + pix * C + 4 * q, kd * s);
     sa += v * s;
+    smax = fmaxf(smax, fabsf(s));
     if (q == 0) ss += s;
   }
   sm[tid] = sa;
@@ -1016,6 +1118,20 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       for (int e = 0; e < 4; ++e) { dst[2 * e] = r1[e]; dst[2 * e + 1] = r2[e]; }
     }
   }
+  if (amax_partial) {          // every pixel's s is seen by all C/4 lanes of its group: a block-wide max of the per-thread maxima
+    __shared__ float smx[4];
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o));
+    if ((tid & 63) == 0) smx[tid >> 6] = smax;
+    __syncthreads();
+    if (pl == 0) {
+      const float m = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+      f32x4 am;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) am[e] = fabsf(kd[e]) * m;
+      st4(amax_partial + (long)blockIdx.x * C + 4 * q, am);
+    }
+  }
 }
 
 // Training step with a per-pixel loss (loss_kind 0 / 1): the head's backward needs nothing but the pixel's own p and y, so
@@ -1030,7 +1146,8 @@ __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restri
                                                           float* __restrict__ da, float* __restrict__ gpartial, long pixels,
                                                           int C, int loss_kind, const float* __restrict__ in_sc,
                                                           const float* __restrict__ in_sh, const float* __restrict__ bn_mean,
-                                                          const float* __restrict__ bn_invstd, float* __restrict__ bn_partial) {
+                                                          const float* __restrict__ bn_invstd, float* __restrict__ bn_partial,
+                                                          float* __restrict__ amax_partial) {
   __shared__ float sm[256][DC_HEAD_SUMS];
   __shared__ f32x4 sm4[256], sm4b[256];
   __shared__ float sms[256];
@@ -1051,7 +1168,7 @@ __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restri
 #pragma unroll
   for (int k = 0; k < DC_HEAD_SUMS; ++k) acc[k] = 0.f;
   f32x4 sa = {0.f, 0.f, 0.f, 0.f}, r1 = sa, r2 = sa;
-  float ss = 0.f;
+  float ss = 0.f, smax = 0.f;
   const long iters = (pixels + (long)gridDim.x * PPB - 1) / ((long)gridDim.x * PPB);
   for (long it0 = 0; it0 < iters; it0 += C4) {
     float kz0 = 0.f, kz1 = 0.f;
@@ -1099,6 +1216,7 @@ __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restri
         const float dp = -(2.f * yt / (pr + 1e-7f) - (1.f - yt) / (1.f - pr + 1e-7f)) * invM;
         sown = dp * pr * (1.f - pr);
       }
+      smax = fmaxf(smax, fabsf(sown));
     }
     // backward of the C4 pixels of this group (their values are re-read: they were loaded a moment ago)
     for (int j = 0; j < C4; ++j) {
@@ -1157,6 +1275,20 @@ __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restri
       for (int e = 0; e < 4; ++e) { dst[2 * e] = r1[e]; dst[2 * e + 1] = r2[e]; }
     }
   }
+  if (amax_partial) {          // every pixel's s is seen by all C/4 lanes of its group: a block-wide max of the per-thread maxima
+    __shared__ float smx[4];
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o));
+    if ((tid & 63) == 0) smx[tid >> 6] = smax;
+    __syncthreads();
+    if (pl == 0) {
+      const float m = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+      f32x4 am;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) am[e] = fabsf(kd[e]) * m;
+      st4(amax_partial + (long)blockIdx.x * C + 4 * q, am);
+    }
+  }
 }
 
 // partial rows are padded to C+4 floats to keep float4 alignment; one block per output element, fixed order
@@ -1212,7 +1344,7 @@ static int head_fwd_impl(const float* a, const float* in_sc, const float* in_sh,
 static int head_bwd_impl(const float* a, const float* in_sc, const float* in_sh, const float* p, const uint8_t* y,
                          const float* kh, float* da, float* partial, int loss_kind, const double* sums, long pixels,
                          int C, dc_stream_t stream, const float* bn_mean = nullptr, const float* bn_invstd = nullptr,
-                         float* bn_partial = nullptr);
+                         float* bn_partial = nullptr, float* amax_partial = nullptr);
 extern "C" int dc_head_bwd(const float* a, const float* p, const uint8_t* y, const float* kh, float* da, float* partial,
                            int loss_kind, const double* sums, long pixels, int C, dc_stream_t stream) {
   return head_bwd_impl(a, nullptr, nullptr, p, y, kh, da, partial, loss_kind, sums, pixels, C, stream);
@@ -1226,27 +1358,28 @@ extern "C" int dc_head_bwd_bnin(const float* z, const float* in_scale, const flo
 extern "C" int dc_head_bwd_bnin_bnred(const float* z, const float* in_scale, const float* in_shift, const float* p,
                                       const uint8_t* y, const float* kh, float* da, float* partial, int loss_kind,
                                       const double* sums, const float* bn_mean, const float* bn_invstd,
-                                      float* bn_partial, long pixels, int C, dc_stream_t stream) {
+                                      float* bn_partial, float* amax_partial, long pixels, int C, dc_stream_t stream) {
   DC_REQUIRE(in_scale && in_shift && bn_mean && bn_invstd && bn_partial, DC_EINVAL, "dc_head_bwd_bnin_bnred: null pointer");
   return head_bwd_impl(z, in_scale, in_shift, p, y, kh, da, partial, loss_kind, sums, pixels, C, stream, bn_mean,
-                       bn_invstd, bn_partial);
+                       bn_invstd, bn_partial, amax_partial);
 }
 static int head_bwd_impl(const float* a, const float* in_sc, const float* in_sh, const float* p, const uint8_t* y,
                          const float* kh, float* da, float* partial, int loss_kind, const double* sums, long pixels,
-                         int C, dc_stream_t stream, const float* bn_mean, const float* bn_invstd, float* bn_partial) {
+                         int C, dc_stream_t stream, const float* bn_mean, const float* bn_invstd, float* bn_partial,
+                         float* amax_partial) {
   DC_REQUIRE(a && p && y && kh && da && partial && pixels > 0, DC_EINVAL, "dc_head_bwd: bad arguments");
   DC_REQUIRE(loss_kind >= 0 && loss_kind <= 3 && (loss_kind < 2 || sums), DC_EINVAL, "dc_head_bwd: bad loss_kind / sums");
   int rc = chan_check("dc_head_bwd", C);
   if (rc) return rc;
   hipLaunchKernelGGL(head_bwd_kernel, dim3(head_blocks(pixels)), dim3(256), 0, (hipStream_t)stream, a, p, y, kh, da,
-                     partial, pixels, C, loss_kind, sums, in_sc, in_sh, bn_mean, bn_invstd, bn_partial);
+                     partial, pixels, C, loss_kind, sums, in_sc, in_sh, bn_mean, bn_invstd, bn_partial, amax_partial);
   DC_CHECK_LAUNCH("dc_head_bwd");
   return DC_OK;
 }
 extern "C" int dc_head_fwd_bwd(const float* a, const float* in_scale, const float* in_shift, const float* kh,
                                const float* bh, const uint8_t* y, float* p, float* partial, float* da, float* grad_partial,
-                               int loss_kind, const float* bn_mean, const float* bn_invstd, float* bn_partial, long pixels,
-                               int C, dc_stream_t stream) {
+                               int loss_kind, const float* bn_mean, const float* bn_invstd, float* bn_partial,
+                               float* amax_partial, long pixels, int C, dc_stream_t stream) {
   DC_REQUIRE(a && kh && bh && y && p && partial && da && grad_partial && pixels > 0, DC_EINVAL, "dc_head_fwd_bwd: bad arguments");
   DC_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), DC_EINVAL, "dc_head_fwd_bwd: in_scale and in_shift go together");
   DC_REQUIRE(loss_kind == 0 || loss_kind == 1, DC_EUNSUP,
@@ -1256,7 +1389,8 @@ extern "C" int dc_head_fwd_bwd(const float* a, const float* in_scale, const floa
   if (rc) return rc;
   DC_REQUIRE(C <= 64, DC_EUNSUP, "dc_head_fwd_bwd: C=%d > 64 (the C/4 lanes of a pixel group must divide a wave)", C);
   hipLaunchKernelGGL(head_fwd_bwd_kernel, dim3(head_blocks(pixels)), dim3(256), 0, (hipStream_t)stream, a, kh, bh, y, p,
-                     partial, da, grad_partial, pixels, C, loss_kind, in_scale, in_shift, bn_mean, bn_invstd, bn_partial);
+                     partial, da, grad_partial, pixels, C, loss_kind, in_scale, in_shift, bn_mean, bn_invstd, bn_partial,
+                     amax_partial);
   DC_CHECK_LAUNCH("dc_head_fwd_bwd");
   return DC_OK;
 }

@@ -60,5 +60,11 @@ struct IgemmParams {
   const float* bnGamma;
   const float* bnBeta;
   float* bnPartial;
+  float* bnAmax;        // nullable: [tile][Ncols] max |dy| per tile and column (dc_bn_bwd_finalize_dzin's amax_partial)
+  // role-split kernel only, data-gradient launches, "dz on load": `in` holds da and `in2` the block's pre-BN tensor z (same
+  // dense layout); the producer waves form dz = fmaf(A, [fmaf(z,sc,sh) > 0] * da, fmaf(D, z - mu, E)) from the table
+  // dzCoef[DC_DZ_COEF_ROWS][Cin] (dc_bn_bwd_finalize_dzin; row 6 = the bound the fp16 range guard scales by)
+  const float* in2;
+  const float* dzCoef;
 };
 

@@ -758,8 +758,8 @@ extern "C" int dc_conv3x3_dgrad_bnred_blocks(int N, int H, int W, int Cin, int C
 }
 extern "C" int dc_conv3x3_dgrad_bnred_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
                                             const float* in_absmax, int in_absmax_n, const float* z, const float* mean, const float* invstd, const float* gamma,
-                                            const float* beta, float* bn_partial, int N, int H, int W, int Cin, int Cout,
-                                            dc_stream_t stream) {
+                                            const float* beta, float* bn_partial, float* amax_partial, int N, int H, int W,
+                                            int Cin, int Cout, dc_stream_t stream) {
   int rc = check_h("dc_conv3x3_dgrad_bnred_f16x3", dz, wp16, dx, N, H, W, Cout, Cin);
   if (rc) return rc;
   DC_REQUIRE(z && mean && invstd && gamma && beta && bn_partial, DC_EINVAL, "dc_conv3x3_dgrad_bnred_f16x3: null pointer");
@@ -767,9 +767,42 @@ extern "C" int dc_conv3x3_dgrad_bnred_f16x3(const float* dz, const void* wp16, f
   IgemmParams p = dgrad_bnred_params(dz, wp16, dx, in_scale, N, H, W, Cin, Cout);
   p.inAbsmax = in_absmax; p.inAbsmaxN = in_absmax_n;
   p.bnZ = z; p.bnMean = mean; p.bnInvstd = invstd; p.bnGamma = gamma; p.bnBeta = beta; p.bnPartial = bn_partial;
+  p.bnAmax = amax_partial;
   DC_REQUIRE(dc_conv3x3_dgrad_bnred_blocks(N, H, W, Cin, Cout) > 0, DC_EUNSUP,
              "dc_conv3x3_dgrad_bnred_f16x3: shape not served (dc_conv3x3_dgrad_bnred_blocks() == 0): use the two-pass path");
   return dc_igemm_pp_launch(p, (hipStream_t)stream, "conv3x3_dgrad_bnred_f16x3_pp");
+}
+
+// "dz on load" data gradient (dcunet.h): role-split kernel only.
+extern "C" int dc_conv3x3_dgrad_dzin_blocks(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  float dummy = 1.f;
+  IgemmParams p = dgrad_bnred_params(nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Cout);
+  p.dzCoef = &dummy;
+  if (!dc_igemm_pp_serves(p)) return 0;
+  return N * dc_cdiv(W, 32) * dc_cdiv(H, Cin <= 32 ? 16 : 8);
+}
+extern "C" int dc_conv3x3_dgrad_dzin_f16x3(const float* da, const float* z, const float* dz_coef, const void* wp16, float* dx,
+                                           const float* red_z, const float* red_mean, const float* red_invstd,
+                                           const float* red_gamma, const float* red_beta, float* bn_partial,
+                                           float* amax_partial, int N, int H, int W, int Cin, int Cout,
+                                           dc_stream_t stream) {
+  int rc = check_h("dc_conv3x3_dgrad_dzin_f16x3", da, wp16, dx, N, H, W, Cout, Cin);
+  if (rc) return rc;
+  DC_REQUIRE(z && dz_coef && dc_aligned16(z) && dc_aligned16(dz_coef), DC_EINVAL,
+             "dc_conv3x3_dgrad_dzin_f16x3: z / dz_coef must be non-null and 16-byte aligned");
+  DC_REQUIRE(Cout % 4 == 0, DC_EUNSUP, "dc_conv3x3_dgrad_dzin_f16x3: Cout=%d must be a multiple of 4", Cout);
+  DC_REQUIRE(red_z == nullptr || (red_mean && red_invstd && red_gamma && red_beta && bn_partial), DC_EINVAL,
+             "dc_conv3x3_dgrad_dzin_f16x3: red_z needs red_mean / red_invstd / red_gamma / red_beta / bn_partial");
+  DC_REQUIRE(dc_conv3x3_dgrad_dzin_blocks(N, H, W, Cin, Cout) > 0, DC_EUNSUP,
+             "dc_conv3x3_dgrad_dzin_f16x3: shape not served (dc_conv3x3_dgrad_dzin_blocks() == 0): use dc_bn_bwd_apply + dc_conv3x3_dgrad_f16x3");
+  IgemmParams p = dgrad_bnred_params(da, wp16, dx, nullptr, N, H, W, Cin, Cout);
+  p.in2 = z; p.dzCoef = dz_coef;
+  if (red_z) {
+    p.bnZ = red_z; p.bnMean = red_mean; p.bnInvstd = red_invstd; p.bnGamma = red_gamma; p.bnBeta = red_beta;
+    p.bnPartial = bn_partial; p.bnAmax = amax_partial;
+  }
+  return dc_igemm_pp_launch(p, (hipStream_t)stream, "conv3x3_dgrad_dzin_f16x3_pp");
 }
 
 extern "C" int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld,

@@ -50,6 +50,8 @@ constexpr int G4 = CK / 4, G8 = CK / 8;
 constexpr int TMP_BYTES = 64;
 constexpr int TABLE_BYTES = 8 * 1024;          // BN-on-load table: 2 x Cin floats, Cin <= 1024
 constexpr int EP_COLS = 512;                   // epilogue parameter table: 3 x Ncols floats, Ncols <= 512
+constexpr int DZ_CIN = 512;                    // dz-on-load table: 6 x Cin floats, Cin <= 512
+constexpr int DZ_BYTES = 6 * DZ_CIN * 4;
 constexpr int THREADS = 768;
 constexpr unsigned OOB = 0x80000000u;
 // The two tile shapes of the 256-thread kernel (same BatchNorm-partial tile counts): <MB 2, NB 2> = 8 x 32 pixels x 64
@@ -98,7 +100,8 @@ struct Item {          // one output tile x column block (wave-uniform)
 // VARIANT 1 (BNRED): the data-gradient variant that also emits the BatchNorm-backward sums of the layer it writes `da` of.
 // VARIANT 2 (POOL): the inference variant whose output also feeds a 2x2 max-pool: the epilogue writes the pooled tensor
 // too.  Each is its own instantiation: the other epilogues are compiled out of it, and its code out of the base kernel.
-template <int MB_, int NB_, int VARIANT = 0>
+// DZIN: the data-gradient launch whose input operand dz is formed on load from (da, z) -- see IgemmParams::in2.
+template <int MB_, int NB_, int VARIANT = 0, bool DZIN = false>
 __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p) {
   constexpr bool BNRED = VARIANT == 1, POOL = VARIANT == 2;
   using namespace pp;
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
   float* tmp = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES + RED_BYTES);
   float* lds_sc = reinterpret_cast<float*>(smem + FIXED_LDS);                 // BN-on-load (scale, shift) per input channel
   float* lds_ep = reinterpret_cast<float*>(smem + FIXED_LDS + TABLE_BYTES);   // epilogue bias | scale | shift per column
+  float* lds_dz = lds_ep + 3 * EP_COLS;                                       // DZIN: sc | sh | mu | A | D | E per input channel
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..11
@@ -164,8 +168,14 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
       lds_sc[EP_COLS + i] = p.bnInvstd[i];
     }
   }
-  const float in_scale = (p.inAbsmax ? dc_block_absmax_scale(p.inAbsmax, p.inAbsmaxN, 1024.f, tmp) : (p.inScale ? *p.inScale : 1.f)) * dc_block_guard_scale(p.inAbound, p.Cin, tmp, p.inAboundLd);
-  if (p.inAbound == nullptr) __syncthreads();                 // (the guard's own barriers publish the tables otherwise)
+  float in_scale;
+  if constexpr (DZIN) {
+    for (int i = tid; i < 6 * p.Cin; i += THREADS) lds_dz[i] = p.dzCoef[i];
+    in_scale = dc_block_guard_scale(p.dzCoef + 6 * p.Cin, p.Cin, tmp);       // (its barriers publish the tables)
+  } else {
+    in_scale = (p.inAbsmax ? dc_block_absmax_scale(p.inAbsmax, p.inAbsmaxN, 1024.f, tmp) : (p.inScale ? *p.inScale : 1.f)) * dc_block_guard_scale(p.inAbound, p.Cin, tmp, p.inAboundLd);
+    if (p.inAbound == nullptr) __syncthreads();               // (the guard's own barriers publish the tables otherwise)
+  }
 
   if (role == 2) {
     // =========================== producers: HBM -> registers -> fp16 hi/lo operand images ==========================
@@ -174,49 +184,70 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
     constexpr int A_STEP = 256 / G4, B_STEP = 256 / BN;
     const int a_g = t % G4, a_pix0 = t / G4;
     const int b_j = t % BN, b_row0 = t / BN;
-    int a_rel[NA], b_rel[NBV];                 // tile-independent parts of the byte offsets
-#pragma unroll
-    for (int it = 0; it < NA; ++it) {
-      const int pix = a_pix0 + it * A_STEP;
+    // tile-independent parts of the byte offsets: kept in registers, except in the DZIN instantiations (their second
+    // input tensor needs the registers: recomputed per item there, ~6 VALU per offset)
+    auto a_rel_of = [&](int it, int pix0) __attribute__((always_inline)) {
+      const int pix = pix0 + it * A_STEP;
       const int r = pix / TWI, c = pix - r * TWI;
-      a_rel[it] = ((r * p.Win + c) * p.Cin + 4 * a_g) * 4;
-    }
-#pragma unroll
-    for (int it = 0; it < NBV; ++it) {
-      const int row = b_row0 + it * B_STEP;    // (tap, g8, hl)
+      return ((r * p.Win + c) * p.Cin + 4 * a_g) * 4;
+    };
+    auto b_rel_of = [&](int it, int row0) __attribute__((always_inline)) {
+      const int row = row0 + it * B_STEP;    // (tap, g8, hl)
       const int tap = row / (2 * G8), g8 = (row >> 1) % G8, hl = row & 1;
-      b_rel[it] = row < BROWS ? (((tap * Cin8 + g8) * 2 + hl) * p.Ncols + b_j) * 16 : -1;
+      return row < BROWS ? (((tap * Cin8 + g8) * 2 + hl) * p.Ncols + b_j) * 16 : -1;
+    };
+    int a_rel[DZIN ? 1 : NA], b_rel[DZIN ? 1 : NBV];
+    if constexpr (!DZIN) {
+#pragma unroll
+      for (int it = 0; it < NA; ++it) a_rel[it] = a_rel_of(it, a_pix0);
+#pragma unroll
+      for (int it = 0; it < NBV; ++it) b_rel[it] = b_rel_of(it, b_row0);
     }
     unsigned a_voff[NA], b_voff[NBV];
-    __amdgpu_buffer_rsrc_t rsrcA = rsrcB;
+    __amdgpu_buffer_rsrc_t rsrcA = rsrcB, rsrcZ = rsrcB;
     auto setup_item = [&](int j) __attribute__((always_inline)) {
       const Item it = decode(j);
       rsrcA = dc_make_rsrc(p.in + (long)it.img * p.Hin * p.Win * p.Cin, (unsigned)(p.Hin * p.Win * p.Cin) * 4u);
+      if constexpr (DZIN) rsrcZ = dc_make_rsrc(p.in2 + (long)it.img * p.Hin * p.Win * p.Cin, (unsigned)(p.Hin * p.Win * p.Cin) * 4u);
       const int iy0 = it.oy0 - 1, ix0 = it.ox0 - 1;
       const int base = (iy0 * p.Win + ix0) * p.Cin * 4;
       const bool inside = iy0 >= 0 && ix0 >= 0 && iy0 + THI <= p.Hin && ix0 + TWI <= p.Win;     // wave-uniform
+      int pix0 = a_pix0, row0 = b_row0;
+      if constexpr (DZIN) {      // re-derived from the thread id, opaque per item: or the offsets are hoisted out of the loop and spilled
+        int t2 = t;
+        asm volatile("" : "+v"(t2));
+        pix0 = t2 / G4; row0 = t2 / BN;
+      }
 #pragma unroll
       for (int k = 0; k < NA; ++k) {
-        const int pix = a_pix0 + k * A_STEP;
+        const int pix = pix0 + k * A_STEP;
         bool ok = pix < NPIXH;
         if (!inside) {
           const int r = pix / TWI, c = pix - r * TWI;
           const int y = iy0 + r, x = ix0 + c;
           ok = ok && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
         }
-        a_voff[k] = ok ? (unsigned)(base + a_rel[k]) : OOB;
+        a_voff[k] = ok ? (unsigned)(base + (DZIN ? a_rel_of(k, pix0) : a_rel[DZIN ? 0 : k])) : OOB;
       }
       const bool col_ok = (it.n0 + b_j) < p.Ncols;
 #pragma unroll
-      for (int k = 0; k < NBV; ++k) b_voff[k] = (b_rel[k] >= 0 && col_ok) ? (unsigned)(b_rel[k] + it.n0 * 16) : OOB;
+      for (int k = 0; k < NBV; ++k) {
+        const int br = DZIN ? b_rel_of(k, row0) : b_rel[DZIN ? 0 : k];
+        b_voff[k] = (br >= 0 && col_ok) ? (unsigned)(br + it.n0 * 16) : OOB;
+      }
     };
-    f32x4 ra[NA];
+    f32x4 ra[NA], rz[DZIN ? NA : 1];
     u32x4 rb[NBV];
     auto load_chunk = [&](int c0) __attribute__((always_inline)) {
       const unsigned a_add = (unsigned)c0 * 4u, b_add = (unsigned)(c0 >> 3) * 2u * (unsigned)p.Ncols * 16u;
 #pragma unroll
       for (int k = 0; k < NA; ++k)
         ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, a_voff[k], (int)a_add, 0));
+      if constexpr (DZIN) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+          rz[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcZ, a_voff[k], (int)a_add, 0));
+      }
 #pragma unroll
       for (int k = 0; k < NBV; ++k) rb[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, b_voff[k], (int)b_add, 0);
     };
@@ -227,11 +258,32 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
         csc = *reinterpret_cast<const f32x4*>(lds_sc + c0 + 4 * a_g);
         csh = *reinterpret_cast<const f32x4*>(lds_sc + Cinp + c0 + 4 * a_g);
       }
+      f32x4 cmu = csh, cA = csc, cD = csh, cE = csh;
+      if constexpr (DZIN) {
+        const float* t = lds_dz + c0 + 4 * a_g;
+        csc = *reinterpret_cast<const f32x4*>(t);
+        csh = *reinterpret_cast<const f32x4*>(t + p.Cin);
+        cmu = *reinterpret_cast<const f32x4*>(t + 2 * p.Cin);
+        cA = *reinterpret_cast<const f32x4*>(t + 3 * p.Cin);
+        cD = *reinterpret_cast<const f32x4*>(t + 4 * p.Cin);
+        cE = *reinterpret_cast<const f32x4*>(t + 5 * p.Cin);
+      }
 #pragma unroll
       for (int k = 0; k < NA; ++k) {
         const int pix = a_pix0 + k * A_STEP;
         if (pix < NPIXH) {
           f32x4 v = ra[k];
+          if constexpr (DZIN) {
+            const bool live = !(a_voff[k] >> 31);              // outside the image dz is 0, not E - D*mu
+            const f32x4 zz = rz[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y = __builtin_fmaf(zz[e], csc[e], csh[e]);       // the forward's own expression: identical ReLU gate
+              const float dy = y > 0.f ? v[e] : 0.f;
+              const float dzv = __builtin_fmaf(cA[e], dy, __builtin_fmaf(cD[e], zz[e] - cmu[e], cE[e]));
+              v[e] = live ? dzv : 0.f;
+            }
+          }
           if (bnin) {
             const bool live = !(a_voff[k] >> 31);              // zero padding stays zero
 #pragma unroll
@@ -475,10 +527,11 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
         const float dy = (ok && y > 0.f) ? v : 0.f;
         e_s1 += dy;
         e_s2 = __builtin_fmaf(dy, (zr[r] - mu) * is, e_s2);
+        e_cnt = fmaxf(e_cnt, fabsf(dy));                        // (the count slot is free in this variant: max |dy|)
       }
       if (mb == MB - 1) {
-        DcMoments m;                                             // container: (unused, sum dy, sum dy*xhat)
-        m.n = 0.f;
+        DcMoments m;                                             // container: (max |dy|, sum dy, sum dy*xhat)
+        m.n = fmaxf(e_cnt, __shfl_xor(e_cnt, 32));
         m.mean = e_s1 + __shfl_xor(e_s1, 32);
         m.m2 = e_s2 + __shfl_xor(e_s2, 32);
         if (h == 0) red[(wave_m * NB + nb) * 32 + li] = m;
@@ -523,13 +576,14 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
       const int ts = tid & 255;
       if (ts < NB * 32) {
         const int nb = ts / 32, l = ts % 32;
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f, s2 = 0.f, am = 0.f;
 #pragma unroll
-        for (int wm = 0; wm < WAVES_M; ++wm) { const DcMoments m = red[(wm * NB + nb) * 32 + l]; s1 += m.mean; s2 += m.m2; }
+        for (int wm = 0; wm < WAVES_M; ++wm) { const DcMoments m = red[(wm * NB + nb) * 32 + l]; s1 += m.mean; s2 += m.m2; am = fmaxf(am, m.n); }
         const int n = mitem.n0 + nb * 32 + l;
         if (n < p.Ncols) {
           float* dst = p.bnPartial + ((long)mitem.tile_id * p.Ncols + n) * 2;
           dst[0] = s1; dst[1] = s2;
+          if (p.bnAmax) p.bnAmax[(long)mitem.tile_id * p.Ncols + n] = am;
         }
       }
     }
@@ -619,7 +673,9 @@ bool dc_igemm_pp_serves(const IgemmParams& p) {
   // weight-gradient kernel of the side stream, and this kernel's 138 KB of LDS cannot share a CU with that one's 87 KB:
   // measured, serving the data gradients too is still the faster setting: 788 vs 780 vs 774 images/s for 1 / 2 / 0)
   static const int knob = getenv("DC_IGEMM_PP") ? atoi(getenv("DC_IGEMM_PP")) : 1;
-  const bool enabled = knob == 1 || (knob == 2 && p.inScale == nullptr);
+  const bool is_dgrad = p.inScale != nullptr || p.inAbsmax != nullptr || p.dzCoef != nullptr;
+  const bool enabled = knob == 1 || (knob == 2 && !is_dgrad);
+  if (p.dzCoef && p.Cin > pp::DZ_CIN) return false;
   const int th = p.Ncols <= 32 ? 16 : 8, bn = p.Ncols <= 32 ? 32 : 64;
   const long total = (long)p.N * dc_cdiv(p.Wout, pp::TW) * dc_cdiv(p.Hout, th) * dc_cdiv(p.Ncols, bn);
   // 2- and 3-step tiles (Cin 32 / 48) take two epilogue blocks per step: with BatchNorm partials that slice is longer than
@@ -629,13 +685,14 @@ bool dc_igemm_pp_serves(const IgemmParams& p) {
          !(p.outAbsmax && p.outAbsmaxLd >= 0) && p.Cin <= 1024 && p.Ncols <= pp::EP_COLS && total >= 8;
 }
 
-template <int MB_, int NB_, int VARIANT>
+template <int MB_, int NB_, int VARIANT, bool DZIN = false>
 static int pp_launch(IgemmParams p, hipStream_t st, const char* name) {
   using C = pp::Cfg<MB_, NB_>;
   static_assert(C::RPM == 1, "the pooled epilogue pairs block rows mb - 1, mb");
-  auto kern = igemm_pp_kernel<MB_, NB_, VARIANT>;
+  auto kern = igemm_pp_kernel<MB_, NB_, VARIANT, DZIN>;
   static DcLdsAttr lds_attr;
-  const int lds = C::FIXED_LDS + pp::TABLE_BYTES + 3 * pp::EP_COLS * 4;
+  const int lds = C::FIXED_LDS + pp::TABLE_BYTES + 3 * pp::EP_COLS * 4 + (DZIN ? pp::DZ_BYTES : 0);
+  static_assert(C::FIXED_LDS + pp::TABLE_BYTES + 3 * pp::EP_COLS * 4 + pp::DZ_BYTES <= 160 * 1024, "LDS budget");
   if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), lds, name)) return rc;
   p.tilesX = dc_cdiv(p.Wout, pp::TW);
   p.tilesY = dc_cdiv(p.Hout, C::TH);
@@ -659,6 +716,11 @@ static int pp_launch(IgemmParams p, hipStream_t st, const char* name) {
 
 // same tile-shape choice as igemm_f16x3.hip's conv3x3 dispatch (and therefore the same BatchNorm-partial tile count)
 int dc_igemm_pp_launch(IgemmParams p, hipStream_t st, const char* name) {
+  if (p.dzCoef) {
+    DC_REQUIRE(p.in2 && p.Cin <= pp::DZ_CIN && !p.inSc && !p.poolOut, DC_EINVAL, "%s: bad dz-on-load launch", name);
+    if (p.bnPartial) return p.Ncols <= 32 ? pp_launch<4, 1, 1, true>(p, st, name) : pp_launch<2, 2, 1, true>(p, st, name);
+    return p.Ncols <= 32 ? pp_launch<4, 1, 0, true>(p, st, name) : pp_launch<2, 2, 0, true>(p, st, name);
+  }
   if (p.bnPartial) return p.Ncols <= 32 ? pp_launch<4, 1, 1>(p, st, name) : pp_launch<2, 2, 1>(p, st, name);
   if (p.poolOut) return p.Ncols <= 32 ? pp_launch<4, 1, 2>(p, st, name) : pp_launch<2, 2, 2>(p, st, name);
   return p.Ncols <= 32 ? pp_launch<4, 1, 0>(p, st, name) : pp_launch<2, 2, 0>(p, st, name);

@@ -43,6 +43,11 @@ struct WgradHParams {
   // fp16 range guard of the ACTIVATION operand (common.h dc_block_guard_scale): its per-channel magnitude bound
   // (xChannels floats, nullable).  The gradient operand brings its scale in aScale / bScale.
   const float* xAbound; int xChannels;
+  // "dz on load" (conv3x3 only, DZIN instantiations): B holds da, bZ the block's pre-BN tensor z (same layout) and the
+  // producer waves form dz = fmaf(A, [fmaf(z,sc,sh) > 0] * da, fmaf(D, z - mu, E)) from dzCoef[DC_DZ_COEF_ROWS][Cn]
+  // (dc_bn_bwd_finalize_dzin); row 6 is the magnitude bound the operand's power-of-two scale comes from
+  const float* bZ;
+  const float* dzCoef;
 };
 
 // WM x WNW waves tile the CTA's (m, n) block, each wave covering 32 m x (32*NBW) n; the remaining
@@ -90,8 +95,9 @@ __device__ __forceinline__ void split4_f16(const f32x4 v, float s, u32x2& hi, u3
   lo = u32x2{l01, l23};
 }
 
-template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW, bool A_SCALED>
+template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW, bool A_SCALED, bool DZIN = false>
 __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
+  static_assert(!(DZIN && A_SCALED), "dz on load: conv3x3 (B = dz) only");
   using Cfg = WgradHCfg<KH, KW, S, PAD, TW, RW, WM, WNW, NBW>;
   constexpr int TAPS = Cfg::TAPS, WK = Cfg::WK, TH = Cfg::TH, CM = Cfg::CM, CN = Cfg::CN;
   constexpr int TWI = Cfg::TWI, APIX = Cfg::APIX, BPIX = Cfg::BPIX;
@@ -113,7 +119,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
   // operand's range guard -- every wave needs them (producers to split, consumers to un-scale)
   const float x_scale = dc_block_guard_scale(hp.xAbound, hp.xChannels, reinterpret_cast<float*>(smem));
   const float a_scale = A_SCALED ? (hp.aScale ? *hp.aScale : 1.f) : x_scale;
-  const float b_scale = A_SCALED ? x_scale : (hp.bScale ? *hp.bScale : 1.f);
+  const float b_scale = DZIN ? dc_block_guard_scale(hp.dzCoef + 6 * p.Cn, p.Cn, reinterpret_cast<float*>(smem))
+                             : (A_SCALED ? x_scale : (hp.bScale ? *hp.bScale : 1.f));
   // XCD-aware rasterisation (speed only): ids b and b+8 share an L2, so each XCD walks a contiguous range of
   // (pixel split, channel block) pairs with the channel block fastest -- the CTAs that stream the same pixel range
   // for different (m,n) blocks run side by side on one L2.
@@ -143,20 +150,35 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
       b_sc = *reinterpret_cast<const f32x4*>(hp.bSc + n0 + 4 * b_c4);
       b_sh = *reinterpret_cast<const f32x4*>(hp.bSh + n0 + 4 * b_c4);
     }
+    f32x4 d_mu = b_sh, d_A = b_sh, d_D = b_sh, d_E = b_sh;     // DZIN: this thread's channel quad of the dz table
+    if (DZIN && b_ch_ok) {
+      const float* t = hp.dzCoef + n0 + 4 * b_c4;
+      b_sc = *reinterpret_cast<const f32x4*>(t);
+      b_sh = *reinterpret_cast<const f32x4*>(t + p.Cn);
+      d_mu = *reinterpret_cast<const f32x4*>(t + 2 * p.Cn);
+      d_A = *reinterpret_cast<const f32x4*>(t + 3 * p.Cn);
+      d_D = *reinterpret_cast<const f32x4*>(t + 4 * p.Cn);
+      d_E = *reinterpret_cast<const f32x4*>(t + 5 * p.Cn);
+    }
 
     // request tile `tile`'s raw rows (zeros outside the image: rows via the descriptor bounds, columns by compare)
-    // ma / mb: per-load 'inside the image' bits, needed only when BN + ReLU is applied on load (0 must stay 0)
-    auto request = [&](int tile, f32x4 (&ra)[NA], f32x4 (&rb)[NB], unsigned& ma, unsigned& mb) {
-      ma = 0u; mb = 0u;
-      int tx, ty, img;
-      if (p.walk) { ty = tile % p.tilesY; const int t = tile / p.tilesY; tx = t % p.tilesX; img = t / p.tilesX; }
-      else { tx = tile % p.tilesX; const int t = tile / p.tilesX; ty = t % p.tilesY; img = t / p.tilesY; }
-      const int py0 = ty * TH, px0 = tx * TW;
-      const int ay0 = py0 * S - PAD, ax0 = px0 * S - PAD;
-      const __amdgpu_buffer_rsrc_t rsA = dc_make_rsrc(p.A + (long)img * p.Ha * p.Wa * p.Cm, (unsigned)(p.Ha * p.Wa * p.Cm) * 4u);
-      const __amdgpu_buffer_rsrc_t rsB = dc_make_rsrc(p.B + (long)img * p.Hb * p.Wb * p.Cn, (unsigned)(p.Hb * p.Wb * p.Cn) * 4u);
+    // ma / mb: per-load 'inside the image' bits, needed only when BN + ReLU / dz is formed on load (0 must stay 0)
+    constexpr int NZ = DZIN ? NB : 1;
+    struct TilePos { int img, py0, px0; };
+    auto tile_pos = [&](int tile) {
+      TilePos t;
+      int tx, ty;
+      if (p.walk) { ty = tile % p.tilesY; const int q = tile / p.tilesY; tx = q % p.tilesX; t.img = q / p.tilesX; }
+      else { tx = tile % p.tilesX; const int q = tile / p.tilesX; ty = q % p.tilesY; t.img = q / p.tilesY; }
+      t.py0 = ty * TH; t.px0 = tx * TW;
+      return t;
+    };
+    auto request_a = [&](int tile, f32x4 (&ra)[NA], unsigned& ma) {
+      ma = 0u;
+      const TilePos t = tile_pos(tile);
+      const int ay0 = t.py0 * S - PAD, ax0 = t.px0 * S - PAD;
+      const __amdgpu_buffer_rsrc_t rsA = dc_make_rsrc(p.A + (long)t.img * p.Ha * p.Wa * p.Cm, (unsigned)(p.Ha * p.Wa * p.Cm) * 4u);
       const int abase = (ay0 * p.Wa + ax0) * p.Cm * 4 + (m0 + 4 * a_c4) * 4;   // may be negative: wraps out of range
-      const int bbase = (py0 * p.Wb + px0) * p.Cn * 4 + (n0 + 4 * b_c4) * 4;
 #pragma unroll
       for (int k = 0; k < NA; ++k) {
         const int pix = st / AC4 + k * (256 / AC4);
@@ -167,14 +189,22 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
         ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
         if (a_bn && ok && (unsigned)(ay0 + r) < (unsigned)p.Ha) ma |= 1u << k;
       }
+    };
+    auto request_b = [&](int tile, f32x4 (&rb)[NB], f32x4 (&rz)[NZ], unsigned& mb) {
+      mb = 0u;
+      const TilePos t = tile_pos(tile);
+      const __amdgpu_buffer_rsrc_t rsB = dc_make_rsrc(p.B + (long)t.img * p.Hb * p.Wb * p.Cn, (unsigned)(p.Hb * p.Wb * p.Cn) * 4u);
+      const __amdgpu_buffer_rsrc_t rsZ = DZIN ? dc_make_rsrc(hp.bZ + (long)t.img * p.Hb * p.Wb * p.Cn, (unsigned)(p.Hb * p.Wb * p.Cn) * 4u) : rsB;
+      const int bbase = (t.py0 * p.Wb + t.px0) * p.Cn * 4 + (n0 + 4 * b_c4) * 4;
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         const int pix = st / BC4 + k * (256 / BC4);
         const int r = pix / TW, cc = pix % TW;
-        const bool ok = b_ch_ok && pix < BPIX && (px0 + cc) < p.Wb;
+        const bool ok = b_ch_ok && pix < BPIX && (t.px0 + cc) < p.Wb;
         const unsigned off = ok ? (unsigned)(bbase + __mul24(r, b_rowb) + __mul24(cc, p.Cn * 4)) : 0x80000000u;
         rb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
-        if (b_bn && ok && (py0 + r) < p.Hb) mb |= 1u << k;
+        if constexpr (DZIN) rz[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, off, 0, 0));
+        if ((b_bn || DZIN) && ok && (t.py0 + r) < p.Hb) mb |= 1u << k;
       }
     };
     // split the requested rows into fp16 hi/lo and write them into image set `set`
@@ -183,7 +213,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
       for (int e = 0; e < 4; ++e) v[e] = live ? fmaxf(__builtin_fmaf(v[e], sc[e], sh[e]), 0.f) : 0.f;
       return v;
     };
-    auto stage = [&](const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], unsigned ma, unsigned mb, char* set) {
+    auto dz_on_load = [&](const f32x4 da, const f32x4 zz, bool live) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = __builtin_fmaf(zz[e], b_sc[e], b_sh[e]);           // the forward's own expression: identical ReLU gate
+        const float dy = y > 0.f ? da[e] : 0.f;
+        const float dzv = __builtin_fmaf(d_A[e], dy, __builtin_fmaf(d_D[e], zz[e] - d_mu[e], d_E[e]));
+        v[e] = live ? dzv : 0.f;
+      }
+      return v;
+    };
+    auto stage_a = [&](const f32x4 (&ra)[NA], unsigned ma, char* set) {
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         const int pix = st / AC4 + j * (256 / AC4);
@@ -194,11 +235,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
           *reinterpret_cast<u32x2*>(set + A_IMG + a_lbase + pix * 64) = lo;
         }
       }
+    };
+    auto stage_b = [&](const f32x4 (&rb)[NB], const f32x4 (&rz)[NZ], unsigned mb, char* set) {
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         const int pix = st / BC4 + k * (256 / BC4);
         u32x2 hi, lo;
-        split4_f16<true>(b_bn ? bn_relu(rb[k], b_sc, b_sh, (mb >> k) & 1u) : rb[k], b_scale, hi, lo);
+        f32x4 bv = rb[k];
+        if constexpr (DZIN) bv = dz_on_load(rb[k], rz[k], (mb >> k) & 1u);
+        else if (b_bn) bv = bn_relu(rb[k], b_sc, b_sh, (mb >> k) & 1u);
+        split4_f16<true>(bv, b_scale, hi, lo);
         if (pix < BPIX) {
           *reinterpret_cast<u32x2*>(set + b_lbase + pix * 64) = hi;
           *reinterpret_cast<u32x2*>(set + B_IMG + b_lbase + pix * 64) = lo;
@@ -208,20 +254,55 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
 
     // Two register sets: while tile i+1 is split into LDS, tile i+2's rows are already in flight (a full tile of
     // MFMA time plus the split covers the HBM latency even when a bandwidth-bound kernel shares the chip).
-    f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+    // B1 (the DZIN instantiations with 32-wide tiles: 2 x (A + da + z) would need > 256 VGPRs): ONE (da, z) set, requested
+    // right after the previous tile's has been split -- one tile of MFMA time ahead instead of two.
+    constexpr bool B1 = DZIN && 8 * (NA + NB + NZ) > 160;
+    f32x4 ra0[NA], rb0[NB], rz0[NZ], ra1[NA], rb1[B1 ? 1 : NB], rz1[B1 ? 1 : NZ];
     unsigned ma0, mb0, ma1 = 0u, mb1 = 0u;
-    request(tile_beg, ra0, rb0, ma0, mb0);
-    if (nt > 1) request(tile_beg + 1, ra1, rb1, ma1, mb1);
-    stage(ra0, rb0, ma0, mb0, smem);
-    __syncthreads();
-    for (int i = 0; i < nt; i += 2) {
-      if (i + 2 < nt) request(tile_beg + i + 2, ra0, rb0, ma0, mb0);
-      if (i + 1 < nt) stage(ra1, rb1, ma1, mb1, smem + SET);
+    if constexpr (B1) {
+      request_a(tile_beg, ra0, ma0);
+      request_b(tile_beg, rb0, rz0, mb0);
+      if (nt > 1) request_a(tile_beg + 1, ra1, ma1);
+      stage_a(ra0, ma0, smem);
+      stage_b(rb0, rz0, mb0, smem);
+      if (nt > 1) request_b(tile_beg + 1, rb0, rz0, mb0);
       __syncthreads();
-      if (i + 1 < nt) {
-        if (i + 3 < nt) request(tile_beg + i + 3, ra1, rb1, ma1, mb1);
-        if (i + 2 < nt) stage(ra0, rb0, ma0, mb0, smem);
+      for (int i = 0; i < nt; i += 2) {
+        if (i + 2 < nt) request_a(tile_beg + i + 2, ra0, ma0);
+        if (i + 1 < nt) { stage_a(ra1, ma1, smem + SET); stage_b(rb0, rz0, mb0, smem + SET); }
+        if (i + 2 < nt) request_b(tile_beg + i + 2, rb0, rz0, mb0);
         __syncthreads();
+        if (i + 1 < nt) {
+          if (i + 3 < nt) request_a(tile_beg + i + 3, ra1, ma1);
+          if (i + 2 < nt) { stage_a(ra0, ma0, smem); stage_b(rb0, rz0, mb0, smem); }
+          if (i + 3 < nt) request_b(tile_beg + i + 3, rb0, rz0, mb0);
+          __syncthreads();
+        }
+      }
+    } else {
+      auto request = [&](int tile, f32x4 (&ra)[NA], f32x4 (&rb)[NB], f32x4 (&rz)[NZ], unsigned& ma, unsigned& mb) {
+        request_a(tile, ra, ma);
+        request_b(tile, rb, rz, mb);
+      };
+      auto stage = [&](const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], const f32x4 (&rz)[NZ], unsigned ma, unsigned mb, char* set) {
+        stage_a(ra, ma, set);
+        stage_b(rb, rz, mb, set);
+      };
+      f32x4 (&rb1r)[NB] = reinterpret_cast<f32x4 (&)[NB]>(rb1);
+      f32x4 (&rz1r)[NZ] = reinterpret_cast<f32x4 (&)[NZ]>(rz1);
+      request(tile_beg, ra0, rb0, rz0, ma0, mb0);
+      if (nt > 1) request(tile_beg + 1, ra1, rb1r, rz1r, ma1, mb1);
+      stage(ra0, rb0, rz0, ma0, mb0, smem);
+      __syncthreads();
+      for (int i = 0; i < nt; i += 2) {
+        if (i + 2 < nt) request(tile_beg + i + 2, ra0, rb0, rz0, ma0, mb0);
+        if (i + 1 < nt) stage(ra1, rb1r, rz1r, ma1, mb1, smem + SET);
+        __syncthreads();
+        if (i + 1 < nt) {
+          if (i + 3 < nt) request(tile_beg + i + 3, ra1, rb1r, rz1r, ma1, mb1);
+          if (i + 2 < nt) stage(ra0, rb0, rz0, ma0, mb0, smem);
+          __syncthreads();
+        }
       }
     }
     if constexpr (WK > 1) {   // keep in step with the barriers of the consumers' cross-wave reduction
@@ -339,12 +420,12 @@ static long wgrad_h_ws(int N, int Hb, int Wb, int Cm, int Cn) {
   return (long)pl.splits * L + 32 * L;
 }
 
-template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW, bool A_SCALED>
+template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW, bool A_SCALED, bool DZIN = false>
 static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, const float* aScale, const float* bScale,
                           const float* xSc, const float* xSh, const float* xAbound, int N, int Ha, int Wa, int Hb, int Wb, int Cm, int Cn,
-                          hipStream_t st, const char* name) {
+                          hipStream_t st, const char* name, const float* bZ = nullptr, const float* dzCoef = nullptr) {
   using Cfg = WgradHCfg<KH, KW, S, PAD, TW, RW, WM, WNW, NBW>;
-  auto kern = wgrad_f16x3_kernel<KH, KW, S, PAD, TW, RW, WM, WNW, NBW, A_SCALED>;
+  auto kern = wgrad_f16x3_kernel<KH, KW, S, PAD, TW, RW, WM, WNW, NBW, A_SCALED, DZIN>;
   static DcLdsAttr lds_attr;      // one per template instantiation; per-device inside
   if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES, name)) return rc;
   WgradHPlan pl = wgrad_h_plan<KH, KW, S, PAD, TW, RW, WM, WNW, NBW>(N, Hb, Wb, Cm, Cn);
@@ -360,6 +441,7 @@ static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, 
   hp.aSc = A_SCALED ? nullptr : xSc; hp.aSh = A_SCALED ? nullptr : xSh;
   hp.bSc = A_SCALED ? xSc : nullptr; hp.bSh = A_SCALED ? xSh : nullptr;
   hp.xAbound = xAbound; hp.xChannels = A_SCALED ? Cn : Cm;
+  hp.bZ = bZ; hp.dzCoef = dzCoef;
   dim3 grid((unsigned)(pl.splits * dc_cdiv(Cm, Cfg::CM) * dc_cdiv(Cn, Cfg::CN)));
   hipLaunchKernelGGL(kern, grid, dim3(512), Cfg::LDS_BYTES, st, hp);
   DC_CHECK_LAUNCH(name);
@@ -409,6 +491,11 @@ static int conv_h_impl(const float* x, const float* xSc, const float* xSh, const
   const float* none = nullptr;
   CONV_H_DISPATCH(wgrad_h_launch, , false>(x, dz, dw, ws, none, dzScale, xSc, xSh, xAb, N, H, W, H, W, Cin, Cout, st, "conv3x3_wgrad_f16x3"))
 }
+static int conv_h_dzin_impl(const float* x, const float* xSc, const float* xSh, const float* xAb, const float* da, const float* z,
+                            const float* dzCoef, float* dw, float* ws, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+  const float* none = nullptr;
+  CONV_H_DISPATCH(wgrad_h_launch, , false, true>(x, da, dw, ws, none, none, xSc, xSh, xAb, N, H, W, H, W, Cin, Cout, st, "conv3x3_wgrad_dzin_f16x3", z, dzCoef))
+}
 static int convT_h_impl(const float* x, const float* xSc, const float* xSh, const float* xAb, const float* dz, float* dw,
                         float* ws, const float* dzScale, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
   const float* none = nullptr;
@@ -455,4 +542,25 @@ extern "C" int dc_convT2x2_wgrad_bnin_f16x3(const float* z_in, const float* in_s
   DC_REQUIRE(in_sc && in_sh && dc_aligned16(in_sc) && dc_aligned16(in_sh), DC_EINVAL,
              "dc_convT2x2_wgrad_bnin_f16x3: scale/shift must be non-null and 16-byte aligned");
   return convT_h_impl(z_in, in_sc, in_sh, in_abound, dz, dw, ws, dz_scale, N, H, W, Cin, Cout, (hipStream_t)stream);
+}
+
+int dc_conv3x3_c1_wgrad_dzin(const float* x, const float* da, const float* z, const float* dz_coef, float* dw, float* ws,
+                             int N, int H, int W, int Cout, hipStream_t st);     // conv_c1.hip
+
+// "dz on load" weight gradient (dcunet.h): dz is formed from (da, z, dz_coef) by the producer waves.
+extern "C" int dc_conv3x3_wgrad_dzin_f16x3(const float* x, const float* in_sc, const float* in_sh, const float* x_abound,
+                                           const float* da, const float* z, const float* dz_coef, float* dw, float* ws,
+                                           int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
+  DC_REQUIRE(z && dz_coef && dc_aligned16(z) && dc_aligned16(dz_coef), DC_EINVAL,
+             "dc_conv3x3_wgrad_dzin_f16x3: z / dz_coef must be non-null and 16-byte aligned");
+  DC_REQUIRE((in_sc == nullptr) == (in_sh == nullptr), DC_EINVAL, "dc_conv3x3_wgrad_dzin_f16x3: in_scale and in_shift go together");
+  if (Cin == 1) {
+    DC_REQUIRE(x && da && dw && ws && !in_sc, DC_EINVAL, "dc_conv3x3_wgrad_dzin_f16x3: bad first-layer arguments");
+    return dc_conv3x3_c1_wgrad_dzin(x, da, z, dz_coef, dw, ws, N, H, W, Cout, (hipStream_t)stream);
+  }
+  int rc = check_h("dc_conv3x3_wgrad_dzin_f16x3", x, da, dw, ws, N, H, W, Cin, Cout);
+  if (rc) return rc;
+  DC_REQUIRE(!in_sc || (dc_aligned16(in_sc) && dc_aligned16(in_sh)), DC_EINVAL,
+             "dc_conv3x3_wgrad_dzin_f16x3: scale/shift must be 16-byte aligned");
+  return conv_h_dzin_impl(x, in_sc, in_sh, x_abound, da, z, dz_coef, dw, ws, N, H, W, Cin, Cout, (hipStream_t)stream);
 }

@@ -184,6 +184,8 @@ class _TtaJob(object):
 
 
 class UNetEngine(object):
+    SLOTS = 3       # rotation depth of the backward's per-block buffers (dz / dz-on-load table / activation gradient)
+
     def __init__(self, window_shape, nb_filters_base=32, prop_dropout_base=0.25, device=None, seed=7535, mfma=None,
                  upsampling=False, bn_mode=None, conv_kernel_init='he_normal'):
         # mfma: 'f16x3' (default; fp32-grade split-fp16 products on the fp16 matrix cores) or 'f32' (fp32 MFMA)
@@ -191,42 +193,21 @@ class UNetEngine(object):
         if self.mfma not in ('f16x3', 'f32'):
             raise ValueError("mfma must be 'f16x3' or 'f32', got %r" % self.mfma)
         self.streams = 1 if os.environ.get('DC_STREAMS', '2') == '1' else 2     # 2: weight gradients on a side stream
-        # Backward schedule, DC_WGRAD_AFTER_DGRAD: 2 (default) = the weight gradient of a block starts when its data gradient
-        # has FINISHED wherever that data gradient runs on the role-split conv kernel -- it owns a CU's whole LDS, so the
-        # two cannot share a CU anyway, and ordered this way the critical path never queues behind 256 persistent
-        # weight-gradient workgroups -- and together with it elsewhere (conv-transpose, narrow layers: the 256-thread
-        # kernels co-reside); 1 = always after, 0 = always together.  Same-box: 840.6 / 838.7 / 843.0 images/s for 2 / 1 / 0,
-        # dominant-kernel launch 0.235 / 0.235 / 0.243 ms.
-        _order = os.environ.get('DC_WGRAD_AFTER_DGRAD', '2')
-        self.wgrad_after_dgrad = _order == '1'
-        self.wgrad_order_hybrid = _order == '2'
-        self.dz_bufs = int(os.environ.get('DC_DZ_BUFS', '3'))
-        # levels whose weight gradients run on the MAIN stream (no overlap): at 512^2 the weight-gradient kernels are
-        # HBM-bound themselves, so beside an HBM-bound BatchNorm pass the two only share the bandwidth (and lose some)
-        self.wgrad_main_lvls = frozenset(int(v) for v in os.environ.get('DC_WGRAD_MAIN_LVLS', '').split(',') if v != '')
         # BN + ReLU on load: activations that only feed a conv / conv-transpose / the head (no dropout, pool or
         # skip) are never written; their consumers take (z, scale, shift) instead.  f16x3 kernels only.
         self.bnin = self.mfma == 'f16x3' and os.environ.get('DC_BNIN', '1') == '1'
-        # BatchNorm-backward pass-1 sums emitted by the kernel that produces da (head / max-pool backward)
-        self.bnred = os.environ.get('DC_BNRED', '1') == '1'
-        # BN + ReLU + dropout of the block in front of a max-pool also does the pooling (one pass less over its activation)
-        self.pool_fused = os.environ.get('DC_POOL_FUSED', '1') == '1'
-        # BCE-type losses: the head's backward is done by its forward kernel (dc_head_fwd_bwd)
-        self.head_fused = os.environ.get('DC_HEAD_FUSED', '1') == '1'
-        # inference: the convolution in front of a max-pool writes the pooled tensor too (role-split kernel, POOL variant)
-        self.conv_pool = os.environ.get('DC_CONV_POOL', '1') == '1'
-        # data gradients served by the role-split kernel also emit the BatchNorm-backward sums of the layer they feed
-        self.dgrad_bnred = os.environ.get('DC_DGRAD_BNRED', '1') == '1'
-        # the finalize launch behind the BatchNorm-backward apply pass (conv-bias gradient + power-of-two scale of dz) runs on
-        # the weight-gradient stream; the data gradient derives the scale itself from the per-block maxima
-        # DC_FINALIZE_SIDE = auto (default) | 1 | 0.  Measured (same box): at the reference's own training windows (128^2 x 20,
-        # launch-latency bound) it takes one launch per block off the main queue, +1.3 %; at 512^2 x 16 it costs 0.7 %: the
-        # weight gradient starts ~8 us later behind the finalize launch, and the NEXT data gradient cannot start before that
-        # weight gradient has released the CUs (the two kernels cannot share one).  auto: small steps only.
-        self.finalize_side = os.environ.get('DC_FINALIZE_SIDE', 'auto') if self.mfma == 'f16x3' else '0'
+        # dz on load (round 4): the BatchNorm-backward apply pass of a Dropout-free conv block is never run -- its data- and
+        # weight-gradient kernels form dz from (da, z) and a per-channel table while they stage their operands
+        # (dc_bn_bwd_finalize_dzin / dc_conv3x3_dgrad_dzin_f16x3 / dc_conv3x3_wgrad_dzin_f16x3).  f16x3 kernels only.
+        # DC_DZIN = 1 (default): the 512^2-class blocks (level 0), where every kernel of the block is HBM-bound and the pass
+        # removed is pure time; 'all': every eligible block (levels >= 1 measured 7-15 % slower matrix kernels for a 30-150 us
+        # apply pass that the weight-gradient stream hides anyway: DESIGN 5e); 0: off.
+        _dz = os.environ.get('DC_DZIN', '1')
+        self.dzin = self.mfma == 'f16x3' and _dz != '0'
+        self.dzin_lvls = frozenset(range(5)) if _dz == 'all' else frozenset((0,))
         self._head_bwd_done = False
-        # fp16 range guard of the activation operands (A/B knob; the weights' pack-time scale is unconditional)
-        self.range_guard = os.environ.get('DC_RANGE_GUARD', '1') == '1'
+        # fp16 range guard of the activation operands of the f16x3 contractions (csrc/common.h)
+        self.range_guard = self.mfma == 'f16x3'
         # Inference starts OPTIMISTIC: no activation scale (a BatchNorm network's activations are O(1)), the kernels only
         # flag an output beyond fp16's range; forward_infer_checked() then repeats the pass with MEASURED per-channel
         # bounds and keeps doing so for this engine (un-normalised inputs, exotic weights).  DC_INFER_GUARD=1: measured
@@ -732,7 +713,7 @@ class UNetEngine(object):
                                     sc, sh, 1, *self._ab_infer(l)[2:], N, h, w, l.cout, st)
             elif l.kind == 'conv':
                 nxt = plan[si + 1] if si + 1 < len(plan) else None
-                if (self.conv_pool and self.mfma == 'f16x3' and not (self.range_guard and self.infer_measured)
+                if (self.mfma == 'f16x3' and not (self.range_guard and self.infer_measured)
                         and nxt is not None and nxt[0] == 'pool' and nxt[2] is dst and nxt[3] == coff
                         and L.dc_conv3x3_fwd_pool_blocks(N, h, w, l.cin, l.cout) > 0):
                     # the block in front of a max-pool: activation (into the concat buffer) and pooled tensor in one kernel
@@ -833,14 +814,19 @@ class UNetEngine(object):
         T['stats_ws'] = torch.empty(stats_floats, dtype=torch.float64, device=dev)      # (sum, sum of squares) partials
         T['part_ws'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['part_ws2'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
+        # per-(row, channel) max |dy| next to the pass-1 sums of the same producer (dc_bn_bwd_finalize_dzin)
+        T['amax_ws'] = torch.empty(part_floats // 2 + 4, dtype=torch.float32, device=dev)
+        T['amax_ws2'] = torch.empty(part_floats // 2 + 4, dtype=torch.float32, device=dev)
         T['head_gpart'] = torch.empty(hb * (nfb + 4), dtype=torch.float32, device=dev)
         # per dz buffer: the apply pass' per-block max |dz| and conv-bias-gradient partials (read by the finalize launch on the
         # weight-gradient stream and by the data gradient: they rotate with the dz buffer they describe)
-        T['absmax'] = [torch.empty(4096, dtype=torch.float32, device=dev) for _ in range(self.dz_bufs)]
+        T['absmax'] = [torch.empty(4096, dtype=torch.float32, device=dev) for _ in range(self.SLOTS)]
         dpart = max(L.dc_bn_bwd_blocks(N * self._hw(l.lvl)[0] * self._hw(l.lvl)[1], l.cout) * l.cout
                     for l in self.layers if l.kind != 'head')
-        T['dbias_part'] = [torch.empty(dpart, dtype=torch.float32, device=dev) for _ in range(self.dz_bufs)]
-        T['dz_scale'] = torch.ones(self.dz_bufs * 4, dtype=torch.float32, device=dev)      # one (16-B aligned) scalar per dz buffer
+        T['dbias_part'] = [torch.empty(dpart, dtype=torch.float32, device=dev) for _ in range(self.SLOTS)]
+        T['dz_scale'] = torch.ones(self.SLOTS * 4, dtype=torch.float32, device=dev)      # one (16-B aligned) scalar per dz buffer
+        cmax = max(l.cout for l in self.layers if l.kind != 'head')
+        T['dz_coef'] = [torch.zeros(7 * cmax, dtype=torch.float32, device=dev) for _ in range(self.SLOTS)]   # dz-on-load tables
         T['red_tmp'] = torch.empty(32 * 1024, dtype=torch.float32, device=dev)
         T['wgrad_ws'] = torch.empty(ws_floats, dtype=torch.float32, device=dev)
         T['sums'] = torch.zeros(12, dtype=torch.float64, device=dev)
@@ -848,10 +834,10 @@ class UNetEngine(object):
         T['bn_gsum'] = torch.zeros(2 * max(l.cout for l in self.layers if l.kind != 'head'), dtype=torch.float32, device=dev)
         big = N * self.H * self.W * nfb
         # dz rotates over 3 buffers: the weight-gradient kernels run on a side stream and may still be reading the
-        # dz of block L while the main stream already produces the dz of block L-1 / L-2
-        T['dz'] = [torch.empty(big, dtype=torch.float32, device=dev) for _ in range(self.dz_bufs)]
-        T['gA'] = torch.empty(big, dtype=torch.float32, device=dev)
-        T['gB'] = torch.empty(big, dtype=torch.float32, device=dev)
+        # dz of block L while the main stream already produces the dz of block L-1 / L-2.  The activation gradients
+        # rotate over 3 buffers for the same reason: with dz formed on load the weight gradient of block L reads `da`.
+        T['dz'] = [torch.empty(big, dtype=torch.float32, device=dev) for _ in range(self.SLOTS)]
+        T['g'] = [torch.empty(big, dtype=torch.float32, device=dev) for _ in range(self.SLOTS)]
         for lvl in range(4):
             h, w = self._hw(lvl)
             T['dcat%d' % lvl] = torch.empty(N * h * w * (self._cup(lvl) + (nfb << lvl)), dtype=torch.float32, device=dev)
@@ -969,7 +955,7 @@ class UNetEngine(object):
                                        self.sview(l, 'mvar'), st)
             mptr, keep, seed = self._drop_args(l, masks, step_seed)
             nxt = plan[si + 1] if si + 1 < len(plan) else None
-            if self.pool_fused and nxt is not None and nxt[0] == 'pool' and nxt[2] is dst and nxt[3] == coff:
+            if nxt is not None and nxt[0] == 'pool' and nxt[2] is dst and nxt[3] == coff:
                 lvl = nxt[1]
                 L.dc_bn_relu_drop_pool_fwd(_ptr(z), self.stat_ptr(l, 0), self.stat_ptr(l, 1),
                                            self.pview(self.pflat, l, 'gamma'), self.pview(self.pflat, l, 'beta'),
@@ -989,16 +975,16 @@ class UNetEngine(object):
         hb = L.dc_head_blocks(pixels)
         hsrc = self._bnin_src(self.by_name['d0b'], T)
         self._head_bwd_done = False
-        if self.head_fused and self.loss_kind in (0, 1):
+        if self.loss_kind in (0, 1):
             # per-pixel losses: the head's backward rides on its forward (one pass over the 512^2 x nfb tensor instead of
             # two); backward() picks up da, the weight-gradient partials and d0b's BatchNorm-backward sums from here
             a_in, sc_in, sh_in = (hsrc[0], hsrc[1][0], hsrc[1][1]) if hsrc is not None else (_ptr(A['d0b']), None, None)
             ld0 = self.by_name['d0b']
-            red = hsrc is not None and self.bnred
+            red = hsrc is not None
             L.dc_head_fwd_bwd(a_in, sc_in, sh_in, self.pview(self.pflat, lo, 'k'), self.pview(self.pflat, lo, 'b'),
-                              y_dev.data_ptr(), _ptr(A['p']), _ptr(T['part_ws']), _ptr(T['gA']), _ptr(T['head_gpart']),
+                              y_dev.data_ptr(), _ptr(A['p']), _ptr(T['part_ws']), _ptr(T['g'][0]), _ptr(T['head_gpart']),
                               self.loss_kind, self.stat_ptr(ld0, 0) if red else None, self.stat_ptr(ld0, 1) if red else None,
-                              _ptr(T['part_ws2']) if red else None, pixels, self.nfb, st)
+                              _ptr(T['part_ws2']) if red else None, _ptr(T['amax_ws2']) if red else None, pixels, self.nfb, st)
             self._head_bwd_done = True
         elif hsrc is not None:
             L.dc_head_fwd_bnin(hsrc[0], hsrc[1][0], hsrc[1][1], self.pview(self.pflat, lo, 'k'),
@@ -1016,93 +1002,95 @@ class UNetEngine(object):
         o_ba, o_dec = self.by_name['ba'].off['k'][0], self.layers[10].off['k'][0]
         return [(o_dec, self.n_train), (o_ba, o_dec), (0, o_ba)]
 
+    def _dzin_ok(self, l, N):
+        """Does block l run without the BatchNorm-backward apply pass (dz formed on load by its gradient kernels)?"""
+        if not self.dzin or l.kind != 'conv' or l.drop > 0.0 or l.lvl not in self.dzin_lvls:
+            return False
+        if l.cin == 1:
+            return True
+        h, w = self._hw(l.lvl)
+        return self.L.dc_conv3x3_dgrad_dzin_blocks(N, h, w, l.cin, l.cout) > 0
+
     @_on_device
     def backward(self, bucket_cb=None):
         """Backward of the last forward_train: fills gflat (same layout as pflat).  bucket_cb(lo, hi), if given, is called
         with the side (weight-gradient) stream current as soon as gflat[lo:hi] is complete on it -- data-parallel training
         starts that range's all-reduce there, so it overlaps with the rest of the backward (grad_buckets()[:2]; the last
-        range is complete when backward() returns)."""
+        range is complete when backward() returns).
+
+        Per Conv -> BN -> ReLU block, in reverse order (unet_2d_summary.py:163-167):
+          pass-1 sums (sum dy, sum dy*xhat [, max |dy|]) -- emitted by the kernel that WROTE da wherever one exists (head,
+            max-pool backward, the data gradient above), else dc_bn_bwd_reduce;
+          Dropout-free conv blocks: dc_bn_bwd_finalize_dzin -> data gradient and weight gradient form dz on load;
+          the others (Dropout, conv-transpose, small shapes): finalize -> dc_bn_bwd_apply (writes dz) -> gradients.
+        Two HIP streams: the critical path (sums -> data gradient -> next block) stays on the caller's stream, the weight
+        gradients go to a side stream.  Hand-offs are stream events; what a weight gradient reads (dz or the table, and
+        `da`) rotates over SLOTS buffers guarded by the event of the weight gradient that read it last."""
         N, masks, step_seed, x_dev, y_dev = self._last
         L, st = self.L, self._stream()
         A, T = self._acts(N), self._train_bufs(N)
         nfb = self.nfb
+        f16 = self.mfma == 'f16x3'
         pixels0 = N * self.H * self.W
         lo = self.by_name['out']
         hb = L.dc_head_blocks(pixels0)
         hsrc = self._bnin_src(self.by_name['d0b'], T)
-        fused_d0b = None          # (partial ptr, rows): BN-backward sums of d0b already produced by the head kernel
+        gb = T['g']
+        fused_d0b = None          # (partial ptr, amax ptr, rows): pass-1 sums of d0b already produced by the head kernel
         gpart = T['part_ws']
-        if self._head_bwd_done:   # forward_train's fused head kernel has written gA, the gradient partials and the sums
+        if self._head_bwd_done:   # forward_train's fused head kernel has written g[0], the gradient partials and the sums
             self._head_bwd_done = False
             gpart = T['head_gpart']
-            if hsrc is not None and self.bnred:
-                fused_d0b = (_ptr(T['part_ws2']), hb)
-        elif hsrc is not None and self.bnred:
+            if hsrc is not None:
+                fused_d0b = (_ptr(T['part_ws2']), _ptr(T['amax_ws2']), hb)
+        elif hsrc is not None:
             ld0 = self.by_name['d0b']
             L.dc_head_bwd_bnin_bnred(hsrc[0], hsrc[1][0], hsrc[1][1], _ptr(A['p']), y_dev.data_ptr(),
-                                     self.pview(self.pflat, lo, 'k'), _ptr(T['gA']), _ptr(T['part_ws']), self.loss_kind,
+                                     self.pview(self.pflat, lo, 'k'), _ptr(gb[0]), _ptr(T['part_ws']), self.loss_kind,
                                      T['sums'].data_ptr(), self.stat_ptr(ld0, 0), self.stat_ptr(ld0, 1),
-                                     _ptr(T['part_ws2']), pixels0, nfb, st)
-            fused_d0b = (_ptr(T['part_ws2']), hb)
-        elif hsrc is not None:
-            L.dc_head_bwd_bnin(hsrc[0], hsrc[1][0], hsrc[1][1], _ptr(A['p']), y_dev.data_ptr(),
-                               self.pview(self.pflat, lo, 'k'), _ptr(T['gA']), _ptr(T['part_ws']), self.loss_kind,
-                               T['sums'].data_ptr(), pixels0, nfb, st)
+                                     _ptr(T['part_ws2']), _ptr(T['amax_ws2']), pixels0, nfb, st)
+            fused_d0b = (_ptr(T['part_ws2']), _ptr(T['amax_ws2']), hb)
         else:
             L.dc_head_bwd(_ptr(A['d0b']), _ptr(A['p']), y_dev.data_ptr(), self.pview(self.pflat, lo, 'k'),
-                          _ptr(T['gA']), _ptr(T['part_ws']), self.loss_kind, T['sums'].data_ptr(), pixels0, nfb, st)
+                          _ptr(gb[0]), _ptr(T['part_ws']), self.loss_kind, T['sums'].data_ptr(), pixels0, nfb, st)
         L.dc_head_grad_finalize(_ptr(gpart), hb, nfb, self.pview(self.gflat, lo, 'k'),
                                 self.pview(self.gflat, lo, 'b'), st)
 
-        # Two HIP streams: the critical path (BN backward -> dgrad -> next block) stays on the caller's stream; the
-        # weight gradients -- off the critical path, matrix-pipe bound, light on HBM -- go to a side stream where they
-        # overlap with the HBM-bound BatchNorm passes of the following blocks.  Hand-offs are stream events.
-        # Measured on one MI355X (same box, interleaved runs): 25.06 -> 23.5 ms/step (+6.6 %); the overlapping
-        # kernels themselves run ~25 % longer (they share CUs and HBM).  DC_STREAMS=1 / engine.streams = 1 turns it off.
         main = torch.cuda.current_stream(self.device)
         if getattr(self, '_side_stream', None) is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
-            self._dz_free = [None] * self.dz_bufs
-        if self.streams == 1:
-            self._dz_free = [None] * self.dz_bufs
         side = self._side_stream if self.streams == 2 else main
-        sw = side.cuda_stream
         two = side is not main
         if two:
             side.wait_stream(main)        # everything queued so far (forward, head) precedes the first wgrad
-        self._dz_turn = getattr(self, '_dz_turn', 0)
-        self._last_side_w = None
-
-        def launch_dgrad(l, dz, wpd, dx_ptr, scale, h, w, f16, red=None, amax=None, amax_n=0):
-            """red = the BatchNorm layer whose `da` this data gradient writes (dense, no dropout): when the role-split
-            kernel serves the shape its epilogue also emits that layer's backward sums -> (partial ptr, rows)."""
-            if l.kind == 'conv':
-                if f16 and red is not None:
-                    rows = L.dc_conv3x3_dgrad_bnred_blocks(N, h, w, l.cin, l.cout)
-                    if rows > 0:
-                        L.dc_conv3x3_dgrad_bnred_f16x3(dz, wpd, dx_ptr, scale, amax, amax_n, _ptr(T['z_' + red.name]), self.stat_ptr(red, 0),
-                                                       self.stat_ptr(red, 1), self.pview(self.pflat, red, 'gamma'),
-                                                       self.pview(self.pflat, red, 'beta'), _ptr(T['part_ws']), N, h, w,
-                                                       l.cin, l.cout, st)
-                        return (_ptr(T['part_ws']), rows)
-                if f16:
-                    L.dc_conv3x3_dgrad_f16x3(dz, wpd, dx_ptr, scale, amax, amax_n, N, h, w, l.cin, l.cout, st)
-                else:
-                    L.dc_conv3x3_dgrad(dz, wpd, dx_ptr, N, h, w, l.cin, l.cout, st)
-            elif f16:
-                L.dc_convT2x2_dgrad_f16x3(dz, wpd, dx_ptr, scale, amax, amax_n, N, h // 2, w // 2, l.cin, l.cout, st)
-            else:
-                L.dc_convT2x2_dgrad(dz, wpd, dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
-            return None
-
+        S = self.SLOTS
+        slot_free = [None] * S            # event of the weight gradient that last read slot k's dz / table
+        g_free = [None] * S               # event of the weight gradient that last read g[k] as `da` (dz on load)
+        state = {'slot': 0, 'g': 0}       # next block slot; index of the buffer holding the current activation gradient
         world = parallel.world_size()
         sync = self.bn_mode == 'sync' and world > 1
 
-        def block_bwd(l, x_in, da_ptr, da_ld, dx_ptr, prod=None, fused=None, red=None):
-            """da (strided) -> grads of l; dx written to dx_ptr (dense [.., cin]) unless None.  prod: the layer that
-            produced x_in (its activation may be non-materialised: BN + ReLU on load).  red: the layer whose `da` dx is
-            (see launch_dgrad); returns what that layer's block_bwd takes as `fused`."""
-            fused_next = None
+        def g_cur():
+            return gb[state['g']]
+
+        def g_next():
+            """The buffer the next activation gradient goes to (rotation): safe to overwrite once the weight gradient
+            that read it as `da` three blocks ago has finished."""
+            k = (state['g'] + 1) % S
+            if two and g_free[k] is not None:
+                main.wait_event(g_free[k])
+                g_free[k] = None
+            return k
+
+        def red_of(la):          # pass-1 sums out of the data gradient's epilogue: dense da of a dropout-free layer only
+            return la if la.drop <= 0.0 else None
+
+        def block_bwd(l, x_in, da_ptr, da_ld, dx_ptr, prod=None, fused=None, red=None, da_g=None):
+            """da (da_ld-strided) -> gradients of block l; dx (dense [.., cin]) written to dx_ptr unless None.  prod: the
+            layer that produced x_in (its activation may be non-materialised: BN + ReLU on load).  fused: (partial, amax,
+            rows) when the producer of da emitted the pass-1 sums.  red: the layer whose `da` dx is -- when the data
+            gradient runs on the role-split kernel it emits that layer's sums; returned for that layer's `fused`.
+            da_g: index of the g buffer da lives in (None: a dcat buffer, written once per step)."""
             bsrc = self._bnin_src(prod, T)
             h, w = self._hw(l.lvl)
             pixels = N * h * w
@@ -1111,70 +1099,124 @@ class UNetEngine(object):
             mean, invstd = self.stat_ptr(l, 0), self.stat_ptr(l, 1)
             gamma, beta = self.pview(self.pflat, l, 'gamma'), self.pview(self.pflat, l, 'beta')
             dgamma, dbeta = self.pview(self.gflat, l, 'gamma'), self.pview(self.gflat, l, 'beta')
-            blocks = L.dc_bn_bwd_blocks(pixels, l.cout)
-            k = self._dz_turn
-            self._dz_turn = (k + 1) % self.dz_bufs
-            dz, scale = _ptr(T['dz'][k]), _ptr(T['dz_scale'], 4 * k)
-            if fused is not None:      # pass-1 sums came out of the kernel that wrote da
-                L.dc_bn_bwd_finalize(fused[0], fused[1], l.cout, dgamma, dbeta, st)
-            else:
+            dk, ws = self.pview(self.gflat, l, 'k'), _ptr(T['wgrad_ws'])
+            dzin = da_ld == l.cout and self._dzin_ok(l, N)
+            k = state['slot']
+            state['slot'] = (k + 1) % S
+            if fused is None:
                 L.dc_bn_bwd_reduce(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed,
-                                   _ptr(T['part_ws']), pixels, l.cout, st)
-                L.dc_bn_bwd_finalize(_ptr(T['part_ws']), blocks, l.cout, dgamma, dbeta, st)
-            if two and self._dz_free[k] is not None:
-                main.wait_event(self._dz_free[k])       # the wgrad that last read this dz buffer has finished
-            dpart, amaxp = _ptr(T['dbias_part'][k]), _ptr(T['absmax'][k])
+                                   _ptr(T['part_ws']), _ptr(T['amax_ws']) if dzin else None, pixels, l.cout, st)
+                fused = (_ptr(T['part_ws']), _ptr(T['amax_ws']), L.dc_bn_bwd_blocks(pixels, l.cout))
+            if two and slot_free[k] is not None:
+                main.wait_event(slot_free[k])       # the weight gradient that last read this slot has finished
+                slot_free[k] = None
+            count = float((world if sync else 1) * pixels)
+            gg = None
             if sync:
                 # (dgamma, dbeta) are adjacent in gflat and stay the rank-LOCAL sums there (the end-of-step all-reduce
-                # of gflat makes them global exactly once); the apply pass needs the GLOBAL sums now: all-reduce a
-                # scratch copy (a device memcpy, no arithmetic outside the kernels)
+                # of gflat makes them global exactly once); dz needs the GLOBAL sums now: all-reduce a scratch copy
+                # (a device memcpy, no arithmetic outside the kernels)
+                L.dc_bn_bwd_finalize(fused[0], fused[2], l.cout, dgamma, dbeta, st)
                 g0, _ = l.off['gamma']
                 gg = T['bn_gsum'][:2 * l.cout]
                 gg.copy_(self.gflat[g0:g0 + 2 * l.cout])
                 parallel.all_reduce_sum(gg)
+
+            if dzin:
+                # ---- dz on load: table -> data gradient (main) -> weight gradient (side); no dz tensor ------------------
+                coef = _ptr(T['dz_coef'][k])
+                if gg is not None:
+                    L.dc_bn_bwd_finalize_dzin(None, fused[1], fused[2], l.cout, mean, invstd, gamma, beta, count,
+                                              _ptr(gg), _ptr(gg, l.cout), coef, self.pview(self.gflat, l, 'b'), st)
+                else:
+                    L.dc_bn_bwd_finalize_dzin(fused[0], fused[1], fused[2], l.cout, mean, invstd, gamma, beta, count,
+                                              dgamma, dbeta, coef, self.pview(self.gflat, l, 'b'), st)
+                fused_next = None
+                if dx_ptr is not None:
+                    rargs = (None,) * 7
+                    if red is not None:
+                        rows = L.dc_conv3x3_dgrad_dzin_blocks(N, h, w, l.cin, l.cout)
+                        rargs = (_ptr(T['z_' + red.name]), self.stat_ptr(red, 0), self.stat_ptr(red, 1),
+                                 self.pview(self.pflat, red, 'gamma'), self.pview(self.pflat, red, 'beta'),
+                                 _ptr(T['part_ws']), _ptr(T['amax_ws']))
+                        fused_next = (_ptr(T['part_ws']), _ptr(T['amax_ws']), rows)
+                    L.dc_conv3x3_dgrad_dzin_f16x3(da_ptr, _ptr(z), coef, _ptr(self.wp_dgrad[l.name]), dx_ptr, *rargs,
+                                                  N, h, w, l.cin, l.cout, st)
+                if two:
+                    ready = torch.cuda.Event()
+                    ready.record(main)
+                    side.wait_event(ready)
+                sw = side.cuda_stream
+                xa = (bsrc[0], bsrc[1][0], bsrc[1][1]) if bsrc is not None else (x_in, None, None)
+                L.dc_conv3x3_wgrad_dzin_f16x3(xa[0], xa[1], xa[2], self._ab_in(l), da_ptr, _ptr(z), coef, dk, ws,
+                                              N, h, w, l.cin, l.cout, sw)
+                if two:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    slot_free[k] = ev
+                    if da_g is not None:
+                        g_free[da_g] = ev
+                return fused_next
+
+            # ---- apply pass: dz is materialised (Dropout blocks, conv-transposes, shapes the dz-on-load kernels skip) ----
+            dz, scale = _ptr(T['dz'][k]), _ptr(T['dz_scale'], 4 * k)
+            dpart, amaxp = _ptr(T['dbias_part'][k]), _ptr(T['absmax'][k])
+            blocks = L.dc_bn_bwd_blocks(pixels, l.cout)
+            if gg is not None:
                 L.dc_bn_bwd_apply_count(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed,
-                                        _ptr(gg), _ptr(gg, l.cout), dz, dpart, amaxp, pixels,
-                                        float(world * pixels), l.cout, st)
+                                        _ptr(gg), _ptr(gg, l.cout), dz, dpart, amaxp, pixels, count, l.cout, st)
             else:
+                L.dc_bn_bwd_finalize(fused[0], fused[2], l.cout, dgamma, dbeta, st)
                 L.dc_bn_bwd_apply(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed, dgamma, dbeta,
                                   dz, dpart, amaxp, pixels, l.cout, st)
-            f16 = self.mfma == 'f16x3'
+
             # one launch: conv-bias gradient (column sums of the dz partials) + -- f16x3 -- the exact power-of-two scale
-            # that brings max|dz| to [512, 1024] before the fp16 split.  Nothing on the critical path needs its outputs when
-            # the data gradient derives the scale from the per-block maxima itself (finalize_side): it then runs on the
-            # weight-gradient stream, in front of the weight gradient that reads the scale.
+            # that brings max|dz| to [512, 1024] before the fp16 split.  On small steps (launch-latency bound: the
+            # reference's own 96^2 / 128^2 training windows) it runs on the weight-gradient stream and the data gradient
+            # derives the scale from the per-block maxima itself (+1.3 % there, -0.7 % at 512^2 x 16: DESIGN 5d).
             def finalize(stream):
                 L.dc_bn_bwd_apply_finalize(dpart, amaxp if f16 else None, blocks, l.cout, 1024.0,
                                            self.pview(self.gflat, l, 'b'), scale if f16 else None, stream)
-            side_fin = f16 and (self.finalize_side == '1' or (self.finalize_side == 'auto' and N * self.H * self.W <= (1 << 20)))
+            side_fin = f16 and N * self.H * self.W <= (1 << 20)
             if not side_fin:
                 finalize(st)
             d_scale, d_amax, d_amax_n = (None, amaxp, blocks) if side_fin else (scale, None, 0)
-            on_main = two and l.lvl in self.wgrad_main_lvls       # this block's weight gradient stays on the main stream
-            if two and not on_main:
+
+            def dgrad():
+                if l.kind == 'conv':
+                    if f16 and red is not None:
+                        rows = L.dc_conv3x3_dgrad_bnred_blocks(N, h, w, l.cin, l.cout)
+                        if rows > 0:
+                            L.dc_conv3x3_dgrad_bnred_f16x3(dz, wpd, dx_ptr, d_scale, d_amax, d_amax_n, _ptr(T['z_' + red.name]),
+                                                           self.stat_ptr(red, 0), self.stat_ptr(red, 1),
+                                                           self.pview(self.pflat, red, 'gamma'), self.pview(self.pflat, red, 'beta'),
+                                                           _ptr(T['part_ws']), _ptr(T['amax_ws']), N, h, w, l.cin, l.cout, st)
+                            return (_ptr(T['part_ws']), _ptr(T['amax_ws']), rows)
+                    if f16:
+                        L.dc_conv3x3_dgrad_f16x3(dz, wpd, dx_ptr, d_scale, d_amax, d_amax_n, N, h, w, l.cin, l.cout, st)
+                    else:
+                        L.dc_conv3x3_dgrad(dz, wpd, dx_ptr, N, h, w, l.cin, l.cout, st)
+                elif f16:
+                    L.dc_convT2x2_dgrad_f16x3(dz, wpd, dx_ptr, d_scale, d_amax, d_amax_n, N, h // 2, w // 2, l.cin, l.cout, st)
+                else:
+                    L.dc_convT2x2_dgrad(dz, wpd, dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
+                return None
+
+            fused_next = None
+            wpd = _ptr(self.wp_dgrad[l.name]) if dx_ptr is not None else None
+            # where the data gradient runs on the role-split kernel (it owns a CU's whole LDS: the two cannot share a CU
+            # anyway) it goes FIRST and the weight gradient starts when it has finished -- the critical path never queues
+            # behind 256 persistent weight-gradient workgroups; elsewhere (conv-transpose, narrow layers) they start together
+            after = dx_ptr is not None and f16 and l.kind == 'conv' and L.dc_conv3x3_pp_blocks(N, h, w, l.cin, l.cout, 1, 0) > 0
+            if after:
+                fused_next = dgrad()
+            if two:
                 ready = torch.cuda.Event()
                 ready.record(main)
-            # ---- main stream first: the data gradient feeds the next block ---------------------------------------
-            wpd = _ptr(self.wp_dgrad[l.name]) if dx_ptr is not None else None
-            after = self.wgrad_after_dgrad
-            if self.wgrad_order_hybrid:
-                after = f16 and l.kind == 'conv' and L.dc_conv3x3_pp_blocks(N, h, w, l.cin, l.cout, 1, 0) > 0
-            if dx_ptr is not None and after:
-                fused_next = launch_dgrad(l, dz, wpd, dx_ptr, d_scale, h, w, f16, red, d_amax, d_amax_n)
-                if two and not on_main:
-                    ready = torch.cuda.Event()
-                    ready.record(main)
-            # ---- side stream: weight gradient of this block -------------------------------------------------------
-            sw = side.cuda_stream
-            if on_main:
-                sw = st
-                if self._last_side_w is not None:
-                    main.wait_event(self._last_side_w)      # the shared slab workspace: one weight gradient at a time
-            elif two:
                 side.wait_event(ready)
+            sw = side.cuda_stream
             if side_fin:
                 finalize(sw)
-            dk, ws = self.pview(self.gflat, l, 'k'), _ptr(T['wgrad_ws'])
             if bsrc is not None and l.kind == 'conv':
                 L.dc_conv3x3_wgrad_bnin_f16x3(bsrc[0], bsrc[1][0], bsrc[1][1], self._ab_in(l), dz, dk, ws, scale, N, h, w,
                                               l.cin, l.cout, sw)
@@ -1190,36 +1232,35 @@ class UNetEngine(object):
                 L.dc_convT2x2_wgrad_f16x3(x_in, dz, dk, ws, scale, self._ab_in(l), N, h // 2, w // 2, l.cin, l.cout, sw)
             else:
                 L.dc_convT2x2_wgrad(x_in, dz, dk, ws, N, h // 2, w // 2, l.cin, l.cout, sw)
-            if two and not on_main:
-                self._dz_free[k] = torch.cuda.Event()
-                self._dz_free[k].record(side)
-                self._last_side_w = self._dz_free[k]
-            elif two:
-                self._dz_free[k] = None                     # main-stream order protects the dz buffer
+            if two:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                slot_free[k] = ev
             if dx_ptr is not None and not after:
-                fused_next = launch_dgrad(l, dz, wpd, dx_ptr, d_scale, h, w, f16, red, d_amax, d_amax_n)
+                fused_next = dgrad()
             return fused_next
 
-        def red_of(la):          # dgrad-fused BatchNorm-backward sums: dense da of a dropout-free layer only
-            return la if (self.bnred and self.dgrad_bnred and la.drop <= 0.0) else None
-
-        g, other = T['gA'], T['gB']      # g holds the gradient w.r.t. the current block's output
+        # ---- decoder: d<l>b -> d<l>a -> (up-conv | up-sampling) for l = 0..3 ---------------------------------------
         for lvl in (0, 1, 2, 3):
             c = nfb << lvl
             cat, dcat = A['cat%d' % lvl], T['dcat%d' % lvl]
             la = self.by_name['d%da' % lvl]
-            fa = block_bwd(self.by_name['d%db' % lvl], _ptr(A['d%da' % lvl]), _ptr(g), c, _ptr(other),
-                           prod=la, fused=fused_d0b if lvl == 0 else None, red=red_of(la))
-            g, other = other, g
-            block_bwd(la, _ptr(cat), _ptr(g), c, _ptr(dcat), fused=fa)
+            ki, ko = state['g'], g_next()
+            fa = block_bwd(self.by_name['d%db' % lvl], _ptr(A['d%da' % lvl]), _ptr(gb[ki]), c, _ptr(gb[ko]),
+                           prod=la, fused=fused_d0b if lvl == 0 else None, red=red_of(la), da_g=ki)
+            state['g'] = ko
+            block_bwd(la, _ptr(cat), _ptr(gb[ko]), c, _ptr(dcat), fused=fa, da_g=ko)
             x_up = A['bb'] if lvl == 3 else A['d%db' % (lvl + 1)]
             l_up = self.by_name['bb' if lvl == 3 else 'd%db' % (lvl + 1)]
+            kn = g_next()
             if self.upsampling:
                 h, w = self._hw(lvl)
                 mptr, keep, seed = self._up_drop_args(lvl, masks, step_seed)
-                L.dc_upsample2x_drop_bwd(_ptr(dcat), 3 * c, mptr, keep, seed, _ptr(g), N, h // 2, w // 2, 2 * c, st)
+                L.dc_upsample2x_drop_bwd(_ptr(dcat), 3 * c, mptr, keep, seed, _ptr(gb[kn]), N, h // 2, w // 2, 2 * c, st)
             else:
-                block_bwd(self.by_name['u%d' % lvl], _ptr(x_up), _ptr(dcat), 2 * c, _ptr(g), prod=l_up)
+                block_bwd(self.by_name['u%d' % lvl], _ptr(x_up), _ptr(dcat), 2 * c, _ptr(gb[kn]), prod=l_up)
+            state['g'] = kn
+
         def bucket_done(i):
             if bucket_cb is None:
                 return
@@ -1229,40 +1270,39 @@ class UNetEngine(object):
                 bucket_cb(*self.grad_buckets()[i])
 
         bucket_done(0)
+        # ---- bottleneck and encoder: (max-pool backward + skip) -> <tag>b -> <tag>a for l = 4..0 --------------------
         for lvl in (4, 3, 2, 1, 0):
             c = nfb << lvl
             h, w = self._hw(lvl)
             tag = 'b' if lvl == 4 else 'e%d' % lvl
             if lvl == 3:
                 bucket_done(1)
+            fused_pool = None
             if lvl < 4:
-                # g = d(pool output); route through the argmax and add the skip gradient (second half of dcat)
+                # g = d(pool output); route through the argmax and add the skip gradient (second half of dcat); the
+                # kernel also emits the pooled layer's pass-1 sums while it writes da
                 cup = self._cup(lvl)
                 lb = self.by_name[tag + 'b']
-                if self.bnred:
-                    mptr, keep, seed = self._drop_args(lb, masks, step_seed)
-                    L.dc_maxpool2x2_bwd_bnred(_ptr(g), A['idx%d' % lvl].data_ptr(), _ptr(T['dcat%d' % lvl], cup), cup + c,
-                                              _ptr(other), _ptr(T['z_' + lb.name]), self.stat_ptr(lb, 0),
-                                              self.stat_ptr(lb, 1), self.pview(self.pflat, lb, 'gamma'),
-                                              self.pview(self.pflat, lb, 'beta'), mptr, keep, seed,
-                                              _ptr(T['part_ws2']), N, h, w, c, st)
-                    fused_pool = (_ptr(T['part_ws2']), L.dc_maxpool2x2_bwd_blocks(N, h, w, c))
-                else:
-                    L.dc_maxpool2x2_bwd(_ptr(g), A['idx%d' % lvl].data_ptr(), _ptr(T['dcat%d' % lvl], cup), cup + c,
-                                        _ptr(other), N, h, w, c, st)
-                    fused_pool = None
-                g, other = other, g
-            else:
-                fused_pool = None
+                ki, ko = state['g'], g_next()
+                mptr, keep, seed = self._drop_args(lb, masks, step_seed)
+                L.dc_maxpool2x2_bwd_bnred(_ptr(gb[ki]), A['idx%d' % lvl].data_ptr(), _ptr(T['dcat%d' % lvl], cup), cup + c,
+                                          _ptr(gb[ko]), _ptr(T['z_' + lb.name]), self.stat_ptr(lb, 0),
+                                          self.stat_ptr(lb, 1), self.pview(self.pflat, lb, 'gamma'),
+                                          self.pview(self.pflat, lb, 'beta'), mptr, keep, seed,
+                                          _ptr(T['part_ws2']), _ptr(T['amax_ws2']), N, h, w, c, st)
+                fused_pool = (_ptr(T['part_ws2']), _ptr(T['amax_ws2']), L.dc_maxpool2x2_bwd_blocks(N, h, w, c))
+                state['g'] = ko
             la = self.by_name[tag + 'a']
-            fa = block_bwd(self.by_name[tag + 'b'], _ptr(A[tag + 'a']), _ptr(g), c, _ptr(other), prod=la,
-                           fused=fused_pool, red=red_of(la))
-            g, other = other, g
+            ki, ko = state['g'], g_next()
+            fa = block_bwd(self.by_name[tag + 'b'], _ptr(A[tag + 'a']), _ptr(gb[ki]), c, _ptr(gb[ko]), prod=la,
+                           fused=fused_pool, red=red_of(la), da_g=ki)
+            state['g'] = ko
             if lvl == 0:
-                block_bwd(la, _ptr(x_dev), _ptr(g), c, None, fused=fa)
+                block_bwd(la, _ptr(x_dev), _ptr(gb[ko]), c, None, fused=fa, da_g=ko)
             else:
-                block_bwd(la, _ptr(A['pool%d' % (lvl - 1)]), _ptr(g), c, _ptr(other), fused=fa)
-                g, other = other, g
+                kn = g_next()
+                block_bwd(la, _ptr(A['pool%d' % (lvl - 1)]), _ptr(gb[ko]), c, _ptr(gb[kn]), fused=fa, da_g=ko)
+                state['g'] = kn
         if two:
             main.wait_stream(side)        # gflat is complete once both streams have drained
 

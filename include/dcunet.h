@@ -192,11 +192,12 @@ int dc_bn_relu_drop_pool_fwd(const float* z, const float* mean, const float* inv
                              float* pooled, uint8_t* idx, int N, int H, int W, int C, double count, float* abound,
                              dc_stream_t stream);
 /* backward, pass 1: partial[blocks][C][2] = (sum dy, sum dy*xhat) with dy = da*relu'(.)*dropmask/keep.
- * blocks = dc_bn_bwd_blocks(pixels, C). */
+ * blocks = dc_bn_bwd_blocks(pixels, C).  amax_partial (nullable) [blocks][C] = max |dy| per block and channel
+ * (what dc_bn_bwd_finalize_dzin bounds |dz| with; every pass-1 producer below takes the same argument). */
 int dc_bn_bwd_blocks(long pixels, int C);
 int dc_bn_bwd_reduce(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, const uint8_t* mask, float keep, uint64_t seed,
-                     float* partial, long pixels, int C, dc_stream_t stream);
+                     float* partial, float* amax_partial, long pixels, int C, dc_stream_t stream);
 /* backward, pass 2: dz = gamma*invstd*(dy - dbeta/M - xhat*dgamma/M); dbias_partial[blocks][C] = sum dz;
  * absmax_partial (nullable) [blocks] = max |dz| per block, for dc_pow2_scale_from_absmax. */
 int dc_bn_bwd_apply(const float* da, long da_ld, const float* z, const float* mean, const float* invstd,
@@ -237,16 +238,48 @@ int dc_conv3x3_dgrad_bnred_blocks(int N, int H, int W, int Cin, int Cout);
 int dc_conv3x3_dgrad_bnred_f16x3(const float* dz, const void* wp16, float* dx, const float* dz_scale,
                                  const float* dz_absmax, int dz_absmax_n, const float* z,
                                  const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                 float* bn_partial, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+                                 float* bn_partial, float* amax_partial, int N, int H, int W, int Cin, int Cout,
+                                 dc_stream_t stream);
 int dc_head_bwd_bnin_bnred(const float* z_in, const float* in_scale, const float* in_shift, const float* p,
                            const uint8_t* y, const float* kh, float* da, float* partial, int loss_kind,
                            const double* sums, const float* bn_mean, const float* bn_invstd, float* bn_partial,
-                           long pixels, int C, dc_stream_t stream);
+                           float* amax_partial, long pixels, int C, dc_stream_t stream);
 int dc_maxpool2x2_bwd_blocks(int N, int H, int W, int C);
 int dc_maxpool2x2_bwd_bnred(const float* dy, const uint8_t* idx, const float* skip, long skip_ld, float* dx,
                             const float* z, const float* mean, const float* invstd, const float* gamma,
                             const float* beta, const uint8_t* mask, float keep, uint64_t seed, float* bn_partial,
-                            int N, int H, int W, int C, dc_stream_t stream);
+                            float* amax_partial, int N, int H, int W, int C, dc_stream_t stream);
+
+/* ---- BatchNorm backward WITHOUT the apply pass: "dz on load" (unet_2d_summary.py:163-167, Dropout-free blocks) ------
+ * dz = gamma*invstd*(dy - dbeta/M - xhat*dgamma/M) is a per-channel affine of (dy, z): the data- and weight-gradient
+ * kernels of the block form it while they stage their operands, so dz is never written and dc_bn_bwd_apply (read da,
+ * read z, write dz) disappears:  dy = [fmaf(z, sc, sh) > 0] * da ;  dz = fmaf(A, dy, fmaf(D, z - mu, E)).
+ *   dc_bn_bwd_finalize_dzin = dc_bn_bwd_finalize (partial != NULL; partial == NULL: dgamma / dbeta are INPUTS, the
+ *     all-reduced sums of 'sync' BatchNorm, count = global elements per channel) + the table
+ *     dz_coef[DC_DZ_COEF_ROWS][C] = { sc, sh, mu, A, D, E, bound } with bound_c >= max |dz_c| for ANY data
+ *     (= |A| (max|dy_c| + |dbeta|/M + sqrt(M) |dgamma|/M); amax_partial[P][C] = per-row max |dy_c| from the pass-1
+ *     producer): the consumers' fp16 range guard brings the largest bound into [2^14, 2^15).
+ *   dc_conv3x3_dgrad_dzin_f16x3: dx = conv3x3_transpose(dz) from (da, z, dz_coef) (all dense [N,H,W,Cout]); role-split
+ *     kernel only: dc_conv3x3_dgrad_dzin_blocks() == 0 -> shape not served, use dc_bn_bwd_apply + dc_conv3x3_dgrad_f16x3.
+ *     red_z != NULL: dx IS the `da` of the BatchNorm layer in front (as dc_conv3x3_dgrad_bnred_f16x3): also emits
+ *     bn_partial[rows][Cin][2] and amax_partial[rows][Cin], rows = the returned block count.
+ *   dc_conv3x3_wgrad_dzin_f16x3: dW = sum_p x[p+tap] (x) dz[p]; x as dc_conv3x3_wgrad_f16x3 (in_scale / in_shift NULL)
+ *     or the producer's pre-BN tensor with BN + ReLU on load (as dc_conv3x3_wgrad_bnin_f16x3).  Cin == 1 (first layer):
+ *     x is the (N,H,W) image.
+ * The conv bias in front of a BatchNorm has the exact gradient sum_p dz = 0: dc_bn_bwd_finalize_dzin writes that 0 to
+ * dbias[C] (nullable; the apply pass summed rounding noise there). */
+#define DC_DZ_COEF_ROWS 7
+int dc_bn_bwd_finalize_dzin(const float* partial, const float* amax_partial, int P, int C, const float* mean,
+                            const float* invstd, const float* gamma, const float* beta, double count,
+                            float* dgamma, float* dbeta, float* dz_coef, float* dbias, dc_stream_t stream);
+int dc_conv3x3_dgrad_dzin_blocks(int N, int H, int W, int Cin, int Cout);
+int dc_conv3x3_dgrad_dzin_f16x3(const float* da, const float* z, const float* dz_coef, const void* wp16, float* dx,
+                                const float* red_z, const float* red_mean, const float* red_invstd,
+                                const float* red_gamma, const float* red_beta, float* bn_partial, float* amax_partial,
+                                int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+int dc_conv3x3_wgrad_dzin_f16x3(const float* x, const float* in_scale, const float* in_shift, const float* x_abound,
+                                const float* da, const float* z, const float* dz_coef, float* dw, float* ws,
+                                int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 
 /* ---- synchronised BatchNorm for batch-sharded data parallelism ('sync' mode) ---------------------
  * The per-channel sums leave the device between two launches so the host can all-reduce them over the ranks:
@@ -307,8 +340,8 @@ int dc_head_bwd(const float* a, const float* p, const uint8_t* y, const float* k
  * backward: DC_EUNSUP. */
 int dc_head_fwd_bwd(const float* a, const float* in_scale, const float* in_shift, const float* kh, const float* bh,
                     const uint8_t* y, float* p, float* partial, float* da, float* grad_partial, int loss_kind,
-                    const float* bn_mean, const float* bn_invstd, float* bn_partial, long pixels, int C,
-                    dc_stream_t stream);
+                    const float* bn_mean, const float* bn_invstd, float* bn_partial, float* amax_partial, long pixels,
+                    int C, dc_stream_t stream);
 int dc_head_grad_finalize(const float* partial, int blocks, int C, float* dkh, float* dbh, dc_stream_t stream);
 
 /* ---- generic deterministic reductions ------------------------------------------

@@ -205,7 +205,7 @@ def test_dgrad_bn_backward_sums_per_tile_at_batch_16(HW, Cin, Cout):
     from deep_calcium_amd._lib import lib
     L = lib()
     Nb = 16
-    if not _fused_paths_enabled('DC_DGRAD_BNRED'):
+    if not _fused_paths_enabled():
         pytest.skip('fused data-gradient sums switched off by the environment')
     rows = L.dc_conv3x3_dgrad_bnred_blocks(Nb, HW, HW, Cin, Cout)
     TH = 16 if Cin <= 32 else 8
@@ -225,10 +225,12 @@ def test_dgrad_bn_backward_sums_per_tile_at_batch_16(HW, Cin, Cout):
     outs = []
     for _ in range(3):
         part = torch.full((rows * Cin * 2,), float('nan'), device='cuda')
+        amx = torch.full((rows * Cin,), float('nan'), device='cuda')
         L.dc_conv3x3_dgrad_bnred_f16x3(dz.data_ptr(), wpd.data_ptr(), dx.data_ptr(), scale.data_ptr(), None, 0, z.data_ptr(), mu.data_ptr(),
-                                       isd.data_ptr(), ga.data_ptr(), be.data_ptr(), part.data_ptr(), Nb, HW, HW, Cin, Cout, None)
+                                       isd.data_ptr(), ga.data_ptr(), be.data_ptr(), part.data_ptr(), amx.data_ptr(), Nb, HW, HW, Cin, Cout, None)
         torch.cuda.synchronize()
         outs.append(part.cpu().numpy().reshape(rows, Cin, 2))
+        amaxs = amx.cpu().numpy().reshape(rows, Cin)
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
     dxa, za = dx.cpu().numpy().astype(np.float64), z.cpu().numpy().astype(np.float64)
     mu64, is64 = mu.cpu().numpy().astype(np.float64), isd.cpu().numpy().astype(np.float64)
@@ -238,6 +240,8 @@ def test_dgrad_bn_backward_sums_per_tile_at_batch_16(HW, Cin, Cout):
     dy = np.where(gate, dxa, 0.0)
     ref = np.stack([_tile_sums(dy, TH, Cin), _tile_sums(dy * (za - mu64) * is64, TH, Cin)], axis=2)
     assert np.abs(outs[0] - ref).max() < 1e-5 * np.abs(ref).max()
+    # max |dy| per (tile, channel) -- what dc_bn_bwd_finalize_dzin bounds |dz| with: a max has no rounding
+    assert np.array_equal(amaxs.max(0), np.abs(dy).reshape(-1, Cin).max(0).astype(np.float32))
 
 
 @pytest.mark.parametrize('HW,Ci,Co', [(512, 32, 32), (256, 64, 64), (64, 256, 256)])
@@ -247,7 +251,7 @@ def test_inference_conv_with_pooled_output_at_batch_8(HW, Ci, Co):
     from deep_calcium_amd._lib import lib
     L = lib()
     Nb = 8
-    if not _fused_paths_enabled('DC_CONV_POOL'):
+    if not _fused_paths_enabled():
         pytest.skip('pooled-output convolution switched off by the environment')
     assert L.dc_conv3x3_fwd_pool_blocks(Nb, HW, HW, Ci, Co) > 0
     g = torch.Generator(device='cuda').manual_seed(8)

@@ -462,7 +462,7 @@ def test_batchnorm_relu_dropout_fwd_bwd(dclib, pixels_shape, C, keep):
     dbias = torch.empty(C, device='cuda')
     tmp = torch.empty(32 * C, device='cuda')
     args = (dad.data_ptr(), C, zd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(), mptr, keep, 0)
-    L.dc_bn_bwd_reduce(*args, part1.data_ptr(), M, C, None)
+    L.dc_bn_bwd_reduce(*args, part1.data_ptr(), None, M, C, None)
     L.dc_bn_bwd_finalize(part1.data_ptr(), blocks, C, dg.data_ptr(), db.data_ptr(), None)
     amax = torch.empty(blocks, device='cuda')
     scl = torch.empty(1, device='cuda')
@@ -552,8 +552,6 @@ def test_dgrad_with_fused_bn_backward_sums(dclib, N, H, W, Cin, Cout):
     it emits for the layer in front (gate from that layer's own affine, xhat from its statistics) finalize to what
     dc_bn_bwd_reduce gives on the same da / z -- interior and ragged tiles, 2- / 3- / many-step tiles, both tile shapes."""
     L = dclib
-    if not _fused_paths_enabled('DC_DGRAD_BNRED'):
-        pytest.skip('fused data-gradient sums switched off by the environment')
     rows = L.dc_conv3x3_dgrad_bnred_blocks(N, H, W, Cin, Cout)
     assert rows > 0
     rs = np.random.RandomState(Cin + H)
@@ -568,8 +566,9 @@ def test_dgrad_with_fused_bn_backward_sums(dclib, N, H, W, Cin, Cout):
     dx0 = torch.full((N, H, W, Cin), float('nan'), device='cuda'); dx1 = torch.full_like(dx0, float('nan'))
     L.dc_conv3x3_dgrad_f16x3(dz.data_ptr(), wpd.data_ptr(), dx0.data_ptr(), scale.data_ptr(), None, 0, N, H, W, Cin, Cout, None)
     part = torch.full((rows * Cin * 2,), float('nan'), device='cuda')
+    amx = torch.full((rows * Cin,), float('nan'), device='cuda')
     L.dc_conv3x3_dgrad_bnred_f16x3(dz.data_ptr(), wpd.data_ptr(), dx1.data_ptr(), scale.data_ptr(), None, 0, z.data_ptr(), mu.data_ptr(),
-                                   isd.data_ptr(), ga.data_ptr(), be.data_ptr(), part.data_ptr(), N, H, W, Cin, Cout, None)
+                                   isd.data_ptr(), ga.data_ptr(), be.data_ptr(), part.data_ptr(), amx.data_ptr(), N, H, W, Cin, Cout, None)
     torch.cuda.synchronize()
     assert np.array_equal(dx0.cpu().numpy(), dx1.cpu().numpy())
     assert np.isfinite(part.cpu().numpy()).all()
@@ -578,7 +577,7 @@ def test_dgrad_with_fused_bn_backward_sums(dclib, N, H, W, Cin, Cout):
     amax_part[7] = 255.9
     dx2, part2 = torch.full_like(dx0, float('nan')), torch.full_like(part, float('nan'))
     L.dc_conv3x3_dgrad_bnred_f16x3(dz.data_ptr(), wpd.data_ptr(), dx2.data_ptr(), None, amax_part.data_ptr(), 19, z.data_ptr(), mu.data_ptr(),
-                                   isd.data_ptr(), ga.data_ptr(), be.data_ptr(), part2.data_ptr(), N, H, W, Cin, Cout, None)
+                                   isd.data_ptr(), ga.data_ptr(), be.data_ptr(), part2.data_ptr(), None, N, H, W, Cin, Cout, None)
     torch.cuda.synchronize()
     assert torch.equal(dx1, dx2) and torch.equal(part, part2)
     pixels = N * H * W
@@ -586,8 +585,9 @@ def test_dgrad_with_fused_bn_backward_sums(dclib, N, H, W, Cin, Cout):
     if Cin & (Cin - 1) == 0:             # (the two-pass kernel takes power-of-two channel counts only)
         blocks = L.dc_bn_bwd_blocks(pixels, Cin)
         p2 = torch.zeros(blocks * Cin * 2, device='cuda')
+        am2 = torch.zeros(blocks * Cin, device='cuda')
         L.dc_bn_bwd_reduce(dx0.data_ptr(), Cin, z.data_ptr(), mu.data_ptr(), isd.data_ptr(), ga.data_ptr(), be.data_ptr(), None, 1.0, 0,
-                           p2.data_ptr(), pixels, Cin, None)
+                           p2.data_ptr(), am2.data_ptr(), pixels, Cin, None)
         todo.append((p2, blocks))
     out = []
     for ptr, r in todo:
@@ -614,7 +614,7 @@ def test_inference_conv_with_pooled_output_equals_conv_then_pool(dclib, N, H, W,
     """dc_conv3x3_fwd_pool_f16x3 (folded BN + ReLU, optimistic range flag) == dc_conv3x3_fwd_f16x3 followed by
     dc_maxpool2x2_fwd on its (strided) output, bit for bit -- interior and ragged tiles, both tile shapes."""
     L = dclib
-    if not _fused_paths_enabled('DC_CONV_POOL'):
+    if not _fused_paths_enabled():
         pytest.skip('pooled-output convolution switched off by the environment')
     assert L.dc_conv3x3_fwd_pool_blocks(N, H, W, Cin, Cout) > 0
     rs = np.random.RandomState(H + Cout)
@@ -660,7 +660,7 @@ def test_head_fused_forward_backward_equals_separate_calls(dclib, C, pixels, kin
         return dict(p=torch.empty(pixels, device='cuda'), part=torch.zeros(hb * 12, device='cuda'), da=torch.empty((pixels, C), device='cuda'),
                     gp=torch.zeros(hb * (C + 4), device='cuda'), bp=torch.zeros(hb * C * 2, device='cuda'),
                     sums=torch.zeros(12, dtype=torch.float64, device='cuda'), dk=torch.zeros((C, 2), device='cuda'), db=torch.zeros(2, device='cuda'),
-                    dg=torch.zeros(C, device='cuda'), dbt=torch.zeros(C, device='cuda'))
+                    dg=torch.zeros(C, device='cuda'), dbt=torch.zeros(C, device='cuda'), am=torch.zeros(hb * C, device='cuda'))
     A, B = bufs(), bufs()
     scp, shp = (sc.data_ptr(), sh.data_ptr()) if bnin else (None, None)
     # separate
@@ -668,7 +668,7 @@ def test_head_fused_forward_backward_equals_separate_calls(dclib, C, pixels, kin
         L.dc_head_fwd_bnin(a.data_ptr(), scp, shp, kh.data_ptr(), bh.data_ptr(), y.data_ptr(), A['p'].data_ptr(), A['part'].data_ptr(), pixels, C, None)
         L.dc_reduce_partials_f64(A['part'].data_ptr(), hb, 12, A['sums'].data_ptr(), None)
         L.dc_head_bwd_bnin_bnred(a.data_ptr(), scp, shp, A['p'].data_ptr(), y.data_ptr(), kh.data_ptr(), A['da'].data_ptr(), A['gp'].data_ptr(), kind,
-                                 A['sums'].data_ptr(), mu.data_ptr(), isd.data_ptr(), A['bp'].data_ptr(), pixels, C, None)
+                                 A['sums'].data_ptr(), mu.data_ptr(), isd.data_ptr(), A['bp'].data_ptr(), A['am'].data_ptr(), pixels, C, None)
     else:
         L.dc_head_fwd(a.data_ptr(), kh.data_ptr(), bh.data_ptr(), y.data_ptr(), A['p'].data_ptr(), A['part'].data_ptr(), pixels, C, None)
         L.dc_reduce_partials_f64(A['part'].data_ptr(), hb, 12, A['sums'].data_ptr(), None)
@@ -676,7 +676,7 @@ def test_head_fused_forward_backward_equals_separate_calls(dclib, C, pixels, kin
     # fused
     L.dc_head_fwd_bwd(a.data_ptr(), scp, shp, kh.data_ptr(), bh.data_ptr(), y.data_ptr(), B['p'].data_ptr(), B['part'].data_ptr(), B['da'].data_ptr(),
                       B['gp'].data_ptr(), kind, mu.data_ptr() if bnin else None, isd.data_ptr() if bnin else None, B['bp'].data_ptr() if bnin else None,
-                      pixels, C, None)
+                      B['am'].data_ptr() if bnin else None, pixels, C, None)
     L.dc_reduce_partials_f64(B['part'].data_ptr(), hb, 12, B['sums'].data_ptr(), None)
     for X in (A, B):
         L.dc_head_grad_finalize(X['gp'].data_ptr(), hb, C, X['dk'].data_ptr(), X['db'].data_ptr(), None)
@@ -686,12 +686,17 @@ def test_head_fused_forward_backward_equals_separate_calls(dclib, C, pixels, kin
     assert np.array_equal(A['p'].cpu().numpy(), B['p'].cpu().numpy())
     assert np.array_equal(A['da'].cpu().numpy(), B['da'].cpu().numpy())
     assert np.array_equal(A['sums'].cpu().numpy(), B['sums'].cpu().numpy())
+    if bnin:       # per-(block, channel) max |da| (the dz-on-load bound's input): its maximum over the blocks is the tensor's
+        amax_ref = np.abs(A['da'].cpu().numpy()).max(0)
+        for X in (A, B):
+            am = X['am'].cpu().numpy().reshape(hb, C).max(0)
+            assert np.all(am >= amax_ref * (1 - 1e-6)) and np.all(am <= amax_ref * (1 + 1e-6) + 1e-30), (am, amax_ref)
     for k in ('dk', 'db') + (('dg', 'dbt') if bnin else ()):
         x, z = A[k].cpu().numpy().astype(np.float64), B[k].cpu().numpy().astype(np.float64)
         assert np.abs(x - z).max() <= 2e-6 * max(np.abs(x).max(), 1e-30), (k, x, z)
     with pytest.raises(Exception):
         L.dc_head_fwd_bwd(a.data_ptr(), scp, shp, kh.data_ptr(), bh.data_ptr(), y.data_ptr(), B['p'].data_ptr(), B['part'].data_ptr(), B['da'].data_ptr(),
-                          B['gp'].data_ptr(), 2, None, None, None, pixels, C, None)
+                          B['gp'].data_ptr(), 2, None, None, None, None, pixels, C, None)
 
 
 @pytest.mark.parametrize('N,H,W,C,drop', [(2, 16, 16, 32, 'rng'), (1, 12, 20, 8, 'mask'), (3, 8, 8, 64, 'none'), (1, 64, 64, 256, 'rng')])
@@ -820,18 +825,30 @@ def test_bnred_sums_from_pool_and_head_backward(dclib, N, H, W, C, keep):
     L.dc_maxpool2x2_bwd(dyd.data_ptr(), idd.data_ptr(), skd.data_ptr() + 32, C + 8, dx1.data_ptr(), N, H, W, C, None)
     P = L.dc_maxpool2x2_bwd_blocks(N, H, W, C)
     part = torch.full((P * C * 2,), float('nan'), device='cuda')
+    amx = torch.full((P * C,), float('nan'), device='cuda')
     L.dc_maxpool2x2_bwd_bnred(dyd.data_ptr(), idd.data_ptr(), skd.data_ptr() + 32, C + 8, dx2.data_ptr(), zd.data_ptr(),
                               md.data_ptr(), isd.data_ptr(), gd.data_ptr(), bd.data_ptr(), mk, keep, 0,
-                              part.data_ptr(), N, H, W, C, None)
+                              part.data_ptr(), amx.data_ptr(), N, H, W, C, None)
     torch.cuda.synchronize()
     assert torch.equal(dx1, dx2)
     Pr = L.dc_bn_bwd_blocks(N * H * W, C)
     part_r = torch.empty(Pr * C * 2, device='cuda')
+    amx_r = torch.full((Pr * C,), float('nan'), device='cuda')
     L.dc_bn_bwd_reduce(dx1.data_ptr(), C, zd.data_ptr(), md.data_ptr(), isd.data_ptr(), gd.data_ptr(), bd.data_ptr(), mk,
-                       keep, 0, part_r.data_ptr(), N * H * W, C, None)
+                       keep, 0, part_r.data_ptr(), amx_r.data_ptr(), N * H * W, C, None)
     (dg, db), (dg_r, db_r) = finalize(part, P), finalize(part_r, Pr)
     tol = 1e-5 * max(1.0, np.abs(dg_r).max(), np.abs(db_r).max())
     assert np.abs(dg - dg_r).max() < tol and np.abs(db - db_r).max() < tol
+    # per-(row, channel) max |dy| (dy = da * relu gate * dropout factor): both producers' maxima over their rows are the
+    # tensor's per-channel maximum, exactly (a max has no rounding)
+    sc32 = gamma * invstd
+    sh32 = (beta.astype(np.float64) - mean.astype(np.float64) * sc32.astype(np.float64)).astype(np.float32)
+    gate = (z.astype(np.float64) * sc32.astype(np.float64) + sh32.astype(np.float64)) > 0
+    dy_ref = dx1.cpu().numpy() * gate * ((mask.astype(np.float32) * np.float32(1.0 / keep)) if mask is not None else 1.0)
+    amax_ref = np.abs(dy_ref).reshape(-1, C).max(0)
+    for a_, rows_ in ((amx, P), (amx_r, Pr)):
+        got = a_.cpu().numpy().reshape(rows_, C).max(0)
+        assert np.allclose(got, amax_ref, rtol=1e-6, atol=0), (got, amax_ref)
 
     # ---- head backward (BN + ReLU on load, no dropout on the head's input layer)
     if keep == 1.0:
@@ -853,11 +870,11 @@ def test_bnred_sums_from_pool_and_head_backward(dclib, N, H, W, C, keep):
                            da1.data_ptr(), r1.data_ptr(), 0, None, pixels, C, None)
         L.dc_head_bwd_bnin_bnred(zd.data_ptr(), sc.data_ptr(), sh.data_ptr(), pd.data_ptr(), yd.data_ptr(), khd.data_ptr(),
                                  da2.data_ptr(), r2.data_ptr(), 0, None, md.data_ptr(), isd.data_ptr(), partb.data_ptr(),
-                                 pixels, C, None)
+                                 None, pixels, C, None)
         torch.cuda.synchronize()
         assert torch.equal(da1, da2) and torch.equal(r1, r2)
         L.dc_bn_bwd_reduce(da1.data_ptr(), C, zd.data_ptr(), md.data_ptr(), isd.data_ptr(), gd.data_ptr(), bd.data_ptr(),
-                           None, 1.0, 0, part_r.data_ptr(), pixels, C, None)
+                           None, 1.0, 0, part_r.data_ptr(), None, pixels, C, None)
         (dg, db), (dg_r, db_r) = finalize(partb, hb), finalize(part_r, Pr)
         tol = 1e-5 * max(1e-6, np.abs(dg_r).max(), np.abs(db_r).max())
         assert np.abs(dg - dg_r).max() < tol and np.abs(db - db_r).max() < tol
