@@ -413,6 +413,8 @@ def main():
 
     global H, W
     H = W = int(args.window)
+    if args.mode != 'train' and H != 512:
+        ap.error("--window applies to --mode train only: 'infer' / 'tta' are BASELINE configs[1] / configs[4], defined at 512x512")
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args.gpus))         # before anything in this process touches the GPU
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -429,6 +431,10 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     shared_gpus = torch.cuda.device_count() < world
+    if world > 1 and not shared_gpus and (torch.distributed.get_backend() != 'nccl'):
+        # N devices are visible: the N-GPU line must be the RCCL one (gloo is the functional mode for N ranks on ONE device)
+        raise SystemExit('--gpus %d with %d devices visible, but the process group is %r, not nccl (RCCL): refusing to '
+                         'print a scaling line' % (world, torch.cuda.device_count(), torch.distributed.get_backend()))
     local = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)

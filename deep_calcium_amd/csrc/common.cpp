@@ -1,5 +1,6 @@
 // Error reporting, version and HIP-event timing helpers of libdcunet.
 #include "common.h"
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -10,7 +11,17 @@ void dc_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int dc_version(void) { return 100; }
+const DcConfig& dc_config() {
+  static const DcConfig cfg = [] {
+    DcConfig c;
+    const char* v = getenv("DC_IGEMM_PP");
+    c.igemm_pp = v ? atoi(v) : 1;
+    return c;
+  }();
+  return cfg;
+}
+
+extern "C" int dc_version(void) { return 101; }
 extern "C" const char* dc_last_error(void) { return g_err; }
 
 extern "C" int dc_event_create(void** ev) {

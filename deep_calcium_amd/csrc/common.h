@@ -14,6 +14,11 @@
 
 void dc_set_error(const char* fmt, ...);
 
+// The library's only environment switch, read ONCE (common.cpp): DC_IGEMM_PP = 1 (default) the persistent role-split
+// conv3x3 kernel serves every launch it can, 2 = forward launches only, 0 = never (A/B against the 256-thread kernels).
+struct DcConfig { int igemm_pp; };
+const DcConfig& dc_config();
+
 #define DC_REQUIRE(cond, code, ...)        \
   do {                                     \
     if (!(cond)) {                         \

@@ -12,11 +12,11 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 // grid cap of the grid-stride BatchNorm passes: 1 280 = ONE resident round of the backward-apply kernel (5 workgroups per
 // CU at its 90 VGPRs) -- no second, partly filled round beside the weight-gradient stream (2 048: -1.7 % end to end,
-// 1 024: -0.8 %, 4 096: -3.9 %; DC_EW_BLOCKS to re-measure)
-static const int kMaxBlocks = getenv("DC_EW_BLOCKS") ? atoi(getenv("DC_EW_BLOCKS")) : 1280;
-// the BatchNorm-backward passes (reduce / apply) run BESIDE the weight-gradient kernel of the side stream: their own cap
+// 1 024: -0.8 %, 4 096: -3.9 %)
+static const int kMaxBlocks = 1280;
+// the BatchNorm-backward passes (reduce / apply) run BESIDE the weight-gradient kernel of the side stream: the same cap
 // (measured flat between 768 and 1280 workgroups, -0.7 % at 512 and at 1792)
-static const int kMaxBwdBlocks = getenv("DC_EW_BWD_BLOCKS") ? atoi(getenv("DC_EW_BWD_BLOCKS")) : kMaxBlocks;
+static const int kMaxBwdBlocks = kMaxBlocks;
 __device__ __forceinline__ void bn_affine4(const f32x4& mu, const f32x4& is, const f32x4& ga, const f32x4& be, f32x4& sc,
                                            f32x4& sh) {
 #pragma unroll

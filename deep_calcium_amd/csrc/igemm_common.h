@@ -3,11 +3,8 @@
 #include "common.h"
 #include <stdlib.h>
 
-// DC_TILE_WALK = 0 | 1 (default 1): see IgemmParams::walk
-static inline int dc_tile_walk() {
-  static const int v = getenv("DC_TILE_WALK") ? atoi(getenv("DC_TILE_WALK")) : 1;
-  return v;
-}
+// see IgemmParams::walk: column-major (measured +0.6 % end to end, weight-gradient fetch of the 512^2 layers -25 %)
+static inline int dc_tile_walk() { return 1; }
 
 struct IgemmParams {
   const float* in;

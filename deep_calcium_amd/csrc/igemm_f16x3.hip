@@ -463,7 +463,7 @@ static int conv3x3_h_launch(IgemmParams p, hipStream_t st) {
   // The narrow layers at small batch x window (the reference's 128^2 x 20 training configuration: 16^2 and 8^2 images at
   // 256 / 512 channels) give 80 workgroups of 64 / 128 columns: half-width column blocks double the workgroups -- same
   // pixel tiles, so the BatchNorm-partial tile count does not change.
-  static const bool narrow = !(getenv("DC_NARROW_COLS") && atoi(getenv("DC_NARROW_COLS")) == 0);
+  constexpr bool narrow = true;
   if (p.Wout > 8) {
     const long wgs = (long)p.N * dc_cdiv(p.Wout, 16) * dc_cdiv(p.Hout, 16) * dc_cdiv(p.Ncols, 64);
     if (narrow && wgs < 256 && p.Ncols > 32) return igemm_h_launch<3, 3, 1, 1, 16, 4, 2, 1>(p, st, "conv3x3_f16x3");
@@ -721,7 +721,7 @@ static IgemmParams fwd_pool_params(const float* x, const void* wp16, const float
 }
 extern "C" int dc_conv3x3_fwd_pool_blocks(int N, int H, int W, int Cin, int Cout) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (H & 1) || (W & 1)) return 0;
-  static const bool off = getenv("DC_CONV_POOL") && atoi(getenv("DC_CONV_POOL")) == 0;
+  constexpr bool off = false;
   IgemmParams p = fwd_pool_params(nullptr, nullptr, nullptr, nullptr, Cout, nullptr, nullptr, 1, nullptr, nullptr, N, H, W, Cin, Cout);
   if (off || !dc_igemm_pp_serves(p)) return 0;
   return N * dc_cdiv(W, 32) * dc_cdiv(H, Cout <= 32 ? 16 : 8);
@@ -750,7 +750,7 @@ static IgemmParams dgrad_bnred_params(const float* dz, const void* wp16, float* 
 }
 extern "C" int dc_conv3x3_dgrad_bnred_blocks(int N, int H, int W, int Cin, int Cout) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
-  static const bool off = getenv("DC_DGRAD_BNRED") && atoi(getenv("DC_DGRAD_BNRED")) == 0;
+  constexpr bool off = false;
   float dummy = 1.f;      // (a non-null inScale marks a data-gradient launch for the DC_IGEMM_PP=2 setting)
   IgemmParams p = dgrad_bnred_params(nullptr, nullptr, nullptr, &dummy, N, H, W, Cin, Cout);
   if (off || !dc_igemm_pp_serves(p)) return 0;

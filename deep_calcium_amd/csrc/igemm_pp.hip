@@ -672,7 +672,7 @@ bool dc_igemm_pp_serves(const IgemmParams& p) {
   // DC_IGEMM_PP: 0 off, 1 (default) every served launch, 2 forward launches only (a data-gradient launch runs beside the
   // weight-gradient kernel of the side stream, and this kernel's 138 KB of LDS cannot share a CU with that one's 87 KB:
   // measured, serving the data gradients too is still the faster setting: 788 vs 780 vs 774 images/s for 1 / 2 / 0)
-  static const int knob = getenv("DC_IGEMM_PP") ? atoi(getenv("DC_IGEMM_PP")) : 1;
+  const int knob = dc_config().igemm_pp;
   const bool is_dgrad = p.inScale != nullptr || p.inAbsmax != nullptr || p.dzCoef != nullptr;
   const bool enabled = knob == 1 || (knob == 2 && !is_dgrad);
   if (p.dzCoef && p.Cin > pp::DZ_CIN) return false;

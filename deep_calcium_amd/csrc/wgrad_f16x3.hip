@@ -434,8 +434,7 @@ static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, 
   p.A = A; p.B = B; p.slabs = ws;
   p.N = N; p.Ha = Ha; p.Wa = Wa; p.Cm = Cm; p.Hb = Hb; p.Wb = Wb; p.Cn = Cn;
   p.tilesX = pl.tilesX; p.tilesY = pl.tilesY; p.tilesTotal = pl.tilesTotal; p.tilesPerSplit = pl.tilesPerSplit;
-  static const int walk = getenv("DC_TILE_WALK") ? atoi(getenv("DC_TILE_WALK")) : 1;
-  p.walk = walk;
+  p.walk = 1;     // a workgroup's consecutive tiles are vertical neighbours (see IgemmParams::walk)
   hp.aScale = aScale; hp.bScale = bScale;
   // the activation operand is the UNscaled one: A for conv3x3 (A_SCALED = false), B for convT2x2
   hp.aSc = A_SCALED ? nullptr : xSc; hp.aSh = A_SCALED ? nullptr : xSh;

@@ -15,6 +15,7 @@ Memory plan (sized for 288 GB HBM: nothing is recomputed, nothing is pooled):
 """
 import collections
 import os
+import threading
 
 import numpy as np
 import torch
@@ -85,6 +86,7 @@ def build_layer_table(nfb=32, drp=0.25, upsampling=False):
 
 _PINNED = collections.OrderedDict()      # key -> [pinned tensor, event of the last async H2D copy that read it | None]
 _PINNED_MAX_BYTES = 512 << 20
+_PINNED_LOCK = threading.Lock()          # concurrent predict() calls (one key set per thread) share the LRU bookkeeping
 
 
 def _pinned(tag, shape, dtype, entry=False):
@@ -93,11 +95,15 @@ def _pinned(tag, shape, dtype, entry=False):
     dataset count / window size / calling thread adds a key); torch's pinned allocator defers the actual release past any
     copy still in flight.  entry=True returns the [tensor, last-H2D-event] cell itself, so the "has the previous copy out of
     this buffer finished" guard survives the job (and the exception) that issued the copy."""
-    import threading
     key = (tag, tuple(shape), dtype, threading.get_ident())      # one set per calling thread: no sharing between concurrent predict()s
-    ent = _PINNED.get(key)
-    if ent is None:
-        ent = _PINNED[key] = [torch.empty(tuple(shape), dtype=dtype).pin_memory(), None]
+    with _PINNED_LOCK:
+        ent = _PINNED.get(key)
+        if ent is not None:
+            _PINNED.move_to_end(key)
+            return ent if entry else ent[0]
+    new = [torch.empty(tuple(shape), dtype=dtype).pin_memory(), None]       # ~9 ms: outside the lock
+    with _PINNED_LOCK:
+        ent = _PINNED.setdefault(key, new)
         total = sum(e[0].numel() * e[0].element_size() for e in _PINNED.values())
         while total > _PINNED_MAX_BYTES and len(_PINNED) > 1:
             k0 = next(iter(_PINNED))
@@ -105,8 +111,6 @@ def _pinned(tag, shape, dtype, entry=False):
                 break
             old = _PINNED.pop(k0)
             total -= old[0].numel() * old[0].element_size()
-    else:
-        _PINNED.move_to_end(key)
     return ent if entry else ent[0]
 
 
@@ -740,11 +744,12 @@ class UNetEngine(object):
         return p
 
     @_on_device
-    def predict_tta(self, img, augmentations, hs, ws, threshold):
+    def predict_tta(self, img, augmentations, hs, ws, threshold, return_mean=False):
         """predict(augmentation=True) for ONE padded (H,W) float32 numpy image, on the device: the K augmented copies are
         gathered by dc_gather_maps, go through one batch-K forward, and dc_tta_merge inverse-maps, averages (double,
         table order), crops to (hs, ws) and thresholds.  augmentations = [(name, fwd, inv)] on (N,H,W) arrays.
-        Returns the uint8 mask (hs, ws).  Host traffic: 4*H*W bytes in, hs*ws bytes out (vs 8x both ways)."""
+        Returns the uint8 mask (hs, ws) -- with return_mean also the float32 mean probability map (hs, ws) it thresholds.
+        Host traffic: 4*H*W bytes in, hs*ws bytes out (vs 8x both ways)."""
         K, H, W = len(augmentations), self.H, self.W
         n = H * W
         key = ('tta', K, tuple(name for name, _, _ in augmentations))
@@ -767,10 +772,13 @@ class UNetEngine(object):
         m['src'].copy_(m['host'].view(-1), non_blocking=True)
         L.dc_gather_maps(_ptr(m['src']), m['fwd'].data_ptr(), _ptr(m['x']), K, n, st)
         p = self.forward_infer_checked(m['x'])
-        L.dc_tta_merge(_ptr(p), m['inv'].data_ptr(), K, H, W, int(hs), int(ws), float(threshold), m['mask'].data_ptr(), None, st)
+        mean = torch.empty(hs * ws, dtype=torch.float32, device=self.device) if return_mean else None
+        L.dc_tta_merge(_ptr(p), m['inv'].data_ptr(), K, H, W, int(hs), int(ws), float(threshold), m['mask'].data_ptr(),
+                       _ptr(mean) if return_mean else None, st)
         m['mask_host'][:hs * ws].copy_(m['mask'][:hs * ws], non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
-        return m['mask_host'][:hs * ws].numpy().reshape(hs, ws).copy()
+        mask = m['mask_host'][:hs * ws].numpy().reshape(hs, ws).copy()
+        return (mask, mean.cpu().numpy().reshape(hs, ws)) if return_mean else mask
 
     def tta_begin(self, count, augmentations):
         """Pipelined predict() over `count` datasets: see _TtaJob."""

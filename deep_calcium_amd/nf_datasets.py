@@ -18,6 +18,7 @@ Host-side numpy; not part of the GPU path.
 import json
 import logging
 import os
+import time
 import shutil
 from glob import glob
 
@@ -108,9 +109,10 @@ def _download(name, datasets_dir, logger):
     shutil.rmtree(stage, ignore_errors=True)
 
 
-def nf_load_hdf5(names, datasets_dir=None):
+def nf_load_hdf5(names, datasets_dir=None, wait_s=6 * 3600.0):
     """Returns the list of `dataset.hdf5` paths for `names` ('all' | 'all_train' | 'all_test' | 'a,b' | list), building
-    the files that do not exist yet.  nf.py:37-150."""
+    the files that do not exist yet.  nf.py:37-150.  Under data parallelism EVERY rank calls it (rank 0 builds, the others
+    poll for the finished files for at most wait_s seconds)."""
     logger = logging.getLogger('nf_load_hdf5')
     if datasets_dir is None:
         datasets_dir = '%s/neurons_nf' % default_dirs()[0]         # nf.py:37
@@ -119,13 +121,18 @@ def nf_load_hdf5(names, datasets_dir=None):
     for name in dataset_names:
         url = NAME_TO_URL[name]          # KeyError for an unknown name, as in the reference (:72)
         del url
-    # Under data-parallel fit() every rank calls this: rank 0 alone downloads / unpacks / builds, the others wait at the
-    # barrier and then find the finished files (a rank must never glob a directory another rank is still extracting).
+    # Under data-parallel fit() EVERY rank calls this.  Rank 0 alone downloads / unpacks / builds; the others never touch a
+    # directory rank 0 may still be extracting: they poll (no collective: a first 'all' build takes far longer than any
+    # process-group timeout) until every dataset.hdf5 exists -- os.replace() publishes a finished file atomically -- or rank
+    # 0 leaves a failure marker.  Calling it from rank-0-only code is fine too (nobody waits on anybody).
     from . import parallel
     dataset_paths = ['%s/%s/dataset.hdf5' % (datasets_dir, name) for name in dataset_names]
-    err = None
+    marker = '%s/.nf_build_failed' % datasets_dir
+    t_start = time.time()
     if parallel.rank() == 0:
         try:
+            if os.path.exists(marker):
+                os.remove(marker)
             for name, ds_path in zip(dataset_names, dataset_paths):
                 if os.path.exists('%s/%s' % (datasets_dir, name)):
                     logger.info('%s already downloaded.' % name)
@@ -134,14 +141,25 @@ def nf_load_hdf5(names, datasets_dir=None):
                 if not os.path.exists(ds_path):
                     logger.info('Populating %s.' % ds_path)
                     _populate(name, '%s/%s' % (datasets_dir, name), ds_path)
-        except Exception as e:           # still reach the barrier: the other ranks must not hang on a failed download
-            err = e
-    parallel.barrier()
-    if err is not None:
-        raise err
+        except Exception as e:           # tell the waiting ranks, then fail here
+            try:
+                with open(marker, 'w') as fp:
+                    fp.write('%s: %s' % (type(e).__name__, e))
+            except OSError:
+                pass
+            raise
+    elif parallel.world_size() > 1:
+        limit = float(wait_s)
+        while not all(os.path.exists(q) for q in dataset_paths):
+            if os.path.exists(marker) and os.path.getmtime(marker) >= t_start - 1.0:
+                raise IOError('rank %d: rank 0 failed to build the datasets: %s' % (parallel.rank(), open(marker).read()))
+            if time.time() - t_start > limit:
+                raise IOError('rank %d: %s still missing after %.0f s' % (
+                    parallel.rank(), ', '.join(q for q in dataset_paths if not os.path.exists(q)), limit))
+            time.sleep(0.2)
     missing = [q for q in dataset_paths if not os.path.exists(q)]
     if missing:
-        raise IOError('rank %d: %s missing after rank 0 built the datasets' % (parallel.rank(), ', '.join(missing)))
+        raise IOError('rank %d: %s missing' % (parallel.rank(), ', '.join(missing)))
     return dataset_paths
 
 

@@ -38,6 +38,19 @@ def device_decisions(eng, N, weights=None):
     return dict(gates=gates, pool=pool)
 
 
+def assert_forcing_is_benign(Wt, nfb, x, masks, p_forced, p_dev=None, tol=1e-5, **oracle_kw):
+    """A forced-only comparison would copy a WRONG device decision (a bad training-path pool index, say) into the reference
+    and pass.  Run the oracle UN-forced too: forcing the device's decisions may move the probabilities only by what a
+    handful of fp32-vs-float64 near-ties can (< tol), and the device must also sit within 1e-4 of the un-forced ones."""
+    from oracle import unet_numpy as on
+    p_u = on.UNetOracle(Wt, nfb, **oracle_kw).forward(x, training=True, masks=masks)
+    d = float(np.abs(np.asarray(p_forced) - p_u).max())
+    assert d < tol, 'forcing the device decisions moved the oracle probabilities by %.3e' % d
+    if p_dev is not None:
+        assert float(np.abs(np.asarray(p_dev) - p_u).max()) < 1e-4
+    return d
+
+
 def flat_grads(G, ref):
     """Concatenate per-layer gradient lists in `ref`'s order, skipping the conv biases in front of BatchNorm (their
     gradient is analytically zero: both sides hold rounding noise there)."""

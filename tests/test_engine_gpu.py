@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import unet_numpy as on
-from _forced import device_decisions, grad_report, count_flips
+from _forced import assert_forcing_is_benign, device_decisions, grad_report, count_flips
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
@@ -48,7 +48,7 @@ def test_forward_inference_matches_oracle(N, H, W, nfb, mfma):
 
 
 @pytest.mark.parametrize('mfma', MODES)
-@pytest.mark.parametrize('N,H,W,nfb', [(1, 16, 16, 4), (2, 32, 32, 32), (2, 64, 64, 8)])
+@pytest.mark.parametrize('N,H,W,nfb', [(1, 16, 16, 4), (2, 32, 32, 32), (2, 64, 64, 8), (2, 64, 64, 32)])
 def test_train_forward_backward_matches_oracle(N, H, W, nfb, mfma):
     eng, Wt = make_engine(H, W, nfb, mfma=mfma)
     x, y = on.synthetic_batch(N, H, W)
@@ -132,6 +132,7 @@ def test_upsampling_branch_matches_oracle():
     G = eng.grads()
     loss_ref, p_ref, G_ref, _ = on.UNetOracle(Wt, nfb, upsampling=True, force=device_decisions(eng, N)).loss_and_grads(x, y, masks)
     assert np.abs(p - p_ref).max() < 1e-4 and abs(eng.read_sums()[0] / p.size - loss_ref) < 1e-4
+    assert_forcing_is_benign(Wt, nfb, x, masks, p_ref, p_dev=p, upsampling=True)
     worst, rel, _ = grad_report(G, G_ref, 'upsampling branch, forced gates: ')
     assert worst < GRAD_TOL and rel < GRAD_TOL, (worst, rel)
     # random-RNG dropout path runs and is reproducible in backward (same seed regenerates the masks)
@@ -154,6 +155,7 @@ def test_alternate_losses_match_oracle(loss):
     G = eng.grads()
     loss_ref, p_ref, G_ref, _ = on.UNetOracle(Wt, nfb, force=device_decisions(eng, N)).loss_and_grads(x, y, masks, loss=loss)
     assert abs(metrics_from_sums(eng.read_sums(), N * H * W, loss)['loss'] - loss_ref) < 1e-4
+    assert_forcing_is_benign(Wt, nfb, x, masks, p_ref)
     worst, rel, _ = grad_report(G, G_ref, '%s, forced gates: ' % loss)
     assert worst < GRAD_TOL and rel < GRAD_TOL, (worst, rel)
 

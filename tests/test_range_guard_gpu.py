@@ -227,7 +227,7 @@ def test_train_step_with_extreme_weights_matches_oracle(kscale, gscale, GRAD_REL
     Wt = _scaled_weights(nfb, kscale, gscale)
     x, y = on.synthetic_batch(N, H, W)
     masks = on.make_drop_masks(nfb, N, H, W)
-    from _forced import device_decisions, grad_report
+    from _forced import assert_forcing_is_benign, device_decisions, grad_report
     eng = UNetEngine((H, W), nb_filters_base=nfb)
     eng.set_weights(Wt)
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
@@ -241,6 +241,7 @@ def test_train_step_with_extreme_weights_matches_oracle(kscale, gscale, GRAD_REL
     if gscale > 1:
         assert max(float(eng.activation(n, N).abs().max()) for n in ('e0b', 'e1a', 'd1a')) > 65504      # really beyond fp16
     assert np.abs(p - p_ref).max() < 1e-4 and abs(loss - loss_ref) < 1e-4
+    assert_forcing_is_benign(Wt, nfb, x, masks, p_ref, p_dev=p)
     keep = lambda n, j: not (j == 1 and n != 'out')          # conv biases in front of BN: analytically zero gradient
     fg = np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(G[n]) if keep(n, j)]).astype(np.float64)
     fr = np.concatenate([g.ravel() for n in G_ref for j, g in enumerate(G_ref[n]) if keep(n, j)])
