@@ -209,6 +209,8 @@ class UNetEngine(object):
         _dz = os.environ.get('DC_DZIN', '1')
         self.dzin = self.mfma == 'f16x3' and _dz != '0'
         self.dzin_lvls = frozenset(range(5)) if _dz == 'all' else frozenset((0,))
+        # the joint data- + weight-gradient kernel for the 32 -> 32 blocks among them (DC_DZIN=2: dz on load, separate kernels)
+        self.joint = self.dzin and _dz != '2'
         self._head_bwd_done = False
         # fp16 range guard of the activation operands of the f16x3 contractions (csrc/common.h)
         self.range_guard = self.mfma == 'f16x3'
@@ -819,6 +821,9 @@ class UNetEngine(object):
         for lvl in range(4):
             h, w = self._hw(lvl)
             part_floats = max(part_floats, L.dc_maxpool2x2_bwd_blocks(N, h, w, nfb << lvl) * (nfb << lvl) * 2)
+        for l in self.layers:
+            if l.kind == 'conv':
+                part_floats = max(part_floats, L.dc_conv3x3_bwd_joint_blocks(N, *self._hw(l.lvl), l.cin, l.cout) * l.cin * 2)
         T['stats_ws'] = torch.empty(stats_floats, dtype=torch.float64, device=dev)      # (sum, sum of squares) partials
         T['part_ws'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['part_ws2'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
@@ -837,6 +842,10 @@ class UNetEngine(object):
         T['dz_coef'] = [torch.zeros(7 * cmax, dtype=torch.float32, device=dev) for _ in range(self.SLOTS)]   # dz-on-load tables
         T['red_tmp'] = torch.empty(32 * 1024, dtype=torch.float32, device=dev)
         T['wgrad_ws'] = torch.empty(ws_floats, dtype=torch.float32, device=dev)
+        # the joint data- + weight-gradient kernel of the 32 -> 32 blocks runs on the MAIN stream: its own slab workspace
+        # (the side stream's weight gradients share wgrad_ws)
+        jws = max([L.dc_conv3x3_bwd_joint_ws_floats(N, *self._hw(l.lvl), l.cin, l.cout) for l in self.layers if l.kind == 'conv'] + [4])
+        T['joint_ws'] = torch.empty(jws, dtype=torch.float32, device=dev)
         T['sums'] = torch.zeros(12, dtype=torch.float64, device=dev)
         T['bn_sums'] = torch.zeros(2 * max(l.cout for l in self.layers if l.kind != 'head'), dtype=torch.float64, device=dev)
         T['bn_gsum'] = torch.zeros(2 * max(l.cout for l in self.layers if l.kind != 'head'), dtype=torch.float32, device=dev)
@@ -1140,6 +1149,21 @@ class UNetEngine(object):
                     L.dc_bn_bwd_finalize_dzin(fused[0], fused[1], fused[2], l.cout, mean, invstd, gamma, beta, count,
                                               dgamma, dbeta, coef, self.pview(self.gflat, l, 'b'), st)
                 fused_next = None
+                xa = (bsrc[0], bsrc[1][0], bsrc[1][1]) if bsrc is not None else (x_in, None, None)
+                jrows = L.dc_conv3x3_bwd_joint_blocks(N, h, w, l.cin, l.cout) if (dx_ptr is not None and self.joint) else 0
+                if jrows > 0:
+                    # ---- 32 -> 32 block at a 512^2-class resolution: data AND weight gradient from one kernel, every tensor
+                    # of the block read once (csrc/bwd_joint.hip); main stream, nothing left for the side stream
+                    rargs = (None,) * 7
+                    if red is not None:
+                        rargs = (_ptr(T['z_' + red.name]), self.stat_ptr(red, 0), self.stat_ptr(red, 1),
+                                 self.pview(self.pflat, red, 'gamma'), self.pview(self.pflat, red, 'beta'),
+                                 _ptr(T['part_ws']), _ptr(T['amax_ws']))
+                        fused_next = (_ptr(T['part_ws']), _ptr(T['amax_ws']), jrows)
+                    L.dc_conv3x3_bwd_joint_f16x3(xa[0], xa[1], xa[2], self._ab_in(l), da_ptr, _ptr(z), coef,
+                                                 _ptr(self.wp_dgrad[l.name]), dx_ptr, *rargs, dk, _ptr(T['joint_ws']),
+                                                 N, h, w, l.cin, l.cout, st)
+                    return fused_next
                 if dx_ptr is not None:
                     rargs = (None,) * 7
                     if red is not None:
@@ -1155,7 +1179,6 @@ class UNetEngine(object):
                     ready.record(main)
                     side.wait_event(ready)
                 sw = side.cuda_stream
-                xa = (bsrc[0], bsrc[1][0], bsrc[1][1]) if bsrc is not None else (x_in, None, None)
                 L.dc_conv3x3_wgrad_dzin_f16x3(xa[0], xa[1], xa[2], self._ab_in(l), da_ptr, _ptr(z), coef, dk, ws,
                                               N, h, w, l.cin, l.cout, sw)
                 if two:

@@ -281,6 +281,21 @@ int dc_conv3x3_wgrad_dzin_f16x3(const float* x, const float* in_scale, const flo
                                 const float* da, const float* z, const float* dz_coef, float* dw, float* ws,
                                 int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 
+/* Joint backward of a 32 -> 32 conv block at a 512^2-class resolution (the HBM-bound blocks e0b / d0b of the network): ONE
+ * kernel stages dz (formed on load, as above) and the block input x once per tile and produces dx, dW and -- red_z != NULL --
+ * the pass-1 sums / max |dy| of the layer in front: every tensor of the block is read once (4 tensor passes instead of 7).
+ * Arguments as dc_conv3x3_dgrad_dzin_f16x3 + dc_conv3x3_wgrad_dzin_f16x3 (wp16 = the data-gradient form of the kernel).
+ * dc_conv3x3_bwd_joint_blocks() = rows of bn_partial / amax_partial (0: shape not served -- needs Cin == Cout == 32,
+ * W >= 32: use the two separate kernels); ws: float[dc_conv3x3_bwd_joint_ws_floats()] (one dW slab per workgroup, reduced
+ * in a fixed order => bit-reproducible). */
+int dc_conv3x3_bwd_joint_blocks(int N, int H, int W, int Cin, int Cout);
+long dc_conv3x3_bwd_joint_ws_floats(int N, int H, int W, int Cin, int Cout);
+int dc_conv3x3_bwd_joint_f16x3(const float* x, const float* in_scale, const float* in_shift, const float* x_abound,
+                               const float* da, const float* z, const float* dz_coef, const void* wp16, float* dx,
+                               const float* red_z, const float* red_mean, const float* red_invstd, const float* red_gamma,
+                               const float* red_beta, float* bn_partial, float* amax_partial, float* dw, float* ws,
+                               int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+
 /* ---- synchronised BatchNorm for batch-sharded data parallelism ('sync' mode) ---------------------
  * The per-channel sums leave the device between two launches so the host can all-reduce them over the ranks:
  *   forward : dc_bn_stats_reduce (conv partials -> double sums[C][2]) | all-reduce(sum) | dc_bn_stats_finalize_sums with

@@ -263,3 +263,64 @@ def test_dzin_fp16_range(dclib, case):
         tol = 1e-4 if case == 'mean50' else 2e-5
         assert np.abs(gx - dx_ref).max() < tol * np.abs(dx_ref).max()
         assert np.abs(gw - dK_ref).max() < tol * np.abs(dK_ref).max()
+
+
+@pytest.mark.parametrize('N,H,W', [(2, 64, 64), (1, 40, 72), (3, 33, 50), (1, 128, 96), (16, 32, 32)])
+@pytest.mark.parametrize('bnin', [True, False])
+def test_conv3x3_bwd_joint(dclib, N, H, W, bnin):
+    """dc_conv3x3_bwd_joint_f16x3 (Cin = Cout = 32): dx, dW and the pass-1 sums of the layer in front from ONE kernel, against
+    the float64 oracle on the float64 dz -- interior and ragged tiles (H % 4, W % 32), more tiles than workgroups and fewer,
+    x materialised / BN + ReLU on load; bit-reproducible run to run."""
+    L = dclib
+    Cin = Cout = 32
+    rows = L.dc_conv3x3_bwd_joint_blocks(N, H, W, Cin, Cout)
+    assert rows > 0 and rows % 2 == 0
+    assert L.dc_conv3x3_bwd_joint_blocks(N, H, W, 64, 32) == 0 and L.dc_conv3x3_bwd_joint_blocks(N, H, 16, 32, 32) == 0
+    rs = np.random.RandomState(H * 7 + W)
+    x, z, mean, invstd, gamma, beta, da = _block_case(rs, N, H, W, Cin, Cout)
+    K = (rs.standard_normal((3, 3, Cin, Cout)) * 0.05).astype(np.float32)
+    dz_ref, _, _, _ = _dz_ref(z, mean, invstd, gamma, beta, da)
+    # the layer in front: x is ITS pre-BN tensor when bnin (the sums are about that layer), a materialised activation otherwise
+    rmu = (rs.standard_normal(Cin) * 0.2).astype(np.float32); ris = (rs.random_sample(Cin) + 0.5).astype(np.float32)
+    rga = (rs.standard_normal(Cin) * 0.5 + 1.0).astype(np.float32); rbe = (rs.standard_normal(Cin) * 0.3).astype(np.float32)
+    xsc = (rga * ris).astype(np.float32)
+    xsh = (rbe.astype(np.float64) - rmu.astype(np.float64) * xsc.astype(np.float64)).astype(np.float32)
+    x_eff = np.maximum(x.astype(np.float64) * xsc.astype(np.float64) + xsh.astype(np.float64), 0.0) if bnin else x.astype(np.float64)
+    dx_ref, dK_ref, _ = on.conv3x3_bwd(x_eff, K.astype(np.float64), dz_ref)
+    zd, dad, coef, _, _, _ = _finalize(L, z, mean, invstd, gamma, beta, da)
+    Kd, xd = dev(K), dev(x)
+    wpd = torch.empty(L.dc_pack_weights_f16x3_floats(9, Cout, Cin), device='cuda')
+    L.dc_pack_weights_f16x3(Kd.data_ptr(), wpd.data_ptr(), 9, Cout, Cin, Cin * Cout, 1, Cout, 1, None)
+    ws = torch.empty(L.dc_conv3x3_bwd_joint_ws_floats(N, H, W, Cin, Cout), device='cuda')
+    rmud, risd, rgad, rbed, xscd, xshd = dev(rmu), dev(ris), dev(rga), dev(rbe), dev(xsc), dev(xsh)
+
+    def run():
+        dx = torch.full((N, H, W, Cin), float('nan'), device='cuda')
+        dw = torch.full((3, 3, Cin, Cout), float('nan'), device='cuda')
+        part = torch.full((rows * Cin * 2,), float('nan'), device='cuda')
+        amx = torch.full((rows * Cin,), float('nan'), device='cuda')
+        L.dc_conv3x3_bwd_joint_f16x3(xd.data_ptr(), xscd.data_ptr() if bnin else None, xshd.data_ptr() if bnin else None, None,
+                                     dad.data_ptr(), zd.data_ptr(), coef.data_ptr(), wpd.data_ptr(), dx.data_ptr(),
+                                     xd.data_ptr(), rmud.data_ptr(), risd.data_ptr(), rgad.data_ptr(), rbed.data_ptr(),
+                                     part.data_ptr(), amx.data_ptr(), dw.data_ptr(), ws.data_ptr(), N, H, W, Cin, Cout, None)
+        torch.cuda.synchronize()
+        return dx, dw, part, amx
+
+    dx, dw, part, amx = run()
+    gx, gw = dx.cpu().numpy(), dw.cpu().numpy()
+    assert np.isfinite(gx).all() and np.isfinite(gw).all()
+    assert np.abs(gx - dx_ref).max() < 2e-5 * np.abs(dx_ref).max(), np.abs(gx - dx_ref).max() / np.abs(dx_ref).max()
+    assert np.abs(gw - dK_ref).max() < 2e-5 * np.abs(dK_ref).max(), np.abs(gw - dK_ref).max() / np.abs(dK_ref).max()
+    dx2, dw2, part2, amx2 = run()
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(part, part2) and torch.equal(amx, amx2)
+    # pass-1 sums of the layer in front (pre-BN tensor x, statistics rmu / ris, affine rga / rbe) from the dx it wrote
+    dg, db = torch.zeros(Cin, device='cuda'), torch.zeros(Cin, device='cuda')
+    L.dc_bn_bwd_finalize(part.data_ptr(), rows, Cin, dg.data_ptr(), db.data_ptr(), None)
+    torch.cuda.synchronize()
+    za = x.astype(np.float64).reshape(-1, Cin)
+    gate = (za * xsc.astype(np.float64) + xsh.astype(np.float64)) > 0
+    dy = np.where(gate, gx.astype(np.float64).reshape(-1, Cin), 0.0)
+    ref_db, ref_dg = dy.sum(0), (dy * (za - rmu.astype(np.float64)) * ris.astype(np.float64)).sum(0)
+    tol = 2e-5 * max(np.abs(ref_dg).max(), np.abs(ref_db).max())
+    assert np.abs(dg.cpu().numpy() - ref_dg).max() < tol and np.abs(db.cpu().numpy() - ref_db).max() < tol
+    assert np.array_equal(amx.cpu().numpy().reshape(rows, Cin).max(0), np.abs(dy).max(0).astype(np.float32))
