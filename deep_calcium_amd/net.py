@@ -209,6 +209,7 @@ class UNetEngine(object):
         _dz = os.environ.get('DC_DZIN', '1')
         self.dzin = self.mfma == 'f16x3' and _dz != '0'
         self.dzin_lvls = frozenset(range(5)) if _dz == 'all' else frozenset((0,))
+        self.dzin_all = _dz == 'all'
         # the joint data- + weight-gradient kernel for the 32 -> 32 blocks among them (DC_DZIN=2: dz on load, separate kernels)
         self.joint = self.dzin and _dz != '2'
         self._head_bwd_done = False
@@ -1023,9 +1024,13 @@ class UNetEngine(object):
         """Does block l run without the BatchNorm-backward apply pass (dz formed on load by its gradient kernels)?"""
         if not self.dzin or l.kind != 'conv' or l.drop > 0.0 or l.lvl not in self.dzin_lvls:
             return False
+        h, w = self._hw(l.lvl)
+        if not self.dzin_all and N * h * w <= (1 << 20):
+            # small steps (the reference's own 96^2 / 128^2 training windows) are launch-latency bound, not HBM-bound: the
+            # apply pass costs ~15 us there while the persistent dz-on-load kernels pay their set-up (same-box 3.29 vs 3.92 ms)
+            return False
         if l.cin == 1:
             return True
-        h, w = self._hw(l.lvl)
         return self.L.dc_conv3x3_dgrad_dzin_blocks(N, h, w, l.cin, l.cout) > 0
 
     @_on_device
