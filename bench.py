@@ -81,15 +81,16 @@ class KernelTimer(object):
     # dc_conv3x3_dgrad* whenever W > 16 and the output has > 32 columns: the persistent role-split kernel of
     # csrc/igemm_pp.hip (Cin a multiple of 16, >= 64; the 256-thread igemm_f16x3_kernel<3,3,1,1,32,4,2,2,16> serves the one
     # Cin = 32 training-forward launch of that shape; the data gradients that also emit BatchNorm-backward sums run its
-    # <2,2,1> instantiation through dc_conv3x3_dgrad_bnred_f16x3 and are not counted here), csrc/igemm_conv.hip for
-    # mfma='f32'.
+    # <2,2,1,*> instantiation through dc_conv3x3_dgrad_bnred_f16x3, the dz-on-load data gradient of d0a its <2,2,0,true>
+    # one through dc_conv3x3_dgrad_dzin_f16x3: other symbols, not counted here), csrc/igemm_conv.hip for mfma='f32'.
+    # Per train step at batch 16 of 512^2: 19 launches (14 forward convolutions + 5 data gradients), 4.6 ms of 18.2.
     KERNELS = {
-        'f16x3': ('igemm_pp_kernel<2,2,0>', PEAK_FP16_MFMA_TFLOPS, 3),
+        'f16x3': ('igemm_pp_kernel<2,2,0,false>', PEAK_FP16_MFMA_TFLOPS, 3),
         'f32': ('igemm_kernel<3,3,1,1,32,4,2,2,16>', PEAK_FP32_MFMA_TFLOPS, 1),
     }
     # entry point -> (GEMM column count is Cout / Cin, is a data gradient, index of the `stats` argument | None); every
     # one ends with N, H, W, Cin, Cout, stream.  A launch is counted only if the library's own routing query says it runs the
-    # named symbol (f16x3: dc_conv3x3_pp_blocks() > 0 and > 32 columns = igemm_pp_kernel<2,2,0>).
+    # named symbol (f16x3: dc_conv3x3_pp_blocks() > 0 and > 32 columns = igemm_pp_kernel<2,2,0,false>).
     SITES = {'dc_conv3x3_fwd': ('cout', 0, 5), 'dc_conv3x3_dgrad': ('cin', 1, None), 'dc_conv3x3_fwd_f16x3': ('cout', 0, 5),
              'dc_conv3x3_dgrad_f16x3': ('cin', 1, None), 'dc_conv3x3_fwd_bnin_f16x3': ('cout', 0, 8)}
 

@@ -479,6 +479,9 @@ static int conv3x3_h_launch(IgemmParams p, hipStream_t st) {
 static int convT_fwd_h_launch(IgemmParams p, hipStream_t st) {
   if (p.Wout > 16) {
     if (p.Ncols <= 32) return igemm_h_launch<1, 1, 1, 0, 32, 4, 4, 1, 32>(p, st, "convT2x2_fwd_f16x3");
+#ifdef DC_CONVT_CK64
+    if (p.Cin % 64 == 0) return igemm_h_launch<1, 1, 1, 0, 32, 4, 2, 2, 64>(p, st, "convT2x2_fwd_f16x3");
+#endif
     return igemm_h_launch<1, 1, 1, 0, 32, 4, 2, 2, 32>(p, st, "convT2x2_fwd_f16x3");
   }
   if (p.Wout > 8) return igemm_h_launch<1, 1, 1, 0, 16, 4, 2, 2, 32>(p, st, "convT2x2_fwd_f16x3");

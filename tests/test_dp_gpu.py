@@ -194,7 +194,7 @@ def test_bench_default_line_schema():
     assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and rf['peak'] == 2500.0
     assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3 and 0.05 < rf['frac'] < 0.25
     assert rf['traffic'] is None or rf['traffic'] > 1e8
-    # 2 instrumented steps x the 19 launches per step that dispatch igemm_pp_kernel<2,2,0> (14 forward convolutions with > 32
+    # 2 instrumented steps x the 19 launches per step that dispatch igemm_pp_kernel<2,2,0,false> (14 forward convolutions with > 32
     # output columns and >= 64 input channels + the 5 data gradients of d1a..d3a, e2a..ba / the Dropout blocks that do not
     # emit BatchNorm sums; d0a's data gradient forms dz on load: the <2,2,0,true> instantiation)
     assert rf['launches'] == 2 * 19, rf
