@@ -479,13 +479,25 @@ static int conv3x3_h_launch(IgemmParams p, hipStream_t st) {
 static int convT_fwd_h_launch(IgemmParams p, hipStream_t st) {
   if (p.Wout > 16) {
     if (p.Ncols <= 32) return igemm_h_launch<1, 1, 1, 0, 32, 4, 4, 1, 32>(p, st, "convT2x2_fwd_f16x3");
-#ifdef DC_CONVT_CK64
-    if (p.Cin % 64 == 0) return igemm_h_launch<1, 1, 1, 0, 32, 4, 2, 2, 64>(p, st, "convT2x2_fwd_f16x3");
-#endif
+    // With ONE tap a staged input tile feeds only 24 MFMAs per wave and chunk: wider column blocks (all four waves side by side on
+    // 2 x 32 pixels x 256 columns, or 2 x 2 on 4 x 32 x 128) split a quarter / half of the input elements per MFMA -- the staging
+    // VALU, not the matrix pipe, bounds these launches.  Measured (scripts/one_convT.py, u0..u3): 200 / 143 / 97 / 82 -> 179 / 123 /
+    // 82 / 72 us.  dc_convT2x2_f16x3_tiles() reports the resulting BatchNorm-partial row count.
+    if (p.Ncols % 256 == 0) return igemm_h_launch<1, 1, 1, 0, 32, 1, 2, 2, 32>(p, st, "convT2x2_fwd_f16x3");
+    if (p.Ncols % 128 == 0) return igemm_h_launch<1, 1, 1, 0, 32, 2, 2, 2, 32>(p, st, "convT2x2_fwd_f16x3");
     return igemm_h_launch<1, 1, 1, 0, 32, 4, 2, 2, 32>(p, st, "convT2x2_fwd_f16x3");
   }
   if (p.Wout > 8) return igemm_h_launch<1, 1, 1, 0, 16, 4, 2, 2, 32>(p, st, "convT2x2_fwd_f16x3");
   return igemm_h_launch<1, 1, 1, 0, 8, 2, 1, 2, 32>(p, st, "convT2x2_fwd_f16x3");
+}
+extern "C" int dc_convT2x2_f16x3_tiles(int N, int H, int W, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  const int Ncols = 4 * Cout;
+  int tw, th;                                       // the tile shapes of convT_fwd_h_launch above
+  if (W > 16) { tw = 32; th = Ncols <= 32 ? 16 : (Ncols % 256 == 0 ? 2 : (Ncols % 128 == 0 ? 4 : 8)); }
+  else if (W > 8) { tw = 16; th = 16; }
+  else { tw = 8; th = 8; }
+  return N * dc_cdiv(W, tw) * dc_cdiv(H, th);
 }
 // Conv2DTranspose dgrad: 2x2 taps over the stride-2 gradient image (no BN partials => free choice of tile).
 static int convT_dgrad_h_launch(IgemmParams p, hipStream_t st) {

@@ -808,7 +808,7 @@ class UNetEngine(object):
                 stats_floats = max(stats_floats, tiles * l.cout * 2)
                 ws_floats = max(ws_floats, L.dc_conv3x3_wgrad_ws_floats(N, h, w, l.cin, l.cout))
             else:
-                tiles = L.dc_convT2x2_tiles(N, h // 2, w // 2, l.cout)
+                tiles = (L.dc_convT2x2_f16x3_tiles if self.mfma == 'f16x3' else L.dc_convT2x2_tiles)(N, h // 2, w // 2, l.cout)
                 stats_floats = max(stats_floats, tiles * 4 * l.cout * 2)
                 ws_floats = max(ws_floats, L.dc_convT2x2_wgrad_ws_floats(N, h // 2, w // 2, l.cin, l.cout))
             blocks = L.dc_bn_bwd_blocks(N * h * w, l.cout)
@@ -941,7 +941,7 @@ class UNetEngine(object):
                 tiles = L.dc_conv3x3_tiles(N, h, w, l.cout)
                 self._conv_fwd(xin, l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h, w, st, bnin=bn)
             else:
-                tiles = L.dc_convT2x2_tiles(N, h // 2, w // 2, l.cout)
+                tiles = (L.dc_convT2x2_f16x3_tiles if self.mfma == 'f16x3' else L.dc_convT2x2_tiles)(N, h // 2, w // 2, l.cout)
                 groups = 4
                 self._convT_fwd(xin, l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h // 2, w // 2, st, bnin=bn)
             pixels = N * h * w

@@ -113,6 +113,10 @@ int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const float* bias, f
 int dc_convT2x2_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* dz_scale,
                             const float* dz_absmax, int dz_absmax_n,
                             int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+/* BatchNorm-partial rows (`tiles`) of the split-fp16 conv-transpose forward: it runs wider column blocks than the fp32 kernel
+ * (256 / 128 columns per workgroup: each staged input tile feeds 4x / 2x the MFMAs) on correspondingly flatter pixel tiles,
+ * so its stats buffer is double[dc_convT2x2_f16x3_tiles()][4*Cout][2] -- NOT dc_convT2x2_tiles(), which sizes dc_convT2x2_fwd's. */
+int dc_convT2x2_f16x3_tiles(int N, int H, int W, int Cout);
 /* weight gradients: same workspace (dc_*_wgrad_ws_floats) and fixed-order slab reduction as the fp32 entry points;
  * dz_scale = device scalar from dc_pow2_scale_from_absmax (nullable). */
 int dc_conv3x3_wgrad_f16x3(const float* x, const float* dz, float* dw, float* ws, const float* dz_scale,
