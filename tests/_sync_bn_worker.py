@@ -17,7 +17,7 @@ from _forced import device_decisions, grad_report          # noqa: E402
 def main():
     out_path = sys.argv[1]
     rank, world = parallel.init_from_env()
-    NG, H, W, nfb = 2 * world, 32, 32, 8
+    NG, H, W, nfb = 2 * world, 32, 32, int(os.environ.get('DC_TEST_NFB', '8'))     # nfb 32: the role-split / dz-on-load / joint kernels engage
     Wt = on.init_weights(nfb, seed=99, randomize_bn=True)
     x, y = on.synthetic_batch(NG, H, W)
     masks = on.make_drop_masks(nfb, NG, H, W)
