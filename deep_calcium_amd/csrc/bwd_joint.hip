@@ -437,6 +437,316 @@ __global__ __launch_bounds__(bj::THREADS, 1) void bwd_joint32_kernel(JointParams
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The 64 -> 32 block of the same resolution (d0a: x = the 64-channel concat buffer, materialised; dx = its gradient, which
+// feeds a Dropout block and the max-pool backward: no fused sums).  Same tiles, same dz image; differences:
+//   * the x image has 128-byte pixel rows (64 channels: 8 chunks, XOR-swizzled with bit 1 of the pixel index: the
+//     transposing reads of 4 consecutive pixels then cover all 64 banks); two stages of (dz + x) fill the LDS (156 KB), so
+//   * the data-gradient weights (74 KB) are NOT LDS-resident: the 72 fragments a tile needs are read from global memory
+//     (L2-resident, the same for every workgroup), three (tap, k-step) groups ahead of the MFMAs that use them;
+//   * data gradient: waves 0-1, two rows each x 64 cin columns (2 x 2 blocks: the weight fragments are shared by two row
+//     blocks, the dz fragments by two column blocks); weight gradient: wave 2 + ww owns the 32 input channels [32 ww, 32 ww + 32)
+//     for ALL four rows and all 9 taps (144 accumulators): no cross-wave reduction, each writes its half of the slab.
+// Per tile and consumer wave 216 MFMAs; fragment reads 464 KB per tile = 52 % of the LDS bandwidth at full MFMA rate.
+namespace bj64 {
+using namespace bj;
+constexpr int CX = 64;                         // x / dx channels
+constexpr int XPLANE = 26624;                  // NPIX * 128 bytes rounded up to a multiple of 1024
+constexpr int XIMG = 2 * XPLANE;
+constexpr int STAGE64 = IMG + XIMG;            // dz image | x image
+constexpr int LDS64 = 2 * STAGE64 + 64;
+constexpr int NLX = (NPIX * 16 + 255) / 256;   // float4 loads of x per producer thread (13)
+static_assert(LDS64 <= 160 * 1024 && NPIX * 128 <= XPLANE && XPLANE % 1024 == 0 && IMG % 1024 == 0, "LDS plan");
+__device__ __forceinline__ int swzx(int rel) { return rel ^ ((rel >> 2) & 0x40); }     // chunk ^= 4 * bit 1 of the pixel
+}  // namespace bj64
+
+__global__ __launch_bounds__(bj::THREADS, 1) void bwd_joint64_kernel(JointParams p) {
+  using namespace bj64;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  float* tmp = reinterpret_cast<float*>(smem + 2 * STAGE64);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float x_scale = dc_block_guard_scale(p.xAbound, CX, tmp);
+  const float dz_scale = dc_block_guard_scale(p.dzCoef + 6 * C, C, tmp);
+  constexpr int W_SLOTS64 = 9 * 4 * 2 * CX;     // [tap][k8][hi|lo][64 cols]
+  const float w_scale = p.wp[W_SLOTS64 * 4];
+
+  const int total = p.N * p.tilesX * p.tilesY;
+  const int G = (int)gridDim.x, xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int nx = (G + 7 - xcd) >> 3;
+  const int qq = total >> 3, rr = total & 7;
+  const int xstart = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq;
+  const int xcount = qq + (xcd < rr ? 1 : 0);
+  const int nt = seq < xcount ? (xcount - seq + nx - 1) / nx : 0;
+  struct Tile { int img, y0, x0; };
+  auto decode = [&](int j) __attribute__((always_inline)) {
+    const int work = xstart + seq + j * nx;
+    const int ty = work % p.tilesY, t2 = work / p.tilesY;
+    Tile t;
+    t.x0 = (t2 % p.tilesX) * TW; t.img = t2 / p.tilesX; t.y0 = ty * TH;
+    return t;
+  };
+  const long dz_img = (long)p.H * p.W * C, x_img = (long)p.H * p.W * CX;
+
+  if (wave >= 4) {
+    // ============================ producers ===========================================================================
+    const int t = tid & 255;
+    const int q = t & 7, pb = t >> 3;               // dz: channel quad (8), first pixel (32 pixels per pass)
+    const int qx = t & 15, pbx = t >> 4;            // x: channel quad (16), first pixel (16 pixels per pass)
+    const float* ct = p.dzCoef + 4 * q;
+    const f32x4 g_sc = *reinterpret_cast<const f32x4*>(ct), g_sh = *reinterpret_cast<const f32x4*>(ct + C),
+                d_mu = *reinterpret_cast<const f32x4*>(ct + 2 * C), d_A = *reinterpret_cast<const f32x4*>(ct + 3 * C),
+                d_D = *reinterpret_cast<const f32x4*>(ct + 4 * C), d_E = *reinterpret_cast<const f32x4*>(ct + 5 * C);
+    auto pix_ok = [&](const Tile& tl, int pix, int& y, int& xx) {
+      const int r = __umul24(pix, (65536 + TWI - 1) / TWI) >> 16;
+      const int c = pix - __umul24(r, TWI);
+      y = tl.y0 - 1 + r; xx = tl.x0 - 1 + c;
+      return pix < NPIX && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+    };
+    auto request_x = [&](int j, f32x4 (&rx)[NLX]) {
+      const Tile tl = decode(j);
+      const __amdgpu_buffer_rsrc_t rsX = dc_make_rsrc(p.x + tl.img * x_img, (unsigned)(x_img * 4));
+#pragma unroll
+      for (int k = 0; k < NLX; ++k) {
+        int y, xx;
+        const bool ok = pix_ok(tl, pbx + 16 * k, y, xx);
+        const unsigned off = ok ? (unsigned)(((y * p.W + xx) * CX + 4 * qx) * 4) : OOB;
+        rx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0));      // zeros outside the image
+      }
+    };
+    auto request_dz = [&](int j, f32x4 (&ra)[NL], f32x4 (&rz)[NL], unsigned& live) {
+      live = 0u;
+      const Tile tl = decode(j);
+      const __amdgpu_buffer_rsrc_t rsA = dc_make_rsrc(p.da + tl.img * dz_img, (unsigned)(dz_img * 4));
+      const __amdgpu_buffer_rsrc_t rsZ = dc_make_rsrc(p.z + tl.img * dz_img, (unsigned)(dz_img * 4));
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        int y, xx;
+        const bool ok = pix_ok(tl, pb + 32 * k, y, xx);
+        const unsigned off = ok ? (unsigned)(((y * p.W + xx) * C + 4 * q) * 4) : OOB;
+        ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
+        rz[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, off, 0, 0));
+        if (ok) live |= 1u << k;
+      }
+    };
+    auto stage_x = [&](const f32x4 (&rx)[NLX], char* set) {
+#pragma unroll
+      for (int k = 0; k < NLX; ++k) {
+        const int pix = pbx + 16 * k;
+        u32x2 xh, xl;
+        split4(rx[k], x_scale, xh, xl);
+        if (pix < NPIX) {
+          const int off = swzx(pix * 128 + qx * 8);
+          *reinterpret_cast<u32x2*>(set + IMG + off) = xh;
+          *reinterpret_cast<u32x2*>(set + IMG + XPLANE + off) = xl;
+        }
+      }
+    };
+    auto stage_dz = [&](const f32x4 (&ra)[NL], const f32x4 (&rz)[NL], unsigned live, char* set) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int pix = pb + 32 * k;
+        const bool lv = (live >> k) & 1u;
+        f32x4 dzv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float zz = rz[k][e];
+          const float y = __builtin_fmaf(zz, g_sc[e], g_sh[e]);
+          const float dy = y > 0.f ? ra[k][e] : 0.f;
+          const float v = __builtin_fmaf(d_A[e], dy, __builtin_fmaf(d_D[e], zz - d_mu[e], d_E[e]));
+          dzv[e] = lv ? v : 0.f;
+        }
+        u32x2 dh, dl;
+        split4(dzv, dz_scale, dh, dl);
+        if (pix < NPIX) {
+          const int off = swz(pix * 64 + q * 8);
+          *reinterpret_cast<u32x2*>(set + off) = dh;
+          *reinterpret_cast<u32x2*>(set + PLANE + off) = dl;
+        }
+      }
+    };
+    f32x4 rx0[NLX], rx1[NLX], ra[NL], rz[NL];
+    unsigned lv = 0u;
+    if (nt > 0) {
+      request_x(0, rx0);
+      request_dz(0, ra, rz, lv);
+      if (nt > 1) request_x(1, rx1);
+      stage_x(rx0, smem);
+      stage_dz(ra, rz, lv, smem);
+      if (nt > 1) request_dz(1, ra, rz, lv);
+    }
+    __syncthreads();
+    for (int i = 0; i < nt; i += 2) {
+      if (i + 2 < nt) request_x(i + 2, rx0);
+      if (i + 1 < nt) { stage_x(rx1, smem + STAGE64); stage_dz(ra, rz, lv, smem + STAGE64); }
+      if (i + 2 < nt) request_dz(i + 2, ra, rz, lv);
+      __syncthreads();
+      if (i + 1 < nt) {
+        if (i + 3 < nt) request_x(i + 3, rx1);
+        if (i + 2 < nt) { stage_x(rx0, smem); stage_dz(ra, rz, lv, smem); }
+        if (i + 3 < nt) request_dz(i + 3, ra, rz, lv);
+        __syncthreads();
+      }
+    }
+    return;
+  }
+
+  const int li = lane & 31, h = lane >> 5;
+  if (wave < 2) {
+    // ================================ data gradient: 2 rows x 32 px x 64 cin per tile ==================================
+    const int wd = wave;
+    const float out_scale = 1.f / (dz_scale * w_scale);
+    int a_rel[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) a_rel[mb] = ((2 * wd + mb) * TWI + li) * 64 + h * 16;
+    const __amdgpu_buffer_rsrc_t rsW = dc_make_rsrc(p.wp, (unsigned)W_SLOTS64 * 16u);
+    const unsigned w_rel = (unsigned)((h * 2 * CX + li) * 16);      // slot ((tap*4 + ks*2 + h)*2 + hl)*64 + nb*32 + li
+    __syncthreads();
+    for (int i = 0; i < nt; ++i) {
+      const char* cur = smem + (i & 1) * STAGE64;
+      int ar0 = a_rel[0], ar1 = a_rel[1];
+      asm volatile("" : "+v"(ar0), "+v"(ar1));
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+      __builtin_amdgcn_s_setprio(2);
+      {
+        constexpr int NG = 18, AHEAD = 3;                          // weight fragments: global (L2) loads AHEAD groups ahead
+        u32x4 wf[AHEAD + 1][2][2];                                 // [ring][nb][hi|lo]
+        f16x8 ah[2][2], al[2][2];
+        auto fetch_w = [&](int g, int slot) __attribute__((always_inline)) {
+          const int tap = g >> 1, ks = g & 1;
+          const int soff = ((tap * 4 + ks * 2) * 2) * CX * 16;
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            wf[slot][nb][0] = __builtin_amdgcn_raw_buffer_load_b128(rsW, w_rel + nb * 512, soff, 0);
+            wf[slot][nb][1] = __builtin_amdgcn_raw_buffer_load_b128(rsW, w_rel + nb * 512, soff + CX * 16, 0);
+          }
+        };
+        auto fetch_a = [&](int g, int buf) __attribute__((always_inline)) {
+          const int tap = g >> 1, ks = g & 1;
+          const int toff = ((tap / 3) * TWI + (tap % 3)) * 64 + ks * 32;
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) {
+            const int ao = swz((mb ? ar1 : ar0) + toff);
+            ah[buf][mb] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(cur + ao));
+            al[buf][mb] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(cur + PLANE + ao));
+          }
+        };
+#pragma unroll
+        for (int g = 0; g < AHEAD; ++g) fetch_w(g, g);
+        fetch_a(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int b = g & 1, ws = g % (AHEAD + 1);
+          if (g + AHEAD < NG) fetch_w(g + AHEAD, (g + AHEAD) % (AHEAD + 1));
+          if (g + 1 < NG) fetch_a(g + 1, b ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+              const f16x8 bh = __builtin_bit_cast(f16x8, wf[ws][nb][0]), bl = __builtin_bit_cast(f16x8, wf[ws][nb][1]);
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b][mb], bh, acc[mb][nb], 0, 0, 0);
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b][mb], bl, acc[mb][nb], 0, 0, 0);
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b][mb], bh, acc[mb][nb], 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      const Tile tl = decode(i);
+      const __amdgpu_buffer_rsrc_t rsO = dc_make_rsrc(p.dx + tl.img * x_img, (unsigned)(x_img * 4));
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const int oy = tl.y0 + 2 * wd + mb, oxb = tl.x0 + 4 * h;
+        const bool row_ok = oy < p.H;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int colc = (r & 3) + 8 * (r >> 2);
+          const bool ok = row_ok && (oxb + colc) < p.W;
+          const unsigned off = ok ? (unsigned)(((oy * p.W + oxb + colc) * CX + li) * 4) : OOB;
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[mb][nb][r] * out_scale), rsO, off, nb * 128, 0);
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ============== weight gradient: wave 2 + ww = input channels [32 ww, 32 ww + 32), all four rows, all taps ==============
+  const int ww = wave - 2;
+  const int cb = (lane >> 4) & 1, c16 = lane & 15, q4 = c16 >> 2, pp = c16 & 3;
+  const int fragz = (cb * 2 + (pp >> 1)) * 16 + (pp & 1) * 8;                 // dz image: 4 chunks per pixel row
+  const int fragx = (ww * 4 + cb * 2 + (pp >> 1)) * 16 + (pp & 1) * 8;        // x image: 8 chunks, this wave's 32-channel half
+  const int lane_z = (8 * h + q4) * 64 + fragz, lane_x = (8 * h + q4) * 128 + fragx;
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  __syncthreads();
+  for (int i = 0; i < nt; ++i) {
+    const char* cur = smem + (i & 1) * STAGE64;
+    int lz = lane_z, lx = lane_x;
+    asm volatile("" : "+v"(lz), "+v"(lx));
+    __builtin_amdgcn_s_setprio(2);
+    {
+      constexpr int NG = 72;                                       // 8 k-steps (row, 16-pixel half) x 9 taps
+      f16x8 ah[2], al[2], bh[2], bl[2];
+      auto fetch_a = [&](int g, int buf) __attribute__((always_inline)) {
+        const int ks = g / 9, tap = g % 9;
+        const int r = ks >> 1, xs = ks & 1;
+        const int pbase = lx + ((r + tap / 3) * TWI + 16 * xs + tap % 3) * 128;
+        const int a0 = swzx(pbase), a1 = swzx(pbase + 4 * 128);
+        ah[buf] = tr_frag(cur + IMG, a0, a1);
+        al[buf] = tr_frag(cur + IMG + XPLANE, a0, a1);
+      };
+      auto fetch_b = [&](int ks, int buf) __attribute__((always_inline)) {
+        const int r = ks >> 1, xs = ks & 1;
+        const int brel = lz + ((r + 1) * TWI + 16 * xs + 1) * 64;
+        const int b0 = swz(brel), b1 = swz(brel + 4 * 64);
+        bh[buf] = tr_frag(cur, b0, b1);
+        bl[buf] = tr_frag(cur + PLANE, b0, b1);
+      };
+      fetch_b(0, 0);
+      fetch_a(0, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int ca = g & 1, ks = g / 9, tap = g % 9, cbuf = ks & 1;
+        if (g + 1 < NG) {
+          fetch_a(g + 1, ca ^ 1);
+          if ((g + 1) % 9 == 0) fetch_b(ks + 1, cbuf ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ca], bh[cbuf], acc[tap], 0, 0, 0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cbuf], acc[tap], 0, 0, 0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cbuf], acc[tap], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+  }
+  // slab [9][64][32] of this workgroup: rows m = input channel, columns n = dz channel (C/D: col = lane & 31, row = (r&3) + 8 (r>>2) + 4h)
+  const float ws_scale = 1.f / (x_scale * dz_scale);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    float* dst = p.slabs + ((long)blockIdx.x * 9 + tap) * CX * C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 32 * ww + (r & 3) + 8 * (r >> 2) + 4 * h;
+      dst[m * C + li] = acc[tap][r] * ws_scale;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 static int joint_grid(int N, int H, int W) {
   static int cus[64] = {};
   int dev = 0;
@@ -450,7 +760,7 @@ static int joint_grid(int N, int H, int W) {
   return (int)(total < cus[dev] ? total : cus[dev]);
 }
 static bool joint_serves(int N, int H, int W, int Cin, int Cout) {
-  return N > 0 && Cin == bj::C && Cout == bj::C && W >= 32 && H >= 4 && (long)H * W * bj::C * 4 < (1L << 31);
+  return N > 0 && (Cin == bj::C || Cin == bj64::CX) && Cout == bj::C && W >= 32 && H >= 4 && (long)H * W * Cin * 4 < (1L << 31);
 }
 
 // rows of bn_partial / amax_partial (2 per workgroup) when the joint kernel serves this shape, else 0
@@ -480,16 +790,25 @@ extern "C" int dc_conv3x3_bwd_joint_f16x3(const float* x, const float* in_sc, co
              "dc_conv3x3_bwd_joint_f16x3: shape not served (dc_conv3x3_bwd_joint_blocks() == 0): use the separate kernels");
   const int grid = joint_grid(N, H, W);
   DC_REQUIRE(grid > 0, DC_EHIP, "dc_conv3x3_bwd_joint_f16x3: no device");
-  static DcLdsAttr lds_attr;
-  if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(bwd_joint32_kernel), bj::LDS_BYTES, "conv3x3_bwd_joint_f16x3"))
-    return rc;
+  static DcLdsAttr lds_attr, lds_attr64;
+  if (Cin == bj::C) {
+    if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(bwd_joint32_kernel), bj::LDS_BYTES, "conv3x3_bwd_joint_f16x3"))
+      return rc;
+  } else {
+    DC_REQUIRE(!in_sc && !red_z, DC_EUNSUP, "dc_conv3x3_bwd_joint_f16x3: the 64 -> 32 kernel takes a materialised x and emits no sums");
+    if (int rc = dc_func_max_lds(lds_attr64, reinterpret_cast<const void*>(bwd_joint64_kernel), bj64::LDS64, "conv3x3_bwd_joint_f16x3"))
+      return rc;
+  }
   JointParams p;
   p.x = x; p.xSc = in_sc; p.xSh = in_sh; p.xAbound = x_abound; p.da = da; p.z = z; p.dzCoef = dz_coef;
   p.wp = reinterpret_cast<const float*>(wp16); p.dx = dx;
   p.redZ = red_z; p.redMean = red_mean; p.redInvstd = red_invstd; p.redGamma = red_gamma; p.redBeta = red_beta;
   p.bnPartial = bn_partial; p.bnAmax = amax_partial; p.slabs = ws;
   p.N = N; p.H = H; p.W = W; p.tilesX = dc_cdiv(W, bj::TW); p.tilesY = dc_cdiv(H, bj::TH);
-  hipLaunchKernelGGL(bwd_joint32_kernel, dim3((unsigned)grid), dim3(bj::THREADS), bj::LDS_BYTES, (hipStream_t)stream, p);
+  if (Cin == bj::C)
+    hipLaunchKernelGGL(bwd_joint32_kernel, dim3((unsigned)grid), dim3(bj::THREADS), bj::LDS_BYTES, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(bwd_joint64_kernel, dim3((unsigned)grid), dim3(bj::THREADS), bj64::LDS64, (hipStream_t)stream, p);
   DC_CHECK_LAUNCH("dc_conv3x3_bwd_joint_f16x3");
   const long L = 9L * Cin * Cout;
   return dc_reduce_partials(ws, grid, L, 1.0f, dw, ws + (long)grid * L, stream);

@@ -1156,6 +1156,8 @@ class UNetEngine(object):
                 fused_next = None
                 xa = (bsrc[0], bsrc[1][0], bsrc[1][1]) if bsrc is not None else (x_in, None, None)
                 jrows = L.dc_conv3x3_bwd_joint_blocks(N, h, w, l.cin, l.cout) if (dx_ptr is not None and self.joint) else 0
+                if jrows > 0 and l.cin != l.cout and (bsrc is not None or red is not None):
+                    jrows = 0          # the 64 -> 32 kernel takes a materialised input and emits no sums
                 if jrows > 0:
                     # ---- 32 -> 32 block at a 512^2-class resolution: data AND weight gradient from one kernel, every tensor
                     # of the block read once (csrc/bwd_joint.hip); main stream, nothing left for the side stream

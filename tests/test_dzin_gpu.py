@@ -275,7 +275,7 @@ def test_conv3x3_bwd_joint(dclib, N, H, W, bnin):
     Cin = Cout = 32
     rows = L.dc_conv3x3_bwd_joint_blocks(N, H, W, Cin, Cout)
     assert rows > 0 and rows % 2 == 0
-    assert L.dc_conv3x3_bwd_joint_blocks(N, H, W, 64, 32) == 0 and L.dc_conv3x3_bwd_joint_blocks(N, H, 16, 32, 32) == 0
+    assert L.dc_conv3x3_bwd_joint_blocks(N, H, W, 64, 64) == 0 and L.dc_conv3x3_bwd_joint_blocks(N, H, 16, 32, 32) == 0
     rs = np.random.RandomState(H * 7 + W)
     x, z, mean, invstd, gamma, beta, da = _block_case(rs, N, H, W, Cin, Cout)
     K = (rs.standard_normal((3, 3, Cin, Cout)) * 0.05).astype(np.float32)
@@ -324,3 +324,42 @@ def test_conv3x3_bwd_joint(dclib, N, H, W, bnin):
     tol = 2e-5 * max(np.abs(ref_dg).max(), np.abs(ref_db).max())
     assert np.abs(dg.cpu().numpy() - ref_dg).max() < tol and np.abs(db.cpu().numpy() - ref_db).max() < tol
     assert np.array_equal(amx.cpu().numpy().reshape(rows, Cin).max(0), np.abs(dy).max(0).astype(np.float32))
+
+
+@pytest.mark.parametrize('N,H,W', [(2, 64, 64), (1, 40, 72), (3, 33, 50), (16, 32, 32)])
+def test_conv3x3_bwd_joint_64_to_32(dclib, N, H, W):
+    """The 64 -> 32 variant (the first decoder convolution at full resolution: x = the concat buffer, materialised; no fused
+    sums): dx (64 channels) and dW (3,3,64,32) against the float64 oracle, ragged tiles, bit-reproducible."""
+    L = dclib
+    Cin, Cout = 64, 32
+    rows = L.dc_conv3x3_bwd_joint_blocks(N, H, W, Cin, Cout)
+    assert rows > 0
+    rs = np.random.RandomState(H * 3 + W)
+    x, z, mean, invstd, gamma, beta, da = _block_case(rs, N, H, W, Cin, Cout)
+    K = (rs.standard_normal((3, 3, Cin, Cout)) * 0.05).astype(np.float32)
+    dz_ref, _, _, _ = _dz_ref(z, mean, invstd, gamma, beta, da)
+    dx_ref, dK_ref, _ = on.conv3x3_bwd(x.astype(np.float64), K.astype(np.float64), dz_ref)
+    zd, dad, coef, _, _, _ = _finalize(L, z, mean, invstd, gamma, beta, da)
+    Kd, xd = dev(K), dev(x)
+    wpd = torch.empty(L.dc_pack_weights_f16x3_floats(9, Cout, Cin), device='cuda')
+    L.dc_pack_weights_f16x3(Kd.data_ptr(), wpd.data_ptr(), 9, Cout, Cin, Cin * Cout, 1, Cout, 1, None)
+    ws = torch.empty(L.dc_conv3x3_bwd_joint_ws_floats(N, H, W, Cin, Cout), device='cuda')
+
+    def run():
+        dx = torch.full((N, H, W, Cin), float('nan'), device='cuda')
+        dw = torch.full((3, 3, Cin, Cout), float('nan'), device='cuda')
+        L.dc_conv3x3_bwd_joint_f16x3(xd.data_ptr(), None, None, None, dad.data_ptr(), zd.data_ptr(), coef.data_ptr(), wpd.data_ptr(),
+                                     dx.data_ptr(), *((None,) * 7), dw.data_ptr(), ws.data_ptr(), N, H, W, Cin, Cout, None)
+        torch.cuda.synchronize()
+        return dx, dw
+
+    dx, dw = run()
+    gx, gw = dx.cpu().numpy(), dw.cpu().numpy()
+    assert np.isfinite(gx).all() and np.isfinite(gw).all()
+    assert np.abs(gx - dx_ref).max() < 2e-5 * np.abs(dx_ref).max(), np.abs(gx - dx_ref).max() / np.abs(dx_ref).max()
+    assert np.abs(gw - dK_ref).max() < 2e-5 * np.abs(dK_ref).max(), np.abs(gw - dK_ref).max() / np.abs(dK_ref).max()
+    dx2, dw2 = run()
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2)
+    with pytest.raises(Exception):          # BN-on-load / fused sums are the 32 -> 32 kernel's
+        L.dc_conv3x3_bwd_joint_f16x3(xd.data_ptr(), zd.data_ptr(), zd.data_ptr(), None, dad.data_ptr(), zd.data_ptr(), coef.data_ptr(),
+                                     wpd.data_ptr(), dx.data_ptr(), *((None,) * 7), dw.data_ptr(), ws.data_ptr(), N, H, W, Cin, Cout, None)
