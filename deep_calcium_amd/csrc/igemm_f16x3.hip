@@ -88,7 +88,10 @@ __device__ __forceinline__ void split_f16(const f32x4 v, float s, u32x2& hi, u32
   lo = u32x2{l01, l23};
 }
 
-template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB, int CK_>
+// BNRED (its own instantiations, conv-transpose data gradients only): the output IS `da` of the BatchNorm layer in front (dense,
+// no Dropout); the epilogue also reads that layer's pre-BN tensor bnZ (same layout) and emits its pass-1 partials
+// bnPartial[tile][Ncols][2] = (sum dy, sum dy*xhat) and bnAmax[tile][Ncols] = max |dy| -- as igemm_pp.hip's BNRED variant does.
+template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB, int CK_, bool BNRED = false>
 __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   using Cfg = IgemmH<KH, KW, S, PAD, TW, WAVES_M, MB, NB, CK_>;
   constexpr int TAPS = Cfg::TAPS, TH = Cfg::TH, BN = Cfg::BN, TWI = Cfg::TWI, NPIXH = Cfg::NPIXH, CK = Cfg::CK;
@@ -392,6 +395,69 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
   using Plain = std::integral_constant<int, 0>;
   using Stats = std::integral_constant<int, 1>;
   using Track = std::integral_constant<int, 2>;
+  if constexpr (BNRED) {
+    const __amdgpu_buffer_rsrc_t rsrcZ = dc_make_rsrc(p.bnZ + (long)img * out_img_floats, (unsigned)(out_img_floats * 4));
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = n0 + (wave_n * NB + nb) * 32 + li;
+      const bool n_ok = n < p.Ncols;
+      const int nl = n_ok ? n : 0;
+      const float mu = p.bnMean[nl], is = p.bnInvstd[nl];
+      float gsc, gsh;
+      dc_bn_affine(mu, is, p.bnGamma[nl], p.bnBeta[nl], gsc, gsh);
+      float s1 = 0.f, s2 = 0.f, amax = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int mblk = wave_m * MB + mb;
+        const int oyb = oy0 + mblk * RPM, oxb = ox0 + 4 * h;
+        unsigned offs[16];
+        float zr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {            // the z values are requested first, the stores of da go out while they fly
+          const int mr = (r & 3) + 8 * (r >> 2);
+          const int rowc = mr / TW, colc = mr % TW;
+          const bool ok = n_ok && (oyb + rowc) < p.Hout && (oxb + colc) < p.Wout;
+          offs[r] = ok ? (unsigned)((((oyb + rowc) * p.Wout + oxb + colc) * ld + n) * 4) : OOB;
+          zr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcZ, offs[r], 0, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[mb][nb][r] * out_scale), rsrcO, offs[r], 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[mb][nb][r] * out_scale;
+          const float y = __builtin_fmaf(zr[r], gsc, gsh);        // the forward's own expression: identical ReLU gate
+          const float dy = (!(offs[r] >> 31) && y > 0.f) ? v : 0.f;
+          s1 += dy;
+          s2 = __builtin_fmaf(dy, (zr[r] - mu) * is, s2);
+          amax = fmaxf(amax, fabsf(dy));
+        }
+      }
+      DcMoments m;                                 // container: (max |dy|, sum dy, sum dy*xhat)
+      m.n = fmaxf(amax, __shfl_xor(amax, 32));
+      m.mean = s1 + __shfl_xor(s1, 32);
+      m.m2 = s2 + __shfl_xor(s2, 32);
+      if (h == 0) red[(wave * NB + nb) * 32 + li] = m;
+    }
+    __syncthreads();
+    if (tid < Cfg::WAVES_N * NB * 32) {
+      const int wn = tid / (NB * 32), rem = tid % (NB * 32);
+      const int nb = rem / 32, l = rem % 32;
+      float s1 = 0.f, s2 = 0.f, am = 0.f;
+#pragma unroll
+      for (int wm = 0; wm < WAVES_M; ++wm) {
+        const DcMoments m = red[((wn * WAVES_M + wm) * NB + nb) * 32 + l];
+        s1 += m.mean; s2 += m.m2; am = fmaxf(am, m.n);
+      }
+      const int n = n0 + (wn * NB + nb) * 32 + l;
+      if (n < p.Ncols) {
+        float* dst = p.bnPartial + ((long)tile_id * p.Ncols + n) * 2;
+        dst[0] = s1; dst[1] = s2;
+        if (p.bnAmax) p.bnAmax[(long)tile_id * p.Ncols + n] = am;
+      }
+    }
+    return;
+  }
   if (p.outAbsmax) {
     if (interior) epilogue(std::true_type{}, Track{}); else epilogue(std::false_type{}, Track{});
     __syncthreads();
@@ -434,10 +500,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB, int CK_ = 16>
+template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB, int CK_ = 16, bool BNRED = false>
 static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name) {
   using Cfg = IgemmH<KH, KW, S, PAD, TW, WAVES_M, MB, NB, CK_>;
-  auto kern = igemm_f16x3_kernel<KH, KW, S, PAD, TW, WAVES_M, MB, NB, CK_>;
+  auto kern = igemm_f16x3_kernel<KH, KW, S, PAD, TW, WAVES_M, MB, NB, CK_, BNRED>;
   static DcLdsAttr lds_attr;      // one per template instantiation; per-device inside
   if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES + 8 * 1024, name)) return rc;
   p.tilesX = dc_cdiv(p.Wout, TW);
@@ -500,6 +566,11 @@ extern "C" int dc_convT2x2_f16x3_tiles(int N, int H, int W, int Cout) {
   return N * dc_cdiv(W, tw) * dc_cdiv(H, th);
 }
 // Conv2DTranspose dgrad: 2x2 taps over the stride-2 gradient image (no BN partials => free choice of tile).
+// ... with the pass-1 sums of the layer whose `da` it writes (W > 16 only: dc_convT2x2_dgrad_bnred_blocks())
+static int convT_dgrad_bnred_h_launch(IgemmParams p, hipStream_t st) {
+  if (p.Ncols >= 128) return igemm_h_launch<2, 2, 2, 0, 32, 4, 1, 4, 16, true>(p, st, "convT2x2_dgrad_bnred_f16x3");
+  return igemm_h_launch<2, 2, 2, 0, 32, 4, 1, 2, 16, true>(p, st, "convT2x2_dgrad_bnred_f16x3");
+}
 static int convT_dgrad_h_launch(IgemmParams p, hipStream_t st) {
   // >= 128 columns: 128-column workgroups (each staged dz chunk feeds twice the MFMAs: 82 -> 70 us on the deep layers; the
   // same widening of the conv-transpose FORWARD, 8 accumulator blocks per wave, ran twice as slow)
@@ -851,4 +922,31 @@ extern "C" int dc_convT2x2_dgrad_f16x3(const float* dz, const void* wp16, float*
   p.N = N; p.Hin = 2 * H; p.Win = 2 * W; p.Cin = Cout; p.Hout = H; p.Wout = W; p.Ncols = Cin;
   p.biasMod = Cin; p.outLd = Cin;
   return convT_dgrad_h_launch(p, (hipStream_t)stream);
+}
+
+// Conv2DTranspose data gradient that also emits the BatchNorm-backward pass-1 sums (and max |dy|) of the layer whose `da` it
+// writes (the block in front of the up-convolution: dense [N,H,W,Cin], no Dropout, pre-BN tensor z of the same shape):
+// rows = dc_convT2x2_dgrad_bnred_blocks() partial rows; 0 -> shape not served (W <= 16), use dc_convT2x2_dgrad_f16x3 +
+// dc_bn_bwd_reduce.
+extern "C" int dc_convT2x2_dgrad_bnred_blocks(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 16 || Cin < 4 || Cin % 4 || Cout <= 0) return 0;
+  return N * dc_cdiv(W, 32) * dc_cdiv(H, 4);            // 4 x 32-pixel tiles of both instantiations
+}
+extern "C" int dc_convT2x2_dgrad_bnred_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
+                                             const float* in_absmax, int in_absmax_n, const float* z, const float* mean,
+                                             const float* invstd, const float* gamma, const float* beta, float* bn_partial,
+                                             float* amax_partial, int N, int H, int W, int Cin, int Cout, dc_stream_t stream) {
+  int rc = check_h("dc_convT2x2_dgrad_bnred_f16x3", dz, wp16, dx, N, H, W, Cout, Cin);
+  if (rc) return rc;
+  if ((rc = check_absmax("dc_convT2x2_dgrad_bnred_f16x3", in_scale, in_absmax, in_absmax_n))) return rc;
+  DC_REQUIRE(z && mean && invstd && gamma && beta && bn_partial, DC_EINVAL, "dc_convT2x2_dgrad_bnred_f16x3: null pointer");
+  DC_REQUIRE(dc_convT2x2_dgrad_bnred_blocks(N, H, W, Cin, Cout) > 0, DC_EUNSUP,
+             "dc_convT2x2_dgrad_bnred_f16x3: shape not served (dc_convT2x2_dgrad_bnred_blocks() == 0): use the two-pass path");
+  IgemmParams p{};
+  p.in = dz; p.wp = reinterpret_cast<const float*>(wp16); p.out = dx; p.inScale = in_scale;
+  p.inAbsmax = in_absmax; p.inAbsmaxN = in_absmax_n;
+  p.N = N; p.Hin = 2 * H; p.Win = 2 * W; p.Cin = Cout; p.Hout = H; p.Wout = W; p.Ncols = Cin;
+  p.biasMod = Cin; p.outLd = Cin;
+  p.bnZ = z; p.bnMean = mean; p.bnInvstd = invstd; p.bnGamma = gamma; p.bnBeta = beta; p.bnPartial = bn_partial; p.bnAmax = amax_partial;
+  return convT_dgrad_bnred_h_launch(p, (hipStream_t)stream);
 }

@@ -825,6 +825,9 @@ class UNetEngine(object):
         for l in self.layers:
             if l.kind == 'conv':
                 part_floats = max(part_floats, L.dc_conv3x3_bwd_joint_blocks(N, *self._hw(l.lvl), l.cin, l.cout) * l.cin * 2)
+            elif l.kind == 'convT':
+                h, w = self._hw(l.lvl)
+                part_floats = max(part_floats, L.dc_convT2x2_dgrad_bnred_blocks(N, h // 2, w // 2, l.cin, l.cout) * l.cin * 2)
         T['stats_ws'] = torch.empty(stats_floats, dtype=torch.float64, device=dev)      # (sum, sum of squares) partials
         T['part_ws'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['part_ws2'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
@@ -1235,6 +1238,13 @@ class UNetEngine(object):
                     else:
                         L.dc_conv3x3_dgrad(dz, wpd, dx_ptr, N, h, w, l.cin, l.cout, st)
                 elif f16:
+                    rows = L.dc_convT2x2_dgrad_bnred_blocks(N, h // 2, w // 2, l.cin, l.cout) if red is not None else 0
+                    if rows > 0:      # dx is `da` of the block in front of the up-convolution: its pass-1 sums from this epilogue
+                        L.dc_convT2x2_dgrad_bnred_f16x3(dz, wpd, dx_ptr, d_scale, d_amax, d_amax_n, _ptr(T['z_' + red.name]),
+                                                        self.stat_ptr(red, 0), self.stat_ptr(red, 1),
+                                                        self.pview(self.pflat, red, 'gamma'), self.pview(self.pflat, red, 'beta'),
+                                                        _ptr(T['part_ws']), _ptr(T['amax_ws']), N, h // 2, w // 2, l.cin, l.cout, st)
+                        return (_ptr(T['part_ws']), _ptr(T['amax_ws']), rows)
                     L.dc_convT2x2_dgrad_f16x3(dz, wpd, dx_ptr, d_scale, d_amax, d_amax_n, N, h // 2, w // 2, l.cin, l.cout, st)
                 else:
                     L.dc_convT2x2_dgrad(dz, wpd, dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
@@ -1279,13 +1289,14 @@ class UNetEngine(object):
             return fused_next
 
         # ---- decoder: d<l>b -> d<l>a -> (up-conv | up-sampling) for l = 0..3 ---------------------------------------
+        fused_up = None           # pass-1 sums of the block in front of the up-convolution, from that up-convolution's data gradient
         for lvl in (0, 1, 2, 3):
             c = nfb << lvl
             cat, dcat = A['cat%d' % lvl], T['dcat%d' % lvl]
             la = self.by_name['d%da' % lvl]
             ki, ko = state['g'], g_next()
             fa = block_bwd(self.by_name['d%db' % lvl], _ptr(A['d%da' % lvl]), _ptr(gb[ki]), c, _ptr(gb[ko]),
-                           prod=la, fused=fused_d0b if lvl == 0 else None, red=red_of(la), da_g=ki)
+                           prod=la, fused=fused_d0b if lvl == 0 else fused_up, red=red_of(la), da_g=ki)
             state['g'] = ko
             block_bwd(la, _ptr(cat), _ptr(gb[ko]), c, _ptr(dcat), fused=fa, da_g=ko)
             x_up = A['bb'] if lvl == 3 else A['d%db' % (lvl + 1)]
@@ -1295,8 +1306,10 @@ class UNetEngine(object):
                 h, w = self._hw(lvl)
                 mptr, keep, seed = self._up_drop_args(lvl, masks, step_seed)
                 L.dc_upsample2x_drop_bwd(_ptr(dcat), 3 * c, mptr, keep, seed, _ptr(gb[kn]), N, h // 2, w // 2, 2 * c, st)
+                fused_up = None
             else:
-                block_bwd(self.by_name['u%d' % lvl], _ptr(x_up), _ptr(dcat), 2 * c, _ptr(gb[kn]), prod=l_up)
+                fused_up = block_bwd(self.by_name['u%d' % lvl], _ptr(x_up), _ptr(dcat), 2 * c, _ptr(gb[kn]), prod=l_up,
+                                     red=red_of(l_up))
             state['g'] = kn
 
         def bucket_done(i):
@@ -1315,7 +1328,7 @@ class UNetEngine(object):
             tag = 'b' if lvl == 4 else 'e%d' % lvl
             if lvl == 3:
                 bucket_done(1)
-            fused_pool = None
+            fused_pool = fused_up if lvl == 4 else None      # bb: its sums came out of u3's data gradient
             if lvl < 4:
                 # g = d(pool output); route through the argmax and add the skip gradient (second half of dcat); the
                 # kernel also emits the pooled layer's pass-1 sums while it writes da

@@ -248,6 +248,14 @@ int dc_head_bwd_bnin_bnred(const float* z_in, const float* in_scale, const float
                            const uint8_t* y, const float* kh, float* da, float* partial, int loss_kind,
                            const double* sums, const float* bn_mean, const float* bn_invstd, float* bn_partial,
                            float* amax_partial, long pixels, int C, dc_stream_t stream);
+/*   dc_convT2x2_dgrad_bnred_f16x3: dc_convT2x2_dgrad_f16x3 whose output dx IS the `da` of the block in front of the up-convolution
+ *   (dense [N,H,W,Cin], no Dropout): rows = dc_convT2x2_dgrad_bnred_blocks(); 0 -> not served (W <= 16), two-pass path. */
+int dc_convT2x2_dgrad_bnred_blocks(int N, int H, int W, int Cin, int Cout);
+int dc_convT2x2_dgrad_bnred_f16x3(const float* dz, const void* wp16, float* dx, const float* dz_scale,
+                                  const float* dz_absmax, int dz_absmax_n, const float* z,
+                                  const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                  float* bn_partial, float* amax_partial, int N, int H, int W, int Cin, int Cout,
+                                  dc_stream_t stream);
 int dc_maxpool2x2_bwd_blocks(int N, int H, int W, int C);
 int dc_maxpool2x2_bwd_bnred(const float* dy, const uint8_t* idx, const float* skip, long skip_ld, float* dx,
                             const float* z, const float* mean, const float* invstd, const float* gamma,

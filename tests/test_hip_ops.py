@@ -928,3 +928,45 @@ def test_error_reporting(dclib):
     x = torch.empty(64, device='cuda')
     with pytest.raises(DcunetError, match='multiple of 4'):
         dclib.dc_conv3x3_dgrad(x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 8, 8, 8, 6, None)
+
+
+@pytest.mark.parametrize('N,H,W,Ci,Co', [(2, 32, 32, 64, 32), (1, 20, 40, 128, 64), (2, 17, 33, 256, 128), (1, 64, 64, 64, 32)])
+def test_convT_dgrad_with_fused_bn_backward_sums(dclib, N, H, W, Ci, Co):
+    """dc_convT2x2_dgrad_bnred_f16x3: the data gradient is dc_convT2x2_dgrad_f16x3's bit for bit, and the pass-1 sums / max |dy| it
+    emits for the block in front of the up-convolution finalize to a float64 reduction of the dx it wrote (both column-block
+    widths, ragged tiles)."""
+    L = dclib
+    rows = L.dc_convT2x2_dgrad_bnred_blocks(N, H, W, Ci, Co)
+    assert rows == N * ((W + 31) // 32) * ((H + 3) // 4)
+    assert L.dc_convT2x2_dgrad_bnred_blocks(N, 16, 16, Ci, Co) == 0
+    rs = np.random.RandomState(Ci + W)
+    dz = dev((rs.standard_normal((N, 2 * H, 2 * W, Co)) * 1e-3).astype(np.float32))
+    K = dev((rs.standard_normal((2, 2, Co, Ci)) * 0.05).astype(np.float32))
+    wpd = torch.empty(L.dc_pack_weights_f16x3_floats(4, Co, Ci), device='cuda')
+    L.dc_pack_weights_f16x3(K.data_ptr(), wpd.data_ptr(), 4, Co, Ci, Co * Ci, Ci, 1, 0, None)
+    z = dev(rs.standard_normal((N, H, W, Ci)).astype(np.float32))
+    mu = dev((rs.standard_normal(Ci) * 0.2).astype(np.float32)); isd = dev((rs.random_sample(Ci) + 0.5).astype(np.float32))
+    ga = dev(rs.standard_normal(Ci).astype(np.float32)); be = dev((rs.standard_normal(Ci) * 0.3).astype(np.float32))
+    scale = torch.full((4,), 2.0 ** 17, device='cuda')
+    dx0 = torch.full((N, H, W, Ci), float('nan'), device='cuda'); dx1 = torch.full_like(dx0, float('nan'))
+    L.dc_convT2x2_dgrad_f16x3(dz.data_ptr(), wpd.data_ptr(), dx0.data_ptr(), scale.data_ptr(), None, 0, N, H, W, Ci, Co, None)
+    part = torch.full((rows * Ci * 2,), float('nan'), device='cuda')
+    amx = torch.full((rows * Ci,), float('nan'), device='cuda')
+    L.dc_convT2x2_dgrad_bnred_f16x3(dz.data_ptr(), wpd.data_ptr(), dx1.data_ptr(), scale.data_ptr(), None, 0, z.data_ptr(), mu.data_ptr(),
+                                    isd.data_ptr(), ga.data_ptr(), be.data_ptr(), part.data_ptr(), amx.data_ptr(), N, H, W, Ci, Co, None)
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1)
+    assert np.isfinite(part.cpu().numpy()).all() and np.isfinite(amx.cpu().numpy()).all()
+    dg, db = torch.zeros(Ci, device='cuda'), torch.zeros(Ci, device='cuda')
+    L.dc_bn_bwd_finalize(part.data_ptr(), rows, Ci, dg.data_ptr(), db.data_ptr(), None)
+    torch.cuda.synchronize()
+    dxa, za = dx0.cpu().numpy().astype(np.float64).reshape(-1, Ci), z.cpu().numpy().astype(np.float64).reshape(-1, Ci)
+    sc = (ga.cpu().numpy() * isd.cpu().numpy()).astype(np.float32)
+    sh = (be.cpu().numpy().astype(np.float64) - mu.cpu().numpy().astype(np.float64) * sc.astype(np.float64)).astype(np.float32)
+    gate = (za * sc.astype(np.float64) + sh.astype(np.float64)) > 0
+    dy = np.where(gate, dxa, 0.0)
+    ref_db = dy.sum(0)
+    ref_dg = (dy * (za - mu.cpu().numpy().astype(np.float64)) * isd.cpu().numpy().astype(np.float64)).sum(0)
+    tol = 2e-5 * max(np.abs(ref_dg).max(), np.abs(ref_db).max())
+    assert np.abs(dg.cpu().numpy() - ref_dg).max() < tol and np.abs(db.cpu().numpy() - ref_db).max() < tol
+    assert np.array_equal(amx.cpu().numpy().reshape(rows, Ci).max(0), np.abs(dy).max(0).astype(np.float32))
