@@ -1,6 +1,7 @@
 """Soak: the example's own training configuration (128x128 windows, batch 20, 100 steps per epoch, validation at 512x512 every
 epoch) for a few epochs on a synthetic Neurofinder directory; reports steps/s per epoch, device / host memory growth and the loss.
-    python scripts/soak_fit.py [epochs=3] [steps=100]"""
+    python scripts/soak_fit.py [epochs=3] [steps=100] [window=128] [batch=20]
+window 512, batch 16: the benchmark configuration through fit() -- the dz-on-load / joint backward kernels inside real training."""
 import os, resource, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
@@ -13,9 +14,12 @@ from deep_calcium_amd.model import Callback
 
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+window = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+batch = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+hw = max(512, (window * 3 // 2 + 15) // 16 * 16)           # the training crop comes from the upper 75 % of the image
 tmp = tempfile.mkdtemp(prefix='dc_soak_')
 for k, name in enumerate(('neurofinder.01.00', 'neurofinder.02.00')):
-    make_neurofinder_dir(tmp, name, seed=5 + k)
+    make_neurofinder_dir(tmp, name, hw=(hw, hw), seed=5 + k)
 paths = nf_load_hdf5('neurofinder.01.00,neurofinder.02.00', datasets_dir=tmp)
 
 
@@ -33,7 +37,7 @@ class Probe(Callback):
 
 np.random.seed(865)
 model = UNet2DSummary(cpdir=os.path.join(tmp, 'cp'))
-hist, _ = model.fit(paths, shape_trn=(128, 128), shape_val=(512, 512), batch_size_trn=20, nb_steps_trn=steps, nb_epochs=epochs,
+hist, _ = model.fit(paths, shape_trn=(window, window), shape_val=(hw, hw), batch_size_trn=batch, nb_steps_trn=steps, nb_epochs=epochs,
                     keras_callbacks=[Probe()], prop_trn=0.75, prop_val=0.25)
 print('loss per epoch', ['%.4f' % v for v in hist['loss']])
 assert hist['loss'][-1] < hist['loss'][0]
