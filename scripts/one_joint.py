@@ -18,8 +18,8 @@ M = N * H * W
 blocks = L.dc_bn_bwd_blocks(M, C)
 part = torch.empty(blocks * C * 2, device='cuda'); amx = torch.empty(blocks * C, device='cuda')
 L.dc_bn_bwd_reduce(da.data_ptr(), C, z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, 1.0, 0, part.data_ptr(), amx.data_ptr(), M, C, None)
-dg, db, coef, dbias = (torch.empty(C, device='cuda') for _ in range(2)) .__iter__().__next__(), torch.empty(C, device='cuda'), torch.empty(7 * C, device='cuda'), torch.empty(C, device='cuda')
-dg = torch.empty(C, device='cuda')
+dg, db, dbias = (torch.empty(C, device='cuda') for _ in range(3))
+coef = torch.empty(7 * C, device='cuda')
 L.dc_bn_bwd_finalize_dzin(part.data_ptr(), amx.data_ptr(), blocks, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(M), dg.data_ptr(), db.data_ptr(), coef.data_ptr(), dbias.data_ptr(), None)
 wpd = torch.empty(L.dc_pack_weights_f16x3_floats(9, C, C), device='cuda')
 L.dc_pack_weights_f16x3(K.data_ptr(), wpd.data_ptr(), 9, C, C, C * C, 1, C, 1, None)
