@@ -36,14 +36,14 @@ constexpr int C = 32;
 constexpr int TH = 4, TW = 32, THI = TH + 2, TWI = TW + 2, NPIX = THI * TWI;      // 204 halo'd pixels
 constexpr int PLANE = 13312;                 // NPIX * 64 bytes rounded up to a multiple of 1024 (the swizzle reads address bits 8-9)
 constexpr int IMG = 2 * PLANE;               // hi | lo
-constexpr int STAGE = 2 * IMG;               // dz image | x image
+constexpr int RAW = TH * TW * C * 4;          // the tile's interior x values as loaded (fp32): the pre-BN tensor of the layer in front
+constexpr int STAGE = 2 * IMG + RAW;         // dz image | x image | raw interior x
 constexpr int W_SLOTS = 9 * 4 * 2 * C;       // packed data-gradient weights: [tap][k8][hi|lo][col] 16-byte slots
-constexpr int W_BYTES = W_SLOTS * 16;
-constexpr int LDS_BYTES = 2 * STAGE + W_BYTES + 64;
+constexpr int LDS_BYTES = 2 * STAGE + 64;
 constexpr int THREADS = 512;
 constexpr int NL = (NPIX * 8 + 255) / 256;   // float4 loads per producer thread and tensor (7)
 constexpr unsigned OOB = 0x80000000u;
-static_assert(LDS_BYTES <= 160 * 1024 && NPIX * 64 <= PLANE && PLANE % 1024 == 0, "LDS plan");
+static_assert(LDS_BYTES <= 160 * 1024 && NPIX * 64 <= PLANE && PLANE % 1024 == 0 && STAGE % 1024 == 0, "LDS plan");
 
 // 16-byte chunk c of pixel p lives at chunk c ^ ((p >> 2) & 3): eight consecutive pixels read the same chunk of
 // their 64-byte rows from eight different bank groups; a 4-aligned pixel group keeps its chunks together (tr reads)
@@ -89,16 +89,16 @@ struct JointParams {
 __global__ __launch_bounds__(bj::THREADS, 1) void bwd_joint32_kernel(JointParams p) {
   using namespace bj;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  char* ldsW = smem + 2 * STAGE;
-  float* tmp = reinterpret_cast<float*>(smem + 2 * STAGE + W_BYTES);
+  float* tmp = reinterpret_cast<float*>(smem + 2 * STAGE);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
 
   const float x_scale = dc_block_guard_scale(p.xAbound, C, tmp);
   const float dz_scale = dc_block_guard_scale(p.dzCoef + 6 * C, C, tmp);
   const float w_scale = p.wp[W_SLOTS * 4];                         // trailer of the packed weights
-  for (int i = tid; i < W_SLOTS; i += THREADS)
-    reinterpret_cast<u32x4*>(ldsW)[i] = reinterpret_cast<const u32x4*>(p.wp)[i];
+  // the layer in front's pre-BN values for its fused sums: when that tensor IS the x operand (BN + ReLU on load: x = its z) the
+  // producers leave the tile's interior values in LDS as they loaded them -- no second trip to HBM (537 MB per launch less)
+  const bool red_lds = p.redZ != nullptr && p.redZ == p.x;
 
   // this workgroup's tiles: each XCD walks a contiguous range of the (image, column, row) list -- consecutive positions
   // are vertically adjacent tiles whose halo rows overlap --, its workgroups striding through it (igemm_pp.hip)
@@ -181,6 +181,11 @@ __global__ __launch_bounds__(bj::THREADS, 1) void bwd_joint32_kernel(JointParams
           const int off = swz(pix * 64 + q * 8);
           *reinterpret_cast<u32x2*>(set + IMG + off) = xh;
           *reinterpret_cast<u32x2*>(set + IMG + PLANE + off) = xl;
+          if (red_lds) {
+            const int r = __umul24(pix, (65536 + TWI - 1) / TWI) >> 16, c = pix - __umul24(r, TWI);
+            if (r >= 1 && r <= TH && c >= 1 && c <= TW)
+              *reinterpret_cast<f32x4*>(set + 2 * IMG + (((r - 1) * TW + (c - 1)) * C + 4 * q) * 4) = rx[k];
+          }
         }
       }
     };
@@ -252,31 +257,18 @@ __global__ __launch_bounds__(bj::THREADS, 1) void bwd_joint32_kernel(JointParams
     int a_rel[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) a_rel[mb] = ((2 * wd + mb) * TWI + li) * 64 + h * 16;
-    // the pre-BN values of the layer in front at a tile's 2 x 16 output positions, requested ONE TILE AHEAD (at the end of
-    // the previous tile's epilogue): they land behind a whole MFMA block (requested inside the epilogue they cost a full
-    // HBM latency per block on the tile's critical path)
-    float zr[2][16];
-    auto request_zr = [&](int j) __attribute__((always_inline)) {
-      const Tile t2 = decode(j);
-      const __amdgpu_buffer_rsrc_t rsR = dc_make_rsrc(p.redZ + t2.img * img_floats, (unsigned)(img_floats * 4));
+    // the 36 weight fragments of this lane (tap, 16-channel half, hi | lo) live in registers for the whole launch: they are the
+    // same for every tile, and the LDS they occupied now holds the raw interior x values
+    u32x4 wreg[18][2];
+    {
+      const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.wp) + h * 64 + li;      // slot ((tap*4 + ks*2 + h)*2 + hl)*32 + li
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        const int oy = t2.y0 + 2 * wd + mb, oxb = t2.x0 + 4 * h;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int colc = (r & 3) + 8 * (r >> 2);
-          const bool ok = oy < p.H && (oxb + colc) < p.W;
-          const unsigned off = ok ? (unsigned)(((oy * p.W + oxb + colc) * C + li) * 4) : OOB;
-          zr[mb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off, 0, 0));
-        }
+      for (int g = 0; g < 18; ++g) {
+        wreg[g][0] = wsrc[(g >> 1) * 256 + (g & 1) * 128];
+        wreg[g][1] = wsrc[(g >> 1) * 256 + (g & 1) * 128 + 32];
       }
-    };
-#ifndef DC_JOINT_ZR_AHEAD
-#define DC_JOINT_ZR_AHEAD 0
-#endif
-    if (DC_JOINT_ZR_AHEAD && red && nt > 0) request_zr(0);
-    const int b_rel = h * 1024 + li * 16;                        // slot ((tap*4 + ks*2 + h)*2 + hl)*32 + li
-    __syncthreads();                                             // stage 0 and the weights are in LDS
+    }
+    __syncthreads();                                             // stage 0 is in LDS
     for (int i = 0; i < nt; ++i) {
       const char* cur = smem + (i & 1) * STAGE;
       int ar0 = a_rel[0], ar1 = a_rel[1];
@@ -294,13 +286,10 @@ __global__ __launch_bounds__(bj::THREADS, 1) void bwd_joint32_kernel(JointParams
         // of group g issue (one wave per SIMD feeds the pipe: without the explicit double buffer every group paid the LDS
         // latency -- the consumer side alone ran at 45 % of the MFMA issue rate)
         constexpr int NG = (DC_JOINT_ABL & 1) ? 2 : 18;
-        f16x8 ah[2][2], al[2][2], bh[2], bl[2];
+        f16x8 ah[2][2], al[2][2];
         auto fetch = [&](int g, int buf) __attribute__((always_inline)) {
           const int tap = g >> 1, ks = g & 1;
           const int toff = ((tap / 3) * TWI + (tap % 3)) * 64 + ks * 32;
-          const int boff = (tap * 4 + ks * 2) * 1024 + b_rel;
-          bh[buf] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ldsW + boff));
-          bl[buf] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ldsW + boff + 512));
 #pragma unroll
           for (int mb = 0; mb < 2; ++mb) {
             const int ao = swz((mb ? ar1 : ar0) + toff);
@@ -314,11 +303,12 @@ __global__ __launch_bounds__(bj::THREADS, 1) void bwd_joint32_kernel(JointParams
           const int b = g & 1;
           if (g + 1 < NG) fetch(g + 1, b ^ 1);
           __builtin_amdgcn_sched_barrier(0);
+          const f16x8 bh = __builtin_bit_cast(f16x8, wreg[g][0]), bl = __builtin_bit_cast(f16x8, wreg[g][1]);
 #pragma unroll
           for (int mb = 0; mb < 2; ++mb) {
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b][mb], bh[b], acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b][mb], bl[b], acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b][mb], bh[b], acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b][mb], bh, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b][mb], bl, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b][mb], bh, acc[mb], 0, 0, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -336,10 +326,16 @@ __global__ __launch_bounds__(bj::THREADS, 1) void bwd_joint32_kernel(JointParams
           const bool ok = row_ok && (oxb + colc) < p.W;
           offs[r] = ok ? (unsigned)(((oy * p.W + oxb + colc) * C + li) * 4) : OOB;
         }
-        if (!DC_JOINT_ZR_AHEAD && red) {      // requested here: the stores of this block go out while they fly
+        float zr[16];
+        if (red_lds) {                        // the producers left this tile's interior x (= that layer's z) in LDS
+          const float* raw = reinterpret_cast<const float*>(cur + 2 * IMG) + ((2 * wd + mb) * TW + 4 * h) * C + li;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) zr[r] = raw[((r & 3) + 8 * (r >> 2)) * C];
+        } else if (red) {                     // another tensor: requested here, the stores of this block go out while they fly
+          // (requesting them a tile ahead / before the MFMA block was measured slower: they compete with the producers' prefetch)
           const __amdgpu_buffer_rsrc_t rsR = dc_make_rsrc(p.redZ + tl.img * img_floats, (unsigned)(img_floats * 4));
 #pragma unroll
-          for (int r = 0; r < 16; ++r) zr[mb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, offs[r], 0, 0));
+          for (int r = 0; r < 16; ++r) zr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, offs[r], 0, 0));
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -350,15 +346,14 @@ __global__ __launch_bounds__(bj::THREADS, 1) void bwd_joint32_kernel(JointParams
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float v = acc[mb][r] * out_scale;
-            const float y = __builtin_fmaf(zr[mb][r], gsc, gsh);
+            const float y = __builtin_fmaf(zr[r], gsc, gsh);
             const float dy = (!(offs[r] >> 31) && y > 0.f) ? v : 0.f;
             s1 += dy;
-            s2 = __builtin_fmaf(dy, (zr[mb][r] - rmu) * ris, s2);
+            s2 = __builtin_fmaf(dy, (zr[r] - rmu) * ris, s2);
             amax = fmaxf(amax, fabsf(dy));
           }
         }
       }
-      if (DC_JOINT_ZR_AHEAD && red && i + 1 < nt) request_zr(i + 1);
       __syncthreads();
     }
     if (red) {
