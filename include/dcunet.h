@@ -293,11 +293,13 @@ int dc_conv3x3_wgrad_dzin_f16x3(const float* x, const float* in_scale, const flo
                                 const float* da, const float* z, const float* dz_coef, float* dw, float* ws,
                                 int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 
-/* Joint backward of a 32 -> 32 conv block at a 512^2-class resolution (the HBM-bound blocks e0b / d0b of the network): ONE
- * kernel stages dz (formed on load, as above) and the block input x once per tile and produces dx, dW and -- red_z != NULL --
- * the pass-1 sums / max |dy| of the layer in front: every tensor of the block is read once (4 tensor passes instead of 7).
- * Arguments as dc_conv3x3_dgrad_dzin_f16x3 + dc_conv3x3_wgrad_dzin_f16x3 (wp16 = the data-gradient form of the kernel).
- * dc_conv3x3_bwd_joint_blocks() = rows of bn_partial / amax_partial (0: shape not served -- needs Cin == Cout == 32,
+/* Joint backward of a conv block with 32 output channels at a 512^2-class resolution (the HBM-bound blocks of the network:
+ * e0b / d0b, 32 -> 32, and d0a, 64 -> 32): ONE kernel stages dz (formed on load, as above) and the block input x once per
+ * tile and produces dx, dW and -- 32 -> 32 only, red_z != NULL -- the pass-1 sums / max |dy| of the layer in front: every
+ * tensor of the block is read once (4 tensor passes instead of 7; when red_z is x itself, the usual case, its values reach the
+ * sums through LDS).  Arguments as dc_conv3x3_dgrad_dzin_f16x3 + dc_conv3x3_wgrad_dzin_f16x3 (wp16 = the data-gradient form
+ * of the kernel); the 64 -> 32 variant takes a materialised x (in_scale NULL) and no red_z.
+ * dc_conv3x3_bwd_joint_blocks() = rows of bn_partial / amax_partial (0: shape not served -- needs Cout == 32, Cin 32 or 64,
  * W >= 32: use the two separate kernels); ws: float[dc_conv3x3_bwd_joint_ws_floats()] (one dW slab per workgroup, reduced
  * in a fixed order => bit-reproducible). */
 int dc_conv3x3_bwd_joint_blocks(int N, int H, int W, int Cin, int Cout);
