@@ -48,7 +48,8 @@ def test_forward_inference_matches_oracle(N, H, W, nfb, mfma):
 
 
 @pytest.mark.parametrize('mfma', MODES)
-@pytest.mark.parametrize('N,H,W,nfb', [(1, 16, 16, 4), (2, 32, 32, 32), (2, 64, 64, 8), (2, 64, 64, 32)])
+# (2, 96, 96, 32) / (2, 128, 128, 32): the reference's own training windows (fit() default 96 x 96; examples/neurons/unet2ds_nf.py 128 x 128)
+@pytest.mark.parametrize('N,H,W,nfb', [(1, 16, 16, 4), (2, 32, 32, 32), (2, 64, 64, 8), (2, 64, 64, 32), (2, 96, 96, 32), (2, 128, 128, 32)])
 def test_train_forward_backward_matches_oracle(N, H, W, nfb, mfma):
     eng, Wt = make_engine(H, W, nfb, mfma=mfma)
     x, y = on.synthetic_batch(N, H, W)
