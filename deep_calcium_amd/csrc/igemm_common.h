@@ -63,5 +63,12 @@ struct IgemmParams {
   // dzCoef[DC_DZ_COEF_ROWS][Cin] (dc_bn_bwd_finalize_dzin; row 6 = the bound the fp16 range guard scales by)
   const float* in2;
   const float* dzCoef;
+  // 256-thread f16x3 kernel only, split-K (grid.y = S > 1: the narrow 16^2 / 8^2 layers of a small step put < 256 workgroups
+  // on the chip with 16-64 serial chunks each): workgroup (x, s) contracts chunks [nch s / S, nch (s+1) / S) and writes its
+  // scaled partial tile to the dense slab splitWs + s * splitSlab ([N][Hout][Wout][Ncols] floats, no bias / statistics);
+  // splitk_combine_kernel adds the S slabs in index order (bit-reproducible), applies the bias, writes the output and forms
+  // the BatchNorm partials of the same tile rows.
+  float* splitWs;
+  long splitSlab;
 };
 

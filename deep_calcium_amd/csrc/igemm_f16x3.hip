@@ -202,8 +202,19 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
+  // split-K (IgemmParams::splitWs): this workgroup's chunk range, and a plain dense store of the partial tile into its slab
+  int c_begin = 0, c_end = p.Cin;
+  if constexpr (TW <= 16 && !BNRED)               // (only the narrow-tile instantiations are ever launched with grid.y > 1)
+  if (gridDim.y > 1) {
+    const int nch = (p.Cin + CK - 1) / CK, ks = (int)blockIdx.y, nsl = (int)gridDim.y;
+    c_begin = (nch * ks / nsl) * CK;
+    c_end = min(p.Cin, (nch * (ks + 1) / nsl) * CK);
+    p.out = p.splitWs + (long)ks * p.splitSlab;
+    p.outLd = p.Ncols;
+    p.bias = nullptr; p.stats = nullptr; p.scale = nullptr; p.shift = nullptr; p.relu = 0; p.outAbsmax = nullptr;
+  }
   DC_TRACE();            // 1: entry + address setup
-  load_chunk(0);
+  load_chunk(c_begin);
   // Per-channel tables and the operand scale AFTER the first chunk's loads are in flight (their latency is the same
   // L2 round trip): the BN-on-load (scale, shift) pairs, and the powers of two -- device scalar of a gradient tensor x
   // range guard of an activation tensor (common.h dc_block_guard_scale; its barriers also publish the table).
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
                          dc_block_guard_scale(p.inAbound, p.Cin, reinterpret_cast<float*>(smem), p.inAboundLd);
   if (bnin && p.inAbound == nullptr) __syncthreads();
   DC_TRACE();            // 2: first loads issued, tables / guard done
-  for (int c0 = 0; c0 < p.Cin; c0 += CK) {
+  for (int c0 = c_begin; c0 < c_end; c0 += CK) {
     DC_TRACE();          // per chunk a: top
 #ifdef DC_IGEMM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
     DC_TRACE();          // b: operands split and written to LDS (includes the wait for this chunk's global loads)
     __syncthreads();
     DC_TRACE();          // c: barrier passed
-    if (c0 + CK < p.Cin) load_chunk(c0 + CK);
+    if (c0 + CK < c_end) load_chunk(c0 + CK);
 
     // Software-pipelined operand fetch: the fragments of step tk+1 are requested from LDS before the 3*MB*NB
     // MFMAs of step tk issue, so the ~100-cycle ds_read latency hides behind 12 x 32 MFMA cycles instead of
@@ -500,6 +511,76 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Second half of a split-K launch: out = sum_s slab_s (index order) + bias, and the BatchNorm partials of the SAME pixel-tile
+// rows the un-split kernel writes (tile_id row-major, one row per TW x TH tile).  One workgroup per (pixel tile, 16 columns)
+// -- 320 / 640 workgroups for the 16^2 / 8^2 layers of a 128^2 x 20 step --, thread = (column quad, one of 64 pixel lanes):
+// a wave reads 16 pixels x 64 bytes per slab.
+__global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ ws, int S, long slab,
+                                                            const float* __restrict__ bias, float* __restrict__ out, long outLd,
+                                                            double* __restrict__ stats, int H, int W, int Ncols, int TW, int TH,
+                                                            int tilesX, int tilesY) {
+  __shared__ DcMoments red[4][4][4];                           // [wave][column quad][element]
+  const int tid = threadIdx.x, cq = tid & 3, pl = tid >> 2, lane = tid & 63, wave = tid >> 6;
+  const int col = blockIdx.y * 16 + 4 * cq;
+  const int tile = blockIdx.x, tx = tile % tilesX, t2 = tile / tilesX, ty = t2 % tilesY, img = t2 / tilesY;
+  const int ncol = Ncols - col;                                // columns of this quad that exist (Ncols % 4 may be != 0)
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias)
+    for (int e = 0; e < 4; ++e) bv[e] = e < ncol ? bias[col + e] : 0.f;
+  float n = 0.f;
+  f32x4 K = {0.f, 0.f, 0.f, 0.f}, s1 = K, s2 = K;
+  if (ncol > 0)
+    for (int pi = pl; pi < TW * TH; pi += 64) {
+      const int y = ty * TH + pi / TW, x = tx * TW + pi % TW;
+      if (y < H && x < W) {
+        const long pix = ((long)img * H + y) * W + x;
+        const float* src = ws + pix * Ncols + col;
+        f32x4 v;
+        if (ncol >= 4 && (Ncols & 3) == 0) {
+          v = *reinterpret_cast<const f32x4*>(src);
+          for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(src + s * slab);
+        } else {
+          for (int e = 0; e < 4; ++e) {
+            float a = 0.f;
+            if (e < ncol) { a = src[e]; for (int s = 1; s < S; ++s) a += src[s * slab + e]; }
+            v[e] = a;
+          }
+        }
+        v += bv;
+        float* dst = out + pix * outLd + col;
+        if (ncol >= 4 && (outLd & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+        else for (int e = 0; e < 4 && e < ncol; ++e) dst[e] = v[e];
+        if (n == 0.f) K = v;
+        const f32x4 d = v - K;
+        s1 += d;
+        s2 += d * d;
+        n += 1.f;
+      }
+    }
+  if (stats == nullptr) return;
+  // moments of this thread's 4 columns -> merge over the 16 pixel lanes of the wave (lane bits 2-5), then over the 4 waves
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    DcMoments m = dc_moments_from_shifted(n, K[e], s1[e], s2[e]);
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+      DcMoments q;
+      q.n = __shfl_xor(m.n, o); q.mean = __shfl_xor(m.mean, o); q.m2 = __shfl_xor(m.m2, o);
+      m = dc_moments_merge(m, q);
+    }
+    if (lane < 4) red[wave][cq][e] = m;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int q = tid >> 2, e = tid & 3;
+    DcMoments m = red[0][q][e];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) m = dc_moments_merge(m, red[w][q][e]);
+    const int c = blockIdx.y * 16 + 4 * q + e;
+    if (c < Ncols) dc_moments_store(stats + ((long)tile * Ncols + c) * 2, m);
+  }
+}
+
 template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB, int CK_ = 16, bool BNRED = false>
 static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name) {
   using Cfg = IgemmH<KH, KW, S, PAD, TW, WAVES_M, MB, NB, CK_>;
@@ -512,6 +593,35 @@ static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name) {
   dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY * dc_cdiv(p.Ncols, Cfg::BN)));
   const int lds = Cfg::LDS_BYTES + (p.inSc ? 8 * ((p.Cin + 3) & ~3) : 0);
   DC_REQUIRE(lds <= Cfg::LDS_BYTES + 8 * 1024, DC_EUNSUP, "%s: Cin=%d too large for the BN-on-load table", name, p.Cin);
+  // Split-K for the narrow layers (images of at most 16 x 16 pixels: 256 / 512 channels at the reference's own training
+  // windows): training forwards (bias + BatchNorm partials) and plain data gradients whose grid leaves most of the chip idle.
+  // 2-4 slabs, at least 2 chunks per slab; the S partial tiles are added in index order by splitk_combine_kernel.
+  int split = 1;
+  const int nch = dc_cdiv(p.Cin, Cfg::CK);
+  if (!BNRED && TW <= 16 && p.scatterCo == 0 && p.outAbsmax == nullptr && p.scale == nullptr && p.relu == 0 && p.poolOut == nullptr &&
+      p.bnPartial == nullptr && grid.x < 256 && nch >= 4) {
+    // (same-box sweep, 128^2 x 20 step: no split 3.10-3.12 ms, <= 2 slabs 3.07-3.09, <= 4 slabs aiming at 512 workgroups
+    // 3.01-3.04, <= 8 / 1 024 3.07; the 96^2 x 32 step is flat)
+    split = (int)(512 / grid.x);
+    split = split > 4 ? 4 : split;
+    split = split > nch / 2 ? nch / 2 : split;
+  }
+  if (split > 1) {
+    const long slab = (long)p.N * p.Hout * p.Wout * p.Ncols;
+    void* ws = nullptr;
+    if (int rc = dc_stream_ws(st, (size_t)slab * split * sizeof(float), &ws)) return rc;
+    IgemmParams q = p;
+    q.splitWs = reinterpret_cast<float*>(ws);
+    q.splitSlab = slab;
+    grid.y = (unsigned)split;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, q);
+    DC_CHECK_LAUNCH(name);
+    hipLaunchKernelGGL(splitk_combine_kernel, dim3((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)dc_cdiv(p.Ncols, 16)), dim3(256), 0, st,
+                       q.splitWs, split, slab, p.bias, p.out, p.outLd, p.stats, p.Hout, p.Wout, p.Ncols, TW, Cfg::TH, p.tilesX,
+                       p.tilesY);
+    DC_CHECK_LAUNCH("splitk_combine");
+    return DC_OK;
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   DC_CHECK_LAUNCH(name);
   return DC_OK;

@@ -63,6 +63,9 @@ CONV_SHAPES = [
     (1, 32, 64, 128, 64),       # deep-layer shape at W > 16: many chunks, interior tiles
     (2, 40, 40, 144, 96),       # ragged in y, x and columns, Cout % 64 != 0
     (1, 24, 48, 136, 64),       # partial last chunk (Cin % 16 = 8)
+    (20, 16, 16, 256, 256),     # the 16^2 layers of the reference's 128^2 x 20 training step: 4-way split-K + combine launch
+    (20, 8, 8, 512, 512),       # its 8^2 layers: split-K on the 8 x 8 tiles
+    (3, 12, 12, 200, 96),       # split-K with a partial tile, a partial last chunk and Cout % 64 != 0
 ]
 
 
