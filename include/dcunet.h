@@ -88,7 +88,12 @@ int dc_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* ws,
  *   in_abound_ld == 0: a single array (the training-mode bound).
  *   out_absmax_ld == -1 (optimistic inference): nothing is measured; out_absmax[0] is set to 1 if any output exceeds
  *   32768 (or is NaN) -- the caller then repeats the forward pass with measured bounds.  A BatchNorm network's
- *   activations are O(1), so this path normally runs with no guard traffic at all. */
+ *   activations are O(1), so this path normally runs with no guard traffic at all.
+ *   Narrow launches (images of at most 16 x 16 pixels whose grid would leave most of the chip idle: the 256- / 512-channel
+ *   layers of a 128^2 / 96^2 training window) are split over K into 2-4 slabs and combined by a second launch in a fixed
+ *   order (bit-reproducible; dc_conv3x3_tiles() rows unchanged).  The slabs live in a scratch buffer the library keeps per
+ *   (device, stream), allocated / grown with hipMalloc on first use: issue the first call of a shape on a stream outside
+ *   any stream capture. */
 #define DC_ABOUND_SLOTS 8
 long dc_pack_weights_f16x3_floats(int taps, int K, int Ncols);
 int dc_pack_weights_f16x3(const float* src, void* dst, int taps, int K, int Ncols,
