@@ -924,6 +924,50 @@ def test_reduce_partials_deterministic(dclib):
         assert np.allclose(out1.cpu().numpy(), 0.5 * x.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
 
 
+def test_split_k_scratch_is_per_stream_and_grows(dclib):
+    """Split-K launches (narrow layers) keep their slabs in a scratch buffer the library owns per (device, stream): the same
+    convolution issued on two streams at once, then a larger one on the first stream (the buffer has to grow), must give
+    the bits of the same launches issued alone, one after the other."""
+    L = dclib
+    rs = np.random.RandomState(11)
+    shapes = [(20, 16, 16, 256, 256), (24, 16, 16, 512, 256)]
+    data = []
+    for N, H, W, Ci, Co in shapes:
+        x = dev(rs.standard_normal((N, H, W, Ci)).astype(np.float32))
+        K = dev((rs.standard_normal((3, 3, Ci, Co)) * np.sqrt(2.0 / (9 * Ci))).astype(np.float32))
+        b = dev(rs.standard_normal(Co).astype(np.float32))
+        wp = torch.empty(L.dc_pack_weights_f16x3_floats(9, Ci, Co), device='cuda')
+        L.dc_pack_weights_f16x3(K.data_ptr(), wp.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
+        data.append((x, wp, b))
+    torch.cuda.synchronize()
+
+    def run(i, stream):
+        N, H, W, Ci, Co = shapes[i]
+        x, wp, b = data[i]
+        tiles = L.dc_conv3x3_tiles(N, H, W, Co)
+        z = torch.full((N, H, W, Co), float('nan'), device='cuda')
+        stats = torch.full((tiles * Co * 2,), float('nan'), device='cuda', dtype=torch.float64)
+        L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, stats.data_ptr(), None, None, 0,
+                               None, 0, None, 0, N, H, W, Ci, Co, stream.cuda_stream if stream is not None else None)
+        return z, stats
+
+    ref = [run(0, None), run(1, None)]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):
+        outs.append((run(0, s1), run(0, s2)))        # both streams busy with the same shape
+    big = run(1, s1)                                 # s1's scratch grows behind its pending launches
+    again = run(0, s1)
+    torch.cuda.synchronize()
+    for a, b2 in outs:
+        for z, st in (a, b2):
+            assert torch.equal(z, ref[0][0]) and torch.equal(st, ref[0][1])
+    assert torch.equal(big[0], ref[1][0]) and torch.equal(big[1], ref[1][1])
+    assert torch.equal(again[0], ref[0][0]) and torch.equal(again[1], ref[0][1])
+
+
 def test_error_reporting(dclib):
     from deep_calcium_amd._lib import DcunetError
     with pytest.raises(DcunetError, match='null pointer'):
