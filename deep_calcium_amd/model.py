@@ -332,7 +332,7 @@ class Model(object):
         if dp:
             self._backward_allreduce()
         else:
-            eng.backward()
+            eng.backward(defer_tail=True)      # adam_step() joins the weight-gradient stream (128^2 x 20 step: 3.19 -> 3.15 ms)
         o = self.optimizer
         eng.adam_step(o.lr, o.beta_1, o.beta_2, o.epsilon, grad_scale=grad_scale)
         copied.synchronize()

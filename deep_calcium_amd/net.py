@@ -1037,8 +1037,11 @@ class UNetEngine(object):
         return self.L.dc_conv3x3_dgrad_dzin_blocks(N, h, w, l.cin, l.cout) > 0
 
     @_on_device
-    def backward(self, bucket_cb=None):
-        """Backward of the last forward_train: fills gflat (same layout as pflat).  bucket_cb(lo, hi), if given, is called
+    def backward(self, bucket_cb=None, defer_tail=False):
+        """Backward of the last forward_train: fills gflat (same layout as pflat).  defer_tail (single-GPU training step
+        only): return WITHOUT joining the weight-gradient stream -- the only thing still running there is the first layer's
+        weight (and bias) gradient, and adam_step() updates everything else and re-packs the weights underneath it before
+        it joins (the first layer's ~320 parameters follow).  bucket_cb(lo, hi), if given, is called
         with the side (weight-gradient) stream current as soon as gflat[lo:hi] is complete on it -- data-parallel training
         starts that range's all-reduce there, so it overlaps with the rest of the backward (grad_buckets()[:2]; the last
         range is complete when backward() returns).
@@ -1054,6 +1057,7 @@ class UNetEngine(object):
         N, masks, step_seed, x_dev, y_dev = self._last
         L, st = self.L, self._stream()
         A, T = self._acts(N), self._train_bufs(N)
+        self._tail = None
         nfb = self.nfb
         f16 = self.mfma == 'f16x3'
         pixels0 = N * self.H * self.W
@@ -1349,12 +1353,15 @@ class UNetEngine(object):
                            fused=fused_pool, red=red_of(la), da_g=ki)
             state['g'] = ko
             if lvl == 0:
+                if two and defer_tail and bucket_cb is None:
+                    self._tail = torch.cuda.Event()       # everything the side stream has been given so far
+                    self._tail.record(side)
                 block_bwd(la, _ptr(x_dev), _ptr(gb[ko]), c, None, fused=fa, da_g=ko)
             else:
                 kn = g_next()
                 block_bwd(la, _ptr(A['pool%d' % (lvl - 1)]), _ptr(gb[ko]), c, _ptr(gb[kn]), fused=fa, da_g=ko)
                 state['g'] = kn
-        if two:
+        if two and getattr(self, '_tail', None) is None:
             main.wait_stream(side)        # gflat is complete once both streams have drained
 
     def _join_side(self):
@@ -1367,10 +1374,34 @@ class UNetEngine(object):
         """Keras-2.0.6 Adam over the flat buffers; `iterations` counts completed steps."""
         t = self.iterations + 1
         lr_t = lr * np.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t)
-        self.L.dc_adam_step_flat(_ptr(self.pflat), _ptr(self.gflat), _ptr(self.mflat), _ptr(self.vflat),
-                                 self.n_train, float(lr_t), beta_1, beta_2, epsilon, float(grad_scale), self._stream())
+
+        def adam(lo, hi):
+            if hi > lo:
+                self.L.dc_adam_step_flat(_ptr(self.pflat, lo), _ptr(self.gflat, lo), _ptr(self.mflat, lo), _ptr(self.vflat, lo),
+                                         hi - lo, float(lr_t), beta_1, beta_2, epsilon, float(grad_scale), self._stream())
+        tail, self._tail = getattr(self, '_tail', None), None
+        l0 = self.layers[0]
+        lo = l0.off['k'][0]
+        hi = l0.off['b'][0] + l0.cout
+        if tail is not None and lo % 4 == 0 and hi % 4 == 0 and hi <= self.n_train and l0.name not in self.wp_fwd:
+            # backward(defer_tail=True): the weight-gradient stream is still on the first layer's weight / bias gradient
+            # (228 us at the benchmark size, with nothing left for the main stream).  Everything else is complete at `tail`:
+            # its Adam update and the re-pack of the split-fp16 weight images (the first layer has none) run underneath,
+            # the first layer's 320 parameters follow the join.
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(tail)
+            adam(0, lo)
+            adam(hi, self.n_train)
+            self._packed_dirty = True
+            self.repack()
+            main.wait_stream(self._side_stream)
+            adam(lo, hi)
+        else:
+            if tail is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self._side_stream)
+            adam(0, self.n_train)
+            self._packed_dirty = True
         self.iterations = t
-        self._packed_dirty = True
         self._fold_dirty = True
 
     def read_sums(self):
