@@ -53,6 +53,13 @@ def parse_header(path=HEADER):
     return protos
 
 
+def header_abi_version(path=HEADER):
+    m = re.search(r'^#define\s+DC_ABI_VERSION\s+(\d+)', open(path).read(), flags=re.M)
+    if not m:
+        raise DcunetError('include/dcunet.h carries no DC_ABI_VERSION')
+    return int(m.group(1))
+
+
 class _Lib(object):
     def __init__(self, path=LIB_PATH):
         if not os.path.exists(path):
@@ -61,6 +68,13 @@ class _Lib(object):
         self.path = path
         self.cdll = ctypes.CDLL(path)
         self.protos = parse_header()
+        # the header's argument lists are only valid for a library of the same ABI revision (DC_LIB_PATH A/B builds!)
+        want = header_abi_version()
+        self.cdll.dc_version.restype = ctypes.c_int
+        got = self.cdll.dc_version()
+        if got != want:
+            raise DcunetError('%s is ABI revision %d, include/dcunet.h declares DC_ABI_VERSION %d -- rebuild the library '
+                              '(`python -m deep_calcium_amd._build --force`)' % (path, got, want))
         # names whose int return is a count/size, not a status code
         self._plain = set(n for n, (rt, _, _) in self.protos.items()
                           if rt is not ctypes.c_int or n.endswith('_tiles') or n.endswith('_blocks') or n.endswith('_floats') or n == 'dc_version')

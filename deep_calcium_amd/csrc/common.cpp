@@ -1,8 +1,6 @@
 // Error reporting, version and HIP-event timing helpers of libdcunet.
 #include "common.h"
 #include <stdlib.h>
-#include <map>
-#include <utility>
 
 static thread_local char g_err[512] = "";
 
@@ -23,32 +21,7 @@ const DcConfig& dc_config() {
   return cfg;
 }
 
-int dc_stream_ws(hipStream_t stream, size_t bytes, void** out) {
-  struct Buf { void* ptr; size_t size; };
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, Buf> table;
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  DC_REQUIRE(e == hipSuccess, DC_EHIP, "dc_stream_ws: hipGetDevice: %s", hipGetErrorString(e));
-  std::lock_guard<std::mutex> lock(mu);
-  Buf& b = table[{dev, stream}];
-  if (b.size < bytes) {
-    if (b.ptr) {
-      e = hipStreamSynchronize(stream);
-      DC_REQUIRE(e == hipSuccess, DC_EHIP, "dc_stream_ws: hipStreamSynchronize: %s", hipGetErrorString(e));
-      (void)hipFree(b.ptr);
-      b.ptr = nullptr; b.size = 0;
-    }
-    const size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
-    e = hipMalloc(&b.ptr, want);
-    DC_REQUIRE(e == hipSuccess, DC_EHIP, "dc_stream_ws: hipMalloc(%zu): %s", want, hipGetErrorString(e));
-    b.size = want;
-  }
-  *out = b.ptr;
-  return DC_OK;
-}
-
-extern "C" int dc_version(void) { return 101; }
+extern "C" int dc_version(void) { return DC_ABI_VERSION; }
 extern "C" const char* dc_last_error(void) { return g_err; }
 
 extern "C" int dc_event_create(void** ev) {

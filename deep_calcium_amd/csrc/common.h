@@ -19,12 +19,6 @@ void dc_set_error(const char* fmt, ...);
 struct DcConfig { int igemm_pp; };
 const DcConfig& dc_config();
 
-// A growable scratch buffer per (device, stream) for launches that need one the C ABI does not pass (the split-K slabs of the
-// narrow conv layers): launches on one stream are serialised, so they may share it; launches on different streams never do.
-// Allocated / grown on demand (hipMalloc, the old buffer is freed after a stream synchronise): make the first call of a
-// shape on a stream outside any stream capture.
-int dc_stream_ws(hipStream_t stream, size_t bytes, void** out);
-
 #define DC_REQUIRE(cond, code, ...)        \
   do {                                     \
     if (!(cond)) {                         \

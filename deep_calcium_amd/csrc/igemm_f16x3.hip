@@ -582,11 +582,13 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
 }
 
 template <int KH, int KW, int S, int PAD, int TW, int WAVES_M, int MB, int NB, int CK_ = 16, bool BNRED = false>
-static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name) {
+static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name, long* query = nullptr) {
+  // query != NULL: no launch, no HIP call -- *query = floats of split-K scratch this launch would use (0: it never splits)
   using Cfg = IgemmH<KH, KW, S, PAD, TW, WAVES_M, MB, NB, CK_>;
   auto kern = igemm_f16x3_kernel<KH, KW, S, PAD, TW, WAVES_M, MB, NB, CK_, BNRED>;
   static DcLdsAttr lds_attr;      // one per template instantiation; per-device inside
-  if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES + 8 * 1024, name)) return rc;
+  if (!query)
+    if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES + 8 * 1024, name)) return rc;
   p.tilesX = dc_cdiv(p.Wout, TW);
   p.tilesY = dc_cdiv(p.Hout, Cfg::TH);
   p.walk = dc_tile_walk();
@@ -606,12 +608,14 @@ static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name) {
     split = split > 4 ? 4 : split;
     split = split > nch / 2 ? nch / 2 : split;
   }
-  if (split > 1) {
+  if (query) {
+    *query = split > 1 ? (long)p.N * p.Hout * p.Wout * p.Ncols * split : 0;
+    return DC_OK;
+  }
+  if (split > 1 && p.splitWs != nullptr) {        // the caller's scratch (dc_*_splitk_ws_floats()); none: one un-split launch
     const long slab = (long)p.N * p.Hout * p.Wout * p.Ncols;
-    void* ws = nullptr;
-    if (int rc = dc_stream_ws(st, (size_t)slab * split * sizeof(float), &ws)) return rc;
+    DC_REQUIRE(dc_aligned16(p.splitWs), DC_EINVAL, "%s: splitk_ws must be 16-byte aligned", name);
     IgemmParams q = p;
-    q.splitWs = reinterpret_cast<float*>(ws);
     q.splitSlab = slab;
     grid.y = (unsigned)split;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, q);
@@ -630,9 +634,11 @@ static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name) {
 // Same tile-shape choice (and therefore the same `tiles` count for the BN partials) as the fp32 kernel.
 bool dc_igemm_pp_serves(const IgemmParams& p);                         // igemm_pp.hip: persistent role-split variant
 int dc_igemm_pp_launch(IgemmParams p, hipStream_t st, const char* name);
-static int conv3x3_h_launch(IgemmParams p, hipStream_t st) {
-  if (dc_igemm_pp_serves(p)) return dc_igemm_pp_launch(p, st, "conv3x3_f16x3_pp");
+static int conv3x3_h_launch(IgemmParams p, hipStream_t st, long* query = nullptr) {
+  if (query) *query = 0;
+  if (dc_igemm_pp_serves(p)) return query ? DC_OK : dc_igemm_pp_launch(p, st, "conv3x3_f16x3_pp");
   if (p.Wout > 16) {
+    if (query) return DC_OK;                       // (the wide-tile instantiations carry no split-K code)
     if (p.Ncols <= 32) return igemm_h_launch<3, 3, 1, 1, 32, 4, 4, 1>(p, st, "conv3x3_f16x3");
     return igemm_h_launch<3, 3, 1, 1, 32, 4, 2, 2>(p, st, "conv3x3_f16x3");
   }
@@ -642,12 +648,12 @@ static int conv3x3_h_launch(IgemmParams p, hipStream_t st) {
   constexpr bool narrow = true;
   if (p.Wout > 8) {
     const long wgs = (long)p.N * dc_cdiv(p.Wout, 16) * dc_cdiv(p.Hout, 16) * dc_cdiv(p.Ncols, 64);
-    if (narrow && wgs < 256 && p.Ncols > 32) return igemm_h_launch<3, 3, 1, 1, 16, 4, 2, 1>(p, st, "conv3x3_f16x3");
-    return igemm_h_launch<3, 3, 1, 1, 16, 4, 2, 2>(p, st, "conv3x3_f16x3");
+    if (narrow && wgs < 256 && p.Ncols > 32) return igemm_h_launch<3, 3, 1, 1, 16, 4, 2, 1>(p, st, "conv3x3_f16x3", query);
+    return igemm_h_launch<3, 3, 1, 1, 16, 4, 2, 2>(p, st, "conv3x3_f16x3", query);
   }
   const long wgs = (long)p.N * dc_cdiv(p.Wout, 8) * dc_cdiv(p.Hout, 8) * dc_cdiv(p.Ncols, 128);
-  if (narrow && wgs < 256 && p.Ncols > 64) return igemm_h_launch<3, 3, 1, 1, 8, 2, 1, 1>(p, st, "conv3x3_f16x3");
-  return igemm_h_launch<3, 3, 1, 1, 8, 2, 1, 2>(p, st, "conv3x3_f16x3");
+  if (narrow && wgs < 256 && p.Ncols > 64) return igemm_h_launch<3, 3, 1, 1, 8, 2, 1, 1>(p, st, "conv3x3_f16x3", query);
+  return igemm_h_launch<3, 3, 1, 1, 8, 2, 1, 2>(p, st, "conv3x3_f16x3", query);
 }
 
 // Conv2DTranspose forward = a 1x1 contraction into 4*Cout columns with the scatter epilogue.  The tile shapes
@@ -681,13 +687,15 @@ static int convT_dgrad_bnred_h_launch(IgemmParams p, hipStream_t st) {
   if (p.Ncols >= 128) return igemm_h_launch<2, 2, 2, 0, 32, 4, 1, 4, 16, true>(p, st, "convT2x2_dgrad_bnred_f16x3");
   return igemm_h_launch<2, 2, 2, 0, 32, 4, 1, 2, 16, true>(p, st, "convT2x2_dgrad_bnred_f16x3");
 }
-static int convT_dgrad_h_launch(IgemmParams p, hipStream_t st) {
+static int convT_dgrad_h_launch(IgemmParams p, hipStream_t st, long* query = nullptr) {
+  if (query) *query = 0;
   // >= 128 columns: 128-column workgroups (each staged dz chunk feeds twice the MFMAs: 82 -> 70 us on the deep layers; the
   // same widening of the conv-transpose FORWARD, 8 accumulator blocks per wave, ran twice as slow)
+  if (p.Wout > 16 && query) return DC_OK;
   if (p.Wout > 16 && p.Ncols >= 128) return igemm_h_launch<2, 2, 2, 0, 32, 4, 1, 4>(p, st, "convT2x2_dgrad_f16x3");
   if (p.Wout > 16) return igemm_h_launch<2, 2, 2, 0, 32, 4, 1, 2>(p, st, "convT2x2_dgrad_f16x3");
-  if (p.Wout > 8) return igemm_h_launch<2, 2, 2, 0, 16, 4, 1, 2>(p, st, "convT2x2_dgrad_f16x3");
-  return igemm_h_launch<2, 2, 2, 0, 8, 2, 1, 2>(p, st, "convT2x2_dgrad_f16x3");
+  if (p.Wout > 8) return igemm_h_launch<2, 2, 2, 0, 16, 4, 1, 2>(p, st, "convT2x2_dgrad_f16x3", query);
+  return igemm_h_launch<2, 2, 2, 0, 8, 2, 1, 2>(p, st, "convT2x2_dgrad_f16x3", query);
 }
 
 // dst (fp16 pairs, same byte size as the fp32 source) + a 16-byte trailer {w_scale, max|src| bits, 0, 0}:
@@ -817,7 +825,7 @@ static int check_h(const char* fn, const void* a, const void* b, const void* c, 
 extern "C" int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld,
                                     double* stats, const float* scale, const float* shift, int relu,
                                     const float* in_abound, long in_abound_ld, float* out_absmax, long out_absmax_ld,
-                                    int N, int H, int W, int Cin, int Cout,
+                                    float* splitk_ws, int N, int H, int W, int Cin, int Cout,
                                     dc_stream_t stream) {
   int rc = check_h("dc_conv3x3_fwd_f16x3", x, wp16, z, N, H, W, Cin, Cout);
   if (rc) return rc;
@@ -829,14 +837,41 @@ extern "C" int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const floa
   p.scale = scale; p.shift = shift; p.inAbound = in_abound; p.inAboundLd = in_abound_ld;
   p.outAbsmax = out_absmax; p.outAbsmaxLd = out_absmax_ld;
   p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = Cout;
-  p.relu = relu; p.scatterCo = 0; p.biasMod = Cout; p.outLd = z_ld;
+  p.relu = relu; p.scatterCo = 0; p.biasMod = Cout; p.outLd = z_ld; p.splitWs = splitk_ws;
   return conv3x3_h_launch(p, (hipStream_t)stream);
+}
+
+// Split-K scratch of a conv3x3 launch (dcunet.h): the routing and split decision of conv3x3_h_launch / igemm_h_launch for the
+// only launch forms that split -- the training forward (bias + BatchNorm partials, no fused epilogue) and the plain data gradient.
+extern "C" long dc_conv3x3_splitk_ws_floats(int N, int H, int W, int Cin, int Cout, int dgrad) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  float dummy = 1.f;
+  double dstat = 0.0;
+  IgemmParams p{};
+  p.N = N; p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W;
+  if (dgrad) { p.Cin = Cout; p.Ncols = Cin; p.inScale = &dummy; }
+  else { p.Cin = Cin; p.Ncols = Cout; p.stats = &dstat; }
+  p.biasMod = p.Ncols; p.outLd = p.Ncols;
+  long need = 0;
+  if (conv3x3_h_launch(p, nullptr, &need) != DC_OK) return 0;
+  return need;
+}
+extern "C" long dc_convT2x2_dgrad_splitk_ws_floats(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  float dummy = 1.f;
+  IgemmParams p{};
+  p.inScale = &dummy;
+  p.N = N; p.Hin = 2 * H; p.Win = 2 * W; p.Cin = Cout; p.Hout = H; p.Wout = W; p.Ncols = Cin;
+  p.biasMod = Cin; p.outLd = Cin;
+  long need = 0;
+  if (convT_dgrad_h_launch(p, nullptr, &need) != DC_OK) return 0;
+  return need;
 }
 
 extern "C" int dc_conv3x3_fwd_bnin_f16x3(const float* z_in, const float* in_sc, const float* in_sh, const float* in_abound,
     const void* wp16, const float* bias, float* z, long z_ld, double* stats, const float* scale,
-                                         const float* shift, int relu, int N, int H, int W, int Cin, int Cout,
-                                         dc_stream_t stream) {
+                                         const float* shift, int relu, float* splitk_ws, int N, int H, int W, int Cin,
+                                         int Cout, dc_stream_t stream) {
   int rc = check_h("dc_conv3x3_fwd_bnin_f16x3", z_in, wp16, z, N, H, W, Cin, Cout);
   if (rc) return rc;
   DC_REQUIRE(in_sc && in_sh, DC_EINVAL, "dc_conv3x3_fwd_bnin_f16x3: null input scale/shift");
@@ -846,7 +881,7 @@ extern "C" int dc_conv3x3_fwd_bnin_f16x3(const float* z_in, const float* in_sc, 
   p.in = z_in; p.wp = reinterpret_cast<const float*>(wp16); p.bias = bias; p.out = z; p.stats = stats;
   p.scale = scale; p.shift = shift; p.inSc = in_sc; p.inSh = in_sh; p.inAbound = in_abound;
   p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = Cout;
-  p.relu = relu; p.scatterCo = 0; p.biasMod = Cout; p.outLd = z_ld;
+  p.relu = relu; p.scatterCo = 0; p.biasMod = Cout; p.outLd = z_ld; p.splitWs = splitk_ws;
   return conv3x3_h_launch(p, (hipStream_t)stream);
 }
 
@@ -873,7 +908,7 @@ static int check_absmax(const char* fn, const float* in_scale, const float* in_a
   return DC_OK;
 }
 extern "C" int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
-                                      const float* in_absmax, int in_absmax_n, int N, int H,
+                                      const float* in_absmax, int in_absmax_n, float* splitk_ws, int N, int H,
                                       int W, int Cin, int Cout, dc_stream_t stream) {
   int rc = check_h("dc_conv3x3_dgrad_f16x3", dz, wp16, dx, N, H, W, Cout, Cin);
   if (rc) return rc;
@@ -882,7 +917,7 @@ extern "C" int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* 
   p.in = dz; p.wp = reinterpret_cast<const float*>(wp16); p.out = dx; p.inScale = in_scale;
   p.inAbsmax = in_absmax; p.inAbsmaxN = in_absmax_n;
   p.N = N; p.Hin = H; p.Win = W; p.Cin = Cout; p.Hout = H; p.Wout = W; p.Ncols = Cin;
-  p.biasMod = Cin; p.outLd = Cin;
+  p.biasMod = Cin; p.outLd = Cin; p.splitWs = splitk_ws;
   return conv3x3_h_launch(p, (hipStream_t)stream);
 }
 
@@ -1021,7 +1056,7 @@ extern "C" int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const flo
 }
 
 extern "C" int dc_convT2x2_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* in_scale,
-                                       const float* in_absmax, int in_absmax_n, int N, int H,
+                                       const float* in_absmax, int in_absmax_n, float* splitk_ws, int N, int H,
                                        int W, int Cin, int Cout, dc_stream_t stream) {
   int rc = check_h("dc_convT2x2_dgrad_f16x3", dz, wp16, dx, N, H, W, Cout, Cin);
   if (rc) return rc;
@@ -1030,7 +1065,7 @@ extern "C" int dc_convT2x2_dgrad_f16x3(const float* dz, const void* wp16, float*
   p.in = dz; p.wp = reinterpret_cast<const float*>(wp16); p.out = dx; p.inScale = in_scale;
   p.inAbsmax = in_absmax; p.inAbsmaxN = in_absmax_n;
   p.N = N; p.Hin = 2 * H; p.Win = 2 * W; p.Cin = Cout; p.Hout = H; p.Wout = W; p.Ncols = Cin;
-  p.biasMod = Cin; p.outLd = Cin;
+  p.biasMod = Cin; p.outLd = Cin; p.splitWs = splitk_ws;
   return convT_dgrad_h_launch(p, (hipStream_t)stream);
 }
 

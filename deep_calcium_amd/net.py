@@ -502,7 +502,7 @@ class UNetEngine(object):
             return self._ab_in(l, True) + self._ab_out(l, True)
         return None, 0, self._ovf.data_ptr(), -1
 
-    def _conv_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None, measured=False):
+    def _conv_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None, measured=False, splitk=None):
         """bnin = (scale_ptr, shift_ptr): x is the producer's pre-BN tensor, BN + ReLU are applied on load.
         measured: inference -- the input bound is a measured one (8 replicas) and the epilogue folds max |output| per
         channel into the output's replicas (the next layer's range-guard bound)."""
@@ -512,10 +512,10 @@ class UNetEngine(object):
             ab_in, ab_in_ld, ab_out, ab_out_ld = self._ab_in(l), 0, None, 0
         if bnin is not None:
             self.L.dc_conv3x3_fwd_bnin_f16x3(x, bnin[0], bnin[1], self._ab_in(l), _ptr(self.wp_fwd[l.name]), bias, z, z_ld,
-                                             stats, sc, sh, relu, N, h, w, l.cin, l.cout, st)
+                                             stats, sc, sh, relu, splitk, N, h, w, l.cin, l.cout, st)
         elif self.mfma == 'f16x3':
             self.L.dc_conv3x3_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu, ab_in, ab_in_ld,
-                                        ab_out, ab_out_ld, N, h, w, l.cin, l.cout, st)
+                                        ab_out, ab_out_ld, splitk, N, h, w, l.cin, l.cout, st)
         else:
             self.L.dc_conv3x3_fwd(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu,
                                   N, h, w, l.cin, l.cout, st)
@@ -828,6 +828,16 @@ class UNetEngine(object):
             elif l.kind == 'convT':
                 h, w = self._hw(l.lvl)
                 part_floats = max(part_floats, L.dc_convT2x2_dgrad_bnred_blocks(N, h // 2, w // 2, l.cin, l.cout) * l.cin * 2)
+        # split-K slabs of the narrow conv layers (forward and data gradients all run on the caller's stream: one workspace)
+        sk = 4
+        for l in self.layers:
+            if l.kind == 'conv' and l.cin > 1 and self.mfma == 'f16x3':
+                h, w = self._hw(l.lvl)
+                sk = max(sk, L.dc_conv3x3_splitk_ws_floats(N, h, w, l.cin, l.cout, 0), L.dc_conv3x3_splitk_ws_floats(N, h, w, l.cin, l.cout, 1))
+            elif l.kind == 'convT' and self.mfma == 'f16x3':
+                h, w = self._hw(l.lvl)
+                sk = max(sk, L.dc_convT2x2_dgrad_splitk_ws_floats(N, h // 2, w // 2, l.cin, l.cout))
+        T['splitk_ws'] = torch.empty(sk, dtype=torch.float32, device=dev)
         T['stats_ws'] = torch.empty(stats_floats, dtype=torch.float64, device=dev)      # (sum, sum of squares) partials
         T['part_ws'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['part_ws2'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
@@ -906,6 +916,7 @@ class UNetEngine(object):
                         h, w = self._hw(lvl)
                         self._check_input("masks['u%d']" % lvl, masks.get('u%d' % lvl), torch.uint8, (N, h, w, self._cup(lvl)))
         L, st = self.L, self._stream()
+        self._settle_tail()
         self.repack()
         A, T = self._acts(N), self._train_bufs(N)
         step_seed = self.drop_seed + self.iterations
@@ -942,7 +953,7 @@ class UNetEngine(object):
                                     None, None, 0, None, 0, N, h, w, l.cout, st)
             elif l.kind == 'conv':
                 tiles = L.dc_conv3x3_tiles(N, h, w, l.cout)
-                self._conv_fwd(xin, l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h, w, st, bnin=bn)
+                self._conv_fwd(xin, l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h, w, st, bnin=bn, splitk=_ptr(T['splitk_ws']))
             else:
                 tiles = (L.dc_convT2x2_f16x3_tiles if self.mfma == 'f16x3' else L.dc_convT2x2_tiles)(N, h // 2, w // 2, l.cout)
                 groups = 4
@@ -1057,7 +1068,7 @@ class UNetEngine(object):
         N, masks, step_seed, x_dev, y_dev = self._last
         L, st = self.L, self._stream()
         A, T = self._acts(N), self._train_bufs(N)
-        self._tail = None
+        self._settle_tail()
         nfb = self.nfb
         f16 = self.mfma == 'f16x3'
         pixels0 = N * self.H * self.W
@@ -1238,7 +1249,7 @@ class UNetEngine(object):
                                                            _ptr(T['part_ws']), _ptr(T['amax_ws']), N, h, w, l.cin, l.cout, st)
                             return (_ptr(T['part_ws']), _ptr(T['amax_ws']), rows)
                     if f16:
-                        L.dc_conv3x3_dgrad_f16x3(dz, wpd, dx_ptr, d_scale, d_amax, d_amax_n, N, h, w, l.cin, l.cout, st)
+                        L.dc_conv3x3_dgrad_f16x3(dz, wpd, dx_ptr, d_scale, d_amax, d_amax_n, _ptr(T['splitk_ws']), N, h, w, l.cin, l.cout, st)
                     else:
                         L.dc_conv3x3_dgrad(dz, wpd, dx_ptr, N, h, w, l.cin, l.cout, st)
                 elif f16:
@@ -1249,7 +1260,7 @@ class UNetEngine(object):
                                                         self.pview(self.pflat, red, 'gamma'), self.pview(self.pflat, red, 'beta'),
                                                         _ptr(T['part_ws']), _ptr(T['amax_ws']), N, h // 2, w // 2, l.cin, l.cout, st)
                         return (_ptr(T['part_ws']), _ptr(T['amax_ws']), rows)
-                    L.dc_convT2x2_dgrad_f16x3(dz, wpd, dx_ptr, d_scale, d_amax, d_amax_n, N, h // 2, w // 2, l.cin, l.cout, st)
+                    L.dc_convT2x2_dgrad_f16x3(dz, wpd, dx_ptr, d_scale, d_amax, d_amax_n, _ptr(T['splitk_ws']), N, h // 2, w // 2, l.cin, l.cout, st)
                 else:
                     L.dc_convT2x2_dgrad(dz, wpd, dx_ptr, N, h // 2, w // 2, l.cin, l.cout, st)
                 return None
@@ -1369,6 +1380,14 @@ class UNetEngine(object):
         if side is not None:
             torch.cuda.current_stream(self.device).wait_stream(side)
 
+    def _settle_tail(self):
+        """backward(defer_tail=True) returns with the weight-gradient stream still on the first layer's dW / db (it reads
+        x, z, g buffers and writes gflat); only adam_step() joins it underneath its own work.  Anything else that follows --
+        another forward_train / backward (an exception between the two calls of a step), grads() -- joins here first."""
+        if getattr(self, '_tail', None) is not None:
+            self._tail = None
+            self._join_side()
+
     @_on_device
     def adam_step(self, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-8, grad_scale=1.0):
         """Keras-2.0.6 Adam over the flat buffers; `iterations` counts completed steps."""
@@ -1411,6 +1430,8 @@ class UNetEngine(object):
 
     def grads(self):
         """gflat split per layer: {name: [dk, db, dgamma, dbeta]} (host numpy)."""
+        with torch.cuda.device(self.device):
+            self._settle_tail()
         g = self.gflat.cpu().numpy()
         out = {}
         for l in self.layers:

@@ -18,6 +18,7 @@ Host-side numpy; not part of the GPU path.
 import json
 import logging
 import os
+import threading
 import time
 import shutil
 from glob import glob
@@ -109,10 +110,16 @@ def _download(name, datasets_dir, logger):
     shutil.rmtree(stage, ignore_errors=True)
 
 
-def nf_load_hdf5(names, datasets_dir=None, wait_s=6 * 3600.0):
+def _run_token():
+    """Identifies THIS launch to the ranks that wait on rank 0's dataset build: the launcher's run id / rendezvous endpoint
+    (the same on every rank of a job, different for a relaunch)."""
+    return (os.environ.get('TORCHELASTIC_RUN_ID') or 'run') + '@' + os.environ.get('MASTER_ADDR', '-') + ':' + os.environ.get('MASTER_PORT', '-')
+
+
+def nf_load_hdf5(names, datasets_dir=None, wait_s=6 * 3600.0, stale_s=120.0):
     """Returns the list of `dataset.hdf5` paths for `names` ('all' | 'all_train' | 'all_test' | 'a,b' | list), building
     the files that do not exist yet.  nf.py:37-150.  Under data parallelism EVERY rank calls it (rank 0 builds, the others
-    poll for the finished files for at most wait_s seconds)."""
+    poll for the finished files for at most wait_s seconds, and give up after stale_s without a heartbeat from rank 0)."""
     logger = logging.getLogger('nf_load_hdf5')
     if datasets_dir is None:
         datasets_dir = '%s/neurons_nf' % default_dirs()[0]         # nf.py:37
@@ -128,8 +135,28 @@ def nf_load_hdf5(names, datasets_dir=None, wait_s=6 * 3600.0):
     from . import parallel
     dataset_paths = ['%s/%s/dataset.hdf5' % (datasets_dir, name) for name in dataset_names]
     marker = '%s/.nf_build_failed' % datasets_dir
-    t_start = time.time()
+    beat = '%s/.nf_build_heartbeat' % datasets_dir
+    token = _run_token()
     if parallel.rank() == 0:
+        todo = [q for q in dataset_paths if not os.path.exists(q)]
+        stop = threading.Event()
+        th = None
+        if todo and parallel.world_size() > 1:
+            # liveness for the waiting ranks: a counter rank 0 bumps every second while it builds (they watch it CHANGE, by
+            # their own monotonic clock: no cross-host clock comparison)
+            def pulse():
+                k = 0
+                while not stop.is_set():
+                    k += 1
+                    try:
+                        with open(beat + '.tmp', 'w') as fp:
+                            fp.write('%s %d' % (token, k))
+                        os.replace(beat + '.tmp', beat)
+                    except OSError:
+                        pass
+                    stop.wait(1.0)
+            th = threading.Thread(target=pulse, daemon=True)
+            th.start()
         try:
             if os.path.exists(marker):
                 os.remove(marker)
@@ -141,21 +168,47 @@ def nf_load_hdf5(names, datasets_dir=None, wait_s=6 * 3600.0):
                 if not os.path.exists(ds_path):
                     logger.info('Populating %s.' % ds_path)
                     _populate(name, '%s/%s' % (datasets_dir, name), ds_path)
-        except Exception as e:           # tell the waiting ranks, then fail here
+        except Exception as e:           # tell the waiting ranks (this run's token, not a timestamp), then fail here
             try:
                 with open(marker, 'w') as fp:
-                    fp.write('%s: %s' % (type(e).__name__, e))
+                    fp.write('%s\n%s: %s' % (token, type(e).__name__, e))
             except OSError:
                 pass
             raise
+        finally:
+            stop.set()
+            if th is not None:
+                th.join(timeout=5)
+                try:
+                    os.remove(beat)
+                except OSError:
+                    pass
     elif parallel.world_size() > 1:
-        limit = float(wait_s)
+        t_start = time.monotonic()
+        last_beat, last_change = None, time.monotonic()
         while not all(os.path.exists(q) for q in dataset_paths):
-            if os.path.exists(marker) and os.path.getmtime(marker) >= t_start - 1.0:
-                raise IOError('rank %d: rank 0 failed to build the datasets: %s' % (parallel.rank(), open(marker).read()))
-            if time.time() - t_start > limit:
+            if os.path.exists(marker):
+                try:
+                    head, _, msg = open(marker).read().partition('\n')
+                except OSError:
+                    head, msg = '', ''
+                if head == token:
+                    raise IOError('rank %d: rank 0 failed to build the datasets: %s' % (parallel.rank(), msg))
+            try:
+                cur = open(beat).read()
+            except OSError:
+                cur = None
+            now = time.monotonic()
+            if cur is not None and cur.split(' ')[0] == token and cur != last_beat:
+                last_beat, last_change = cur, now
+            # rank 0 gone (SIGKILL, OOM) or the directory is not shared: its heartbeat stopped / never showed up
+            if now - last_change > stale_s:
+                raise IOError('rank %d: no sign of life from rank 0 in %s for %.0f s (%s) -- is it running, and is the directory '
+                              'shared between the ranks?' % (parallel.rank(), datasets_dir, stale_s,
+                                                             'heartbeat stopped' if last_beat else 'no heartbeat seen'))
+            if now - t_start > float(wait_s):
                 raise IOError('rank %d: %s still missing after %.0f s' % (
-                    parallel.rank(), ', '.join(q for q in dataset_paths if not os.path.exists(q)), limit))
+                    parallel.rank(), ', '.join(q for q in dataset_paths if not os.path.exists(q)), float(wait_s)))
             time.sleep(0.2)
     missing = [q for q in dataset_paths if not os.path.exists(q)]
     if missing:

@@ -15,7 +15,8 @@
  *     addresses channel c of pixel i at p[i*ld + c] (lets producers write into
  *     channel slices of a concat buffer; pass ld == C for a dense tensor).
  *   - The library never allocates, frees or retains memory; workspaces are
- *     caller-allocated (sizes from the *_ws_floats helpers).
+ *     caller-allocated (sizes from the *_ws_floats helpers).  There is no
+ *     hipMalloc / hipFree / hipStreamSynchronize anywhere in the library.
  *   - Every launch is asynchronous on `stream` (a hipStream_t passed as void*;
  *     NULL = the legacy default stream).  The caller sets the device.
  *   - Return value: 0 OK, -1 invalid argument/shape/alignment, -2 HIP runtime
@@ -32,6 +33,9 @@ extern "C" {
 
 typedef void* dc_stream_t;
 
+/* ABI revision: dc_version() of the loaded library must EQUAL the DC_ABI_VERSION of the header the caller was built /
+ * bound against (argument lists change between revisions; the Python binding refuses a mismatch). */
+#define DC_ABI_VERSION 102
 int dc_version(void);
 const char* dc_last_error(void);
 
@@ -91,9 +95,10 @@ int dc_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* ws,
  *   activations are O(1), so this path normally runs with no guard traffic at all.
  *   Narrow launches (images of at most 16 x 16 pixels whose grid would leave most of the chip idle: the 256- / 512-channel
  *   layers of a 128^2 / 96^2 training window) are split over K into 2-4 slabs and combined by a second launch in a fixed
- *   order (bit-reproducible; dc_conv3x3_tiles() rows unchanged).  The slabs live in a scratch buffer the library keeps per
- *   (device, stream), allocated / grown with hipMalloc on first use: issue the first call of a shape on a stream outside
- *   any stream capture. */
+ *   order (bit-reproducible; dc_conv3x3_tiles() rows unchanged).  The slabs live in the CALLER's `splitk_ws`
+ *   (float[dc_conv3x3_splitk_ws_floats()] / float[dc_convT2x2_dgrad_splitk_ws_floats()]; 0 floats: this shape never
+ *   splits); splitk_ws == NULL: the launch is not split (same result up to summation order).  One workspace serves the
+ *   launches of ONE stream: launches on different streams that may run concurrently need their own. */
 #define DC_ABOUND_SLOTS 8
 long dc_pack_weights_f16x3_floats(int taps, int K, int Ncols);
 int dc_pack_weights_f16x3(const float* src, void* dst, int taps, int K, int Ncols,
@@ -102,21 +107,26 @@ int dc_pack_weights_f16x3(const float* src, void* dst, int taps, int K, int Ncol
  *   { src pointer, dst pointer, taps, K, Ncols, s_tap, s_k, s_n, flip, first block of the job };
  * the trailing sentinel entry only carries the grid size (= total_blocks) in its last field. */
 int dc_pack_weights_f16x3_batch(const long* jobs_dev, int njobs, int total_blocks, dc_stream_t stream);
+/* floats of split-K scratch a conv3x3 launch of this shape may use: forward incl. the _bnin variant (dgrad == 0) or plain
+ * data gradient (dgrad != 0). */
+long dc_conv3x3_splitk_ws_floats(int N, int H, int W, int Cin, int Cout, int dgrad);
+long dc_convT2x2_dgrad_splitk_ws_floats(int N, int H, int W, int Cin, int Cout);
 int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, double* stats,
                          const float* scale, const float* shift, int relu, const float* in_abound, long in_abound_ld,
-                         float* out_absmax, long out_absmax_ld, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+                         float* out_absmax, long out_absmax_ld, float* splitk_ws, int N, int H, int W, int Cin, int Cout,
+                         dc_stream_t stream);
 /* data gradients: the power-of-two scale of dz comes EITHER as a device scalar (dz_scale, from dc_pow2_scale_from_absmax /
  * dc_bn_bwd_apply_finalize; nullable = 1) OR as the per-block max |dz| array dc_bn_bwd_apply wrote (dz_absmax[dz_absmax_n]):
  * every workgroup then derives the same power of two itself (target 1024), and no finalize launch sits between the
  * BatchNorm-backward apply pass and the data gradient.  Pass at most one of the two. */
 int dc_conv3x3_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* dz_scale,
-                           const float* dz_absmax, int dz_absmax_n,
+                           const float* dz_absmax, int dz_absmax_n, float* splitk_ws,
                            int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 int dc_convT2x2_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, double* stats,
                           const float* scale, const float* shift, int relu, const float* in_abound, long in_abound_ld,
                           float* out_absmax, long out_absmax_ld, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 int dc_convT2x2_dgrad_f16x3(const float* dz, const void* wp16, float* dx, const float* dz_scale,
-                            const float* dz_absmax, int dz_absmax_n,
+                            const float* dz_absmax, int dz_absmax_n, float* splitk_ws,
                             int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
 /* BatchNorm-partial rows (`tiles`) of the split-fp16 conv-transpose forward: it runs wider column blocks than the fp32 kernel
  * (256 / 128 columns per workgroup: each staged input tile feeds 4x / 2x the MFMAs) on correspondingly flatter pixel tiles,
@@ -145,7 +155,8 @@ int dc_bn_stats_finalize_affine(const double* partial, int parts, int groups, in
                                 dc_stream_t stream);
 int dc_conv3x3_fwd_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const float* in_abound,
                               const void* wp16, const float* bias, float* z, long z_ld, double* stats, const float* scale,
-                              const float* shift, int relu, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);
+                              const float* shift, int relu, float* splitk_ws, int N, int H, int W, int Cin, int Cout,
+                              dc_stream_t stream);
 int dc_convT2x2_fwd_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const float* in_abound,
                                const void* wp16, const float* bias, float* z, long z_ld, double* stats, const float* scale,
                                const float* shift, int relu, int N, int H, int W, int Cin, int Cout, dc_stream_t stream);

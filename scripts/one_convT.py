@@ -24,7 +24,7 @@ for HW, Ci, Co in [(256, 64, 32), (128, 128, 64), (64, 256, 128), (32, 512, 256)
     stats = torch.zeros(L.dc_convT2x2_tiles(N, HW, HW, Co) * 4 * Co * 2 * 16 + 1024, device='cuda')
     dw = torch.empty(4 * Ci * Co, device='cuda'); ws = torch.empty(L.dc_convT2x2_wgrad_ws_floats(N, HW, HW, Ci, Co), device='cuda')
     f = lambda: L.dc_convT2x2_fwd_f16x3(x.data_ptr(), wf.data_ptr(), None, z.data_ptr(), Co, stats.data_ptr(), None, None, 0, None, 0, None, 0, N, HW, HW, Ci, Co, None)
-    d = lambda: L.dc_convT2x2_dgrad_f16x3(dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), one.data_ptr(), None, 0, N, HW, HW, Ci, Co, None)
+    d = lambda: L.dc_convT2x2_dgrad_f16x3(dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), one.data_ptr(), None, 0, None, N, HW, HW, Ci, Co, None)
     w = lambda: L.dc_convT2x2_wgrad_f16x3(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), one.data_ptr(), None, N, HW, HW, Ci, Co, None)
     tf, td, tw = timeit(f), timeit(d), timeit(w)
     floor = (x.numel() + z.numel()) * 4 / 6.3e9

@@ -21,6 +21,26 @@ def test_library_exports_every_declared_symbol(dclib):
     assert exported == set(protos), exported ^ set(protos)
 
 
+def test_library_never_allocates_or_synchronises():
+    """dcunet.h: 'the library never allocates, frees or retains memory' and every launch is asynchronous -- no hipMalloc /
+    hipFree / hipStreamSynchronize / hipDeviceSynchronize anywhere under csrc/ (round 4 had a library-owned split-K scratch)."""
+    root = os.path.join(os.path.dirname(__file__), '..', 'deep_calcium_amd', 'csrc')
+    for f in sorted(os.listdir(root)):
+        src = open(os.path.join(root, f)).read()
+        src = re.sub(r'//.*', '', src)
+        src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+        for word in ('hipMalloc', 'hipFree', 'hipStreamSynchronize', 'hipDeviceSynchronize', 'hipMallocAsync', 'hipHostMalloc'):
+            assert word not in src, '%s calls %s' % (f, word)
+
+
+def test_abi_version_matches_the_header(dclib):
+    from deep_calcium_amd import _lib
+    assert dclib.dc_version() == _lib.header_abi_version() >= 102
+    assert dclib.dc_conv3x3_splitk_ws_floats(20, 16, 16, 256, 256, 0) == 3 * 20 * 16 * 16 * 256      # 160 workgroups x 3 slabs
+    assert dclib.dc_conv3x3_splitk_ws_floats(16, 512, 512, 32, 32, 0) == 0
+    assert dclib.dc_convT2x2_dgrad_splitk_ws_floats(20, 8, 8, 512, 256) >= 0
+
+
 def test_header_cites_reference_call_sites():
     src = open(os.path.join(os.path.dirname(__file__), '..', 'include', 'dcunet.h')).read()
     assert 'unet_2d_summary.py:123-224' in src and 'unet_2d_summary.py:164-165' in src and ':156-157' in src
@@ -28,7 +48,7 @@ def test_header_cites_reference_call_sites():
 
 def test_host_side_helpers_run_without_gpu(dclib):
     L = dclib
-    assert L.dc_version() >= 100
+    assert L.dc_version() >= 102
     assert L.dc_conv3x3_tiles(16, 512, 512, 32) == 16 * 32 * 16          # 512px x 32col tiles
     assert L.dc_conv3x3_tiles(16, 256, 256, 64) == 16 * 32 * 8           # 256px x 64col tiles
     assert L.dc_convT2x2_tiles(2, 32, 32, 256) == 2 * 4

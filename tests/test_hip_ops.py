@@ -135,18 +135,33 @@ def test_conv3x3_f16x3_fwd_dgrad(dclib, N, H, W, Ci, Co):
     z = torch.full((N, H, W, Co), float('nan'), device='cuda')
     tiles = L.dc_conv3x3_tiles(N, H, W, Co)
     stats = torch.zeros(tiles * Co * 2, device='cuda', dtype=torch.float64)
+    # the caller owns the split-K slabs (dcunet.h): sized by the query, 0 floats = this shape never splits
+    skf, skd = L.dc_conv3x3_splitk_ws_floats(N, H, W, Ci, Co, 0), L.dc_conv3x3_splitk_ws_floats(N, H, W, Ci, Co, 1)
+    if (N, H, W, Ci, Co) in ((20, 16, 16, 256, 256), (20, 8, 8, 512, 512), (3, 12, 12, 200, 96)):
+        assert skf > 0 and skf % (N * H * W * Co) == 0 and 2 <= skf // (N * H * W * Co) <= 4
+    if W > 16:
+        assert skf == 0 and skd == 0
+    skws = torch.full((max(skf, skd, 4),), float('nan'), device='cuda')
     L.dc_conv3x3_fwd_f16x3(dev(x).data_ptr(), wp.data_ptr(), dev(b).data_ptr(), z.data_ptr(), Co, stats.data_ptr(),
-                           None, None, 0, None, 0, None, 0, N, H, W, Ci, Co, None)
+                           None, None, 0, None, 0, None, 0, skws.data_ptr(), N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert rel_err(z.cpu().numpy(), z_ref) < 2e-5
     st = stats.cpu().numpy().reshape(tiles, Co, 2).astype(np.float64).sum(0)
     assert np.allclose(st[:, 0], z_ref.sum((0, 1, 2)), rtol=1e-4, atol=1e-3 * np.sqrt(N * H * W))
     assert np.allclose(st[:, 1], (z_ref ** 2).sum((0, 1, 2)), rtol=1e-4)
+    if skf > 0:      # no workspace: ONE un-split launch -- same values up to the summation order, same statistics rows
+        z1 = torch.full((N, H, W, Co), float('nan'), device='cuda')
+        stats1 = torch.zeros(tiles * Co * 2, device='cuda', dtype=torch.float64)
+        L.dc_conv3x3_fwd_f16x3(dev(x).data_ptr(), wp.data_ptr(), dev(b).data_ptr(), z1.data_ptr(), Co, stats1.data_ptr(),
+                               None, None, 0, None, 0, None, 0, None, N, H, W, Ci, Co, None)
+        torch.cuda.synchronize()
+        assert rel_err(z1.cpu().numpy(), z_ref) < 2e-5 and not torch.equal(z, z1)
+        assert np.allclose(stats1.cpu().numpy(), stats.cpu().numpy(), rtol=1e-4, atol=1e-3)
     amax = dev(np.array([np.abs(dz).max()], np.float32))
     scl = torch.empty(1, device='cuda')
     L.dc_pow2_scale_from_absmax(amax.data_ptr(), 1, 1024.0, scl.data_ptr(), None)
     dx = torch.full((N, H, W, Ci), float('nan'), device='cuda')
-    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), scl.data_ptr(), None, 0, N, H, W, Ci, Co, None)
+    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), scl.data_ptr(), None, 0, skws.data_ptr(), N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert rel_err(dx.cpu().numpy(), dx_ref) < 2e-5
     # the scale derived IN the kernel from per-block maxima (what dc_bn_bwd_apply leaves behind; the true maximum sits in
@@ -154,11 +169,11 @@ def test_conv3x3_f16x3_fwd_dgrad(dclib, N, H, W, Ci, Co):
     part = np.full(37, np.abs(dz).max() * 0.3, np.float32)
     part[11] = np.abs(dz).max()
     dxa = torch.full((N, H, W, Ci), float('nan'), device='cuda')
-    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dxa.data_ptr(), None, dev(part).data_ptr(), 37, N, H, W, Ci, Co, None)
+    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dxa.data_ptr(), None, dev(part).data_ptr(), 37, skws.data_ptr(), N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert torch.equal(dx, dxa)
     with pytest.raises(Exception, match='not both'):
-        L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dxa.data_ptr(), scl.data_ptr(), dev(part).data_ptr(), 37, N, H, W, Ci, Co, None)
+        L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dxa.data_ptr(), scl.data_ptr(), dev(part).data_ptr(), 37, None, N, H, W, Ci, Co, None)
     ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, H, W, Ci, Co), device='cuda')
     dw = torch.full((3, 3, Ci, Co), float('nan'), device='cuda')
     L.dc_conv3x3_wgrad_f16x3(dev(x).data_ptr(), dev(dz).data_ptr(), dw.data_ptr(), ws.data_ptr(), scl.data_ptr(),
@@ -167,7 +182,7 @@ def test_conv3x3_f16x3_fwd_dgrad(dclib, N, H, W, Ci, Co):
     _, dK_ref, _ = on.conv3x3_bwd(x.astype(np.float64), K.astype(np.float64), dz.astype(np.float64))
     assert rel_err(dw.cpu().numpy(), dK_ref) < 2e-5
     # without the scale the same input underflows fp16 and the result is garbage-level: the scale is load-bearing
-    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, None, 0, N, H, W, Ci, Co, None)
+    L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, None, 0, None, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert rel_err(dx.cpu().numpy(), dx_ref) > 1e-3
 
@@ -211,10 +226,10 @@ def test_bn_relu_on_load_conv_convT_wgrad_head(dclib, N, H, W, Ci, Co):
     wp = torch.empty(L.dc_pack_weights_f16x3_floats(9, Ci, Co), device='cuda')
     L.dc_pack_weights_f16x3(Kd.data_ptr(), wp.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
     z1 = torch.full((N, H, W, Co), float('nan'), device='cuda'); z2 = torch.full_like(z1, float('nan'))
-    L.dc_conv3x3_fwd_f16x3(a.data_ptr(), wp.data_ptr(), None, z1.data_ptr(), Co, None, None, None, 0, ab.data_ptr(), 0, None, 0,
+    L.dc_conv3x3_fwd_f16x3(a.data_ptr(), wp.data_ptr(), None, z1.data_ptr(), Co, None, None, None, 0, ab.data_ptr(), 0, None, 0, None,
                            N, H, W, Ci, Co, None)
     L.dc_conv3x3_fwd_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), ab.data_ptr(), wp.data_ptr(), None,
-                                z2.data_ptr(), Co, None, None, None, 0, N, H, W, Ci, Co, None)
+                                z2.data_ptr(), Co, None, None, None, 0, None, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert torch.equal(z1, z2)                       # same operand bits -> same result bits
     z_ref = on.conv3x3_fwd(a_ref, K.astype(np.float64), np.zeros(Co))
@@ -385,7 +400,7 @@ def test_convT2x2(dclib, N, H, W, Ci, Co):
     torch.cuda.synchronize()
     assert torch.equal(zi, z2)
     dx2 = torch.full((N, H, W, Ci), float('nan'), device='cuda')
-    L.dc_convT2x2_dgrad_f16x3(dev(dzs).data_ptr(), wpd16.data_ptr(), dx2.data_ptr(), scl.data_ptr(), None, 0, N, H, W, Ci, Co, None)
+    L.dc_convT2x2_dgrad_f16x3(dev(dzs).data_ptr(), wpd16.data_ptr(), dx2.data_ptr(), scl.data_ptr(), None, 0, None, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert rel_err(z2.cpu().numpy(), z_ref) < 2e-5
     assert np.array_equal(amx.cpu().numpy(), np.abs(z2.cpu().numpy()).max((0, 1, 2)))
@@ -396,7 +411,7 @@ def test_convT2x2(dclib, N, H, W, Ci, Co):
     part = np.full(5, np.abs(dzs).max() * 0.5, np.float32)
     part[4] = np.abs(dzs).max()
     dx3 = torch.full((N, H, W, Ci), float('nan'), device='cuda')
-    L.dc_convT2x2_dgrad_f16x3(dev(dzs).data_ptr(), wpd16.data_ptr(), dx3.data_ptr(), None, dev(part).data_ptr(), 5, N, H, W, Ci, Co, None)
+    L.dc_convT2x2_dgrad_f16x3(dev(dzs).data_ptr(), wpd16.data_ptr(), dx3.data_ptr(), None, dev(part).data_ptr(), 5, None, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert torch.equal(dx2, dx3)                     # scale derived in the kernel from per-block maxima: same bits
     dw2 = torch.full((2, 2, Co, Ci), float('nan'), device='cuda')
@@ -570,7 +585,7 @@ def test_dgrad_with_fused_bn_backward_sums(dclib, N, H, W, Cin, Cout):
     ga = dev((rs.standard_normal(Cin)).astype(np.float32)); be = dev((rs.standard_normal(Cin) * 0.3).astype(np.float32))
     scale = torch.full((4,), 4.0, device='cuda')
     dx0 = torch.full((N, H, W, Cin), float('nan'), device='cuda'); dx1 = torch.full_like(dx0, float('nan'))
-    L.dc_conv3x3_dgrad_f16x3(dz.data_ptr(), wpd.data_ptr(), dx0.data_ptr(), scale.data_ptr(), None, 0, N, H, W, Cin, Cout, None)
+    L.dc_conv3x3_dgrad_f16x3(dz.data_ptr(), wpd.data_ptr(), dx0.data_ptr(), scale.data_ptr(), None, 0, None, N, H, W, Cin, Cout, None)
     part = torch.full((rows * Cin * 2,), float('nan'), device='cuda')
     amx = torch.full((rows * Cin,), float('nan'), device='cuda')
     L.dc_conv3x3_dgrad_bnred_f16x3(dz.data_ptr(), wpd.data_ptr(), dx1.data_ptr(), scale.data_ptr(), None, 0, z.data_ptr(), mu.data_ptr(),
@@ -640,7 +655,7 @@ def test_inference_conv_with_pooled_output_equals_conv_then_pool(dclib, N, H, W,
                                         flag.data_ptr(), pool.data_ptr(), N, H, W, Cin, Cout, None)
         else:
             L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), None, cat.data_ptr() + 4 * Cout, ld, None, sc.data_ptr(), sh.data_ptr(), 1,
-                                   None, 0, flag.data_ptr(), -1, N, H, W, Cin, Cout, None)
+                                   None, 0, flag.data_ptr(), -1, None, N, H, W, Cin, Cout, None)
             L.dc_maxpool2x2_fwd(cat.data_ptr() + 4 * Cout, ld, pool.data_ptr(), None, N, H, W, Cout, None)
         torch.cuda.synchronize()
         outs.append((cat.cpu().numpy(), pool.cpu().numpy(), flag.cpu().numpy()))
@@ -924,10 +939,10 @@ def test_reduce_partials_deterministic(dclib):
         assert np.allclose(out1.cpu().numpy(), 0.5 * x.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
 
 
-def test_split_k_scratch_is_per_stream_and_grows(dclib):
-    """Split-K launches (narrow layers) keep their slabs in a scratch buffer the library owns per (device, stream): the same
-    convolution issued on two streams at once, then a larger one on the first stream (the buffer has to grow), must give
-    the bits of the same launches issued alone, one after the other."""
+def test_split_k_workspace_is_caller_owned_one_per_stream(dclib):
+    """Split-K launches (narrow layers) keep their slabs in the CALLER's workspace (dc_conv3x3_splitk_ws_floats): the same
+    convolution issued on two streams at once, each with its own workspace, then a larger one, must give the bits of the
+    same launches issued alone, one after the other -- and the library itself never allocates (tests/test_abi.py)."""
     L = dclib
     rs = np.random.RandomState(11)
     shapes = [(20, 16, 16, 256, 256), (24, 16, 16, 512, 256)]
@@ -939,33 +954,43 @@ def test_split_k_scratch_is_per_stream_and_grows(dclib):
         wp = torch.empty(L.dc_pack_weights_f16x3_floats(9, Ci, Co), device='cuda')
         L.dc_pack_weights_f16x3(K.data_ptr(), wp.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
         data.append((x, wp, b))
+    need = max(L.dc_conv3x3_splitk_ws_floats(*sh, 0) for sh in shapes)
+    assert need > 0
+    wss = [torch.full((need,), float('nan'), device='cuda') for _ in range(3)]
     torch.cuda.synchronize()
 
-    def run(i, stream):
+    def run(i, stream, ws):
         N, H, W, Ci, Co = shapes[i]
         x, wp, b = data[i]
         tiles = L.dc_conv3x3_tiles(N, H, W, Co)
         z = torch.full((N, H, W, Co), float('nan'), device='cuda')
         stats = torch.full((tiles * Co * 2,), float('nan'), device='cuda', dtype=torch.float64)
         L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, stats.data_ptr(), None, None, 0,
-                               None, 0, None, 0, N, H, W, Ci, Co, stream.cuda_stream if stream is not None else None)
+                               None, 0, None, 0, ws.data_ptr(), N, H, W, Ci, Co, stream.cuda_stream if stream is not None else None)
         return z, stats
 
-    ref = [run(0, None), run(1, None)]
+    ref = [run(0, None, wss[0]), run(1, None, wss[0])]
     torch.cuda.synchronize()
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
     outs = []
     for rep in range(3):
-        outs.append((run(0, s1), run(0, s2)))        # both streams busy with the same shape
-    big = run(1, s1)                                 # s1's scratch grows behind its pending launches
-    again = run(0, s1)
+        outs.append((run(0, s1, wss[1]), run(0, s2, wss[2])))      # both streams busy with the same shape, one workspace each
+    big = run(1, s1, wss[1])
+    again = run(0, s1, wss[1])
     torch.cuda.synchronize()
     for a, b2 in outs:
         for z, st in (a, b2):
             assert torch.equal(z, ref[0][0]) and torch.equal(st, ref[0][1])
     assert torch.equal(big[0], ref[1][0]) and torch.equal(big[1], ref[1][1])
     assert torch.equal(again[0], ref[0][0]) and torch.equal(again[1], ref[0][1])
+    from deep_calcium_amd._lib import DcunetError
+    with pytest.raises(DcunetError, match='16-byte aligned'):
+        N, H, W, Ci, Co = shapes[0]
+        x, wp, b = data[0]
+        z = torch.empty((N, H, W, Co), device='cuda')
+        L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, None, None, None, 0,
+                               None, 0, None, 0, wss[0].data_ptr() + 4, N, H, W, Ci, Co, None)
 
 
 def test_error_reporting(dclib):
@@ -996,7 +1021,7 @@ def test_convT_dgrad_with_fused_bn_backward_sums(dclib, N, H, W, Ci, Co):
     ga = dev(rs.standard_normal(Ci).astype(np.float32)); be = dev((rs.standard_normal(Ci) * 0.3).astype(np.float32))
     scale = torch.full((4,), 2.0 ** 17, device='cuda')
     dx0 = torch.full((N, H, W, Ci), float('nan'), device='cuda'); dx1 = torch.full_like(dx0, float('nan'))
-    L.dc_convT2x2_dgrad_f16x3(dz.data_ptr(), wpd.data_ptr(), dx0.data_ptr(), scale.data_ptr(), None, 0, N, H, W, Ci, Co, None)
+    L.dc_convT2x2_dgrad_f16x3(dz.data_ptr(), wpd.data_ptr(), dx0.data_ptr(), scale.data_ptr(), None, 0, None, N, H, W, Ci, Co, None)
     part = torch.full((rows * Ci * 2,), float('nan'), device='cuda')
     amx = torch.full((rows * Ci,), float('nan'), device='cuda')
     L.dc_convT2x2_dgrad_bnred_f16x3(dz.data_ptr(), wpd.data_ptr(), dx1.data_ptr(), scale.data_ptr(), None, 0, z.data_ptr(), mu.data_ptr(),

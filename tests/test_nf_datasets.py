@@ -92,6 +92,28 @@ def test_missing_directory_offline_is_a_clear_error(tmp_path, monkeypatch):
         nf_datasets.nf_load_hdf5('neurofinder.02.00', datasets_dir=str(tmp_path))
 
 
+def test_waiting_rank_fails_fast_when_rank0_is_gone(tmp_path, monkeypatch):
+    """A rank that waits for rank 0's dataset build gives up after `stale_s` without a heartbeat (rank 0 killed, or the directory
+    is not shared) instead of polling for hours; a failure marker counts only when it carries THIS launch's token (a stale
+    marker of an earlier run, whatever its mtime, is ignored)."""
+    import time
+    from deep_calcium_amd import parallel
+    monkeypatch.setattr(parallel, 'rank', lambda: 1)
+    monkeypatch.setattr(parallel, 'world_size', lambda: 2)
+    monkeypatch.setenv('MASTER_PORT', '12345')
+    root = str(tmp_path)
+    with open('%s/.nf_build_failed' % root, 'w') as fp:
+        fp.write('other-run@-:999\nValueError: an earlier launch')
+    t = time.time()
+    with pytest.raises(IOError, match='no sign of life from rank 0'):
+        nf_datasets.nf_load_hdf5('neurofinder.02.00', datasets_dir=root, stale_s=0.6)
+    assert time.time() - t < 5
+    with open('%s/.nf_build_failed' % root, 'w') as fp:
+        fp.write('%s\nIOError: disk full' % nf_datasets._run_token())
+    with pytest.raises(IOError, match='disk full'):
+        nf_datasets.nf_load_hdf5('neurofinder.02.00', datasets_dir=root, stale_s=30)
+
+
 def test_deferred_datasets_roundtrip(tmp_path):
     w = hdf5_min.Writer()
     a = w.create_dataset('g/big', shape=(3, 4, 5), dtype='int16')
