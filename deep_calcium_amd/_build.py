@@ -11,8 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdcunet.so')
-SOURCES = ['common.cpp', 'igemm_conv.hip', 'igemm_f16x3.hip', 'igemm_pp.hip', 'wgrad.hip', 'wgrad_f16x3.hip', 'bwd_joint.hip', 'conv_c1.hip', 'elementwise.hip']
+SOURCES = ['common.cpp', 'nf_score.cpp', 'igemm_conv.hip', 'igemm_f16x3.hip', 'igemm_pp.hip', 'wgrad.hip', 'wgrad_f16x3.hip', 'bwd_joint.hip', 'conv_c1.hip', 'elementwise.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+HOST_ONLY = {'nf_score.cpp': ['-ffp-contract=off']}      # host arithmetic that must round like numpy's: no fused multiply-add
 
 
 def _hipcc():
@@ -41,7 +42,7 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
-        cmd = [hipcc] + FLAGS + ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + HOST_ONLY.get(src, []) + ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-6000:]))

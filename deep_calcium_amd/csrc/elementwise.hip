@@ -1570,3 +1570,91 @@ extern "C" int dc_tta_merge(const float* preds, const int* invmaps, int K, int H
   DC_CHECK_LAUNCH("dc_tta_merge");
   return DC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Training-batch assembly on the device: the array half of UNet2DSummary._batch_gen
+// (/root/reference/deepcalcium/models/neurons/unet_2d_summary.py:434-530).  The host keeps drawing the reference's single
+// numpy random stream (dataset, neuron pixel, jitter, augmentation indices :479-527) and reduces every item to four longs;
+// the summaries / masks of all datasets are resident in HBM (a few tens of MB), so no image data crosses PCIe per step:
+//   crop [y0 : y0+eh, x0 : x0+ew] of dataset k  ->  zero-filled (hw, hw) window (:505-521)  ->  the composition of the drawn
+//   flips / rot90s (:524-527), ONE of the 8 dihedral pixel permutations:  out[i][j] = win[r][c],
+//   (r, c) = (d4 & 1) ? (j, i) : (i, j);  r = (d4 & 2) ? hw-1-r : r;  c = (d4 & 4) ? hw-1-c : c.
+// The items ride in the KERNEL ARGUMENT block (<= DC_CROP_MAX_ITEMS per launch): nothing is staged, copied or retained.
+struct CropItems { long v[DC_CROP_MAX_ITEMS][4]; };       // { element offset of (y0, x0), row stride, eh << 32 | ew, d4 }
+__global__ __launch_bounds__(256) void crop_augment_kernel(const float* __restrict__ S, const uint8_t* __restrict__ M,
+                                                           CropItems items, int hw, float* __restrict__ x,
+                                                           uint8_t* __restrict__ y) {
+  const int b = blockIdx.y;
+  const long org = items.v[b][0], ld = items.v[b][1];
+  const int eh = (int)(items.v[b][2] >> 32), ew = (int)(items.v[b][2] & 0xffffffffL), d4 = (int)items.v[b][3];
+  const int q4 = hw >> 2;                                   // 4 consecutive output pixels of a row per thread
+  const long outb = (long)b * hw * hw;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < hw * q4; t += gridDim.x * 256) {
+    const int i = t / q4, j0 = (t - i * q4) * 4;
+    f32x4 v;
+    uchar4 m;
+    uint8_t* mm = reinterpret_cast<uint8_t*>(&m);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int r = (d4 & 1) ? j0 + e : i, c = (d4 & 1) ? i : j0 + e;
+      if (d4 & 2) r = hw - 1 - r;
+      if (d4 & 4) c = hw - 1 - c;
+      const bool in = r < eh && c < ew;
+      const long src = org + (long)r * ld + c;
+      v[e] = in ? S[src] : 0.f;
+      mm[e] = in ? M[src] : (uint8_t)0;
+    }
+    st4(x + outb + (long)i * hw + j0, v);
+    *reinterpret_cast<uchar4*>(y + outb + (long)i * hw + j0) = m;
+  }
+}
+extern "C" int dc_crop_augment(const float* S, const uint8_t* M, long src_elems, const long* items_host, int B, int hw,
+                               float* x, uint8_t* y, dc_stream_t stream) {
+  DC_REQUIRE(S && M && items_host && x && y && B > 0 && hw > 0 && src_elems > 0, DC_EINVAL, "dc_crop_augment: bad arguments");
+  DC_REQUIRE(hw % 4 == 0 && dc_aligned16(x) && (reinterpret_cast<uintptr_t>(y) & 3) == 0, DC_EINVAL,
+             "dc_crop_augment: the window side must be a multiple of 4, x 16-byte and y 4-byte aligned");
+  for (int b = 0; b < B; ++b) {                               // the items come from the host: a bad one must not read out of bounds
+    const long org = items_host[4 * b], ld = items_host[4 * b + 1];
+    const long eh = items_host[4 * b + 2] >> 32, ew = items_host[4 * b + 2] & 0xffffffffL, d4 = items_host[4 * b + 3];
+    DC_REQUIRE(org >= 0 && ld > 0 && eh >= 0 && ew >= 0 && eh <= hw && ew <= hw && ew <= ld && d4 >= 0 && d4 < 8 &&
+               (eh == 0 || ew == 0 || org + (eh - 1) * ld + ew <= src_elems), DC_EINVAL,
+               "dc_crop_augment: item %d {offset %ld, stride %ld, %ld x %ld, d4 %ld} leaves the %ld-element source", b, org, ld, eh, ew,
+               d4, src_elems);
+  }
+  const int per = hw * (hw / 4);
+  const int gx = (per + 255) / 256 > 64 ? 64 : (per + 255) / 256;
+  for (int b0 = 0; b0 < B; b0 += DC_CROP_MAX_ITEMS) {
+    const int nb = B - b0 < DC_CROP_MAX_ITEMS ? B - b0 : DC_CROP_MAX_ITEMS;
+    CropItems it;
+    for (int b = 0; b < nb; ++b)
+      for (int e = 0; e < 4; ++e) it.v[b][e] = items_host[4 * (b0 + b) + e];
+    hipLaunchKernelGGL(crop_augment_kernel, dim3(gx, nb), dim3(256), 0, (hipStream_t)stream, S, M, it, hw,
+                       x + (long)b0 * hw * hw, y + (long)b0 * hw * hw);
+  }
+  DC_CHECK_LAUNCH("dc_crop_augment");
+  return DC_OK;
+}
+
+// p > 0.5 as uint8 over the [y0:y1, x0:x1] window of each (H, W) probability map: numpy's `mp[y0:y1, x0:x1].round()` on
+// probabilities (round half to even: 0.5 -> 0) of the validation callback (unet_2d_summary.py:90-91), so that only the scored
+// stripe, one byte per pixel, leaves the device.
+__global__ __launch_bounds__(256) void round_window_kernel(const float* __restrict__ p, int H, int W, int y0, int y1, int x0,
+                                                           int x1, uint8_t* __restrict__ out) {
+  const int hh = y1 - y0, ww = x1 - x0;
+  const long per = (long)hh * ww;
+  const long n = blockIdx.y;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < per; i += gridDim.x * 256L) {
+    const int r = (int)(i / ww), c = (int)(i - (long)r * ww);
+    out[n * per + i] = p[(n * H + y0 + r) * (long)W + x0 + c] > 0.5f ? 1 : 0;
+  }
+}
+extern "C" int dc_round_window_u8(const float* p, int N, int H, int W, int y0, int y1, int x0, int x1, uint8_t* out,
+                                  dc_stream_t stream) {
+  DC_REQUIRE(p && out && N > 0 && 0 <= y0 && y0 < y1 && y1 <= H && 0 <= x0 && x0 < x1 && x1 <= W, DC_EINVAL,
+             "dc_round_window_u8: bad window [%d:%d, %d:%d] of %d x %d", y0, y1, x0, x1, H, W);
+  const long per = (long)(y1 - y0) * (x1 - x0);
+  const int gx = (int)((per + 255) / 256 > 256 ? 256 : (per + 255) / 256);
+  hipLaunchKernelGGL(round_window_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, p, H, W, y0, y1, x0, x1, out);
+  DC_CHECK_LAUNCH("dc_round_window_u8");
+  return DC_OK;
+}

@@ -65,6 +65,30 @@ class Adam(object):
         return dict(lr=self.lr, beta_1=self.beta_1, beta_2=self.beta_2, epsilon=self.epsilon)
 
 
+# ---- device-side training batches ---------------------------------------------------------------------------
+def crop_layout(shapes):
+    """Element offsets of the datasets' (H, W) images inside the ONE concatenated source buffer dc_crop_augment reads
+    (summaries float32, masks uint8: same layout), each image starting on a 16-element boundary.  -> (offsets, total)."""
+    offs, o = [], 0
+    for h, w in shapes:
+        offs.append(o)
+        o += (int(h) * int(w) + 15) // 16 * 16
+    return offs, max(o, 16)
+
+
+class DeviceBatch(object):
+    """One training batch as crop / augmentation items instead of pixel arrays: `items` int64 (B, 4) as dc_crop_augment
+    takes them (include/dcunet.h), `window` the side of the square window.  Model.fit_generator hands it to
+    Model.train_on_items; len() is the batch size (Keras' logs['size'])."""
+    __slots__ = ('items', 'window')
+
+    def __init__(self, items, window):
+        self.items, self.window = np.ascontiguousarray(items, dtype=np.int64), int(window)
+
+    def __len__(self):
+        return len(self.items)
+
+
 # ---- callbacks (keras.callbacks protocol) -----------------------------------------------------------------
 class Callback(object):
     def __init__(self):
@@ -123,9 +147,14 @@ class CSVLogger(Callback):
 
 
 class ModelCheckpoint(Callback):
-    def __init__(self, filepath, monitor='val_loss', verbose=0, save_best_only=False, mode='auto', period=1):
+    """keras.callbacks.ModelCheckpoint.  background=True (not in Keras; UNet2DSummary.fit uses it): the model is
+    snapshotted when the callback runs -- so the file holds exactly the epoch's weights -- but serialised and written by a
+    background thread while the next epoch trains; on_train_end waits for the last file."""
+
+    def __init__(self, filepath, monitor='val_loss', verbose=0, save_best_only=False, mode='auto', period=1, background=False):
         super(ModelCheckpoint, self).__init__()
         self.filepath, self.monitor, self.verbose, self.save_best_only = filepath, monitor, verbose, save_best_only
+        self.background = bool(background)
         self.cmp = np.greater if (mode == 'max' or (mode == 'auto' and ('acc' in monitor or monitor.startswith('fmeasure')))) else np.less
         self.best = -np.inf if self.cmp is np.greater else np.inf
 
@@ -139,7 +168,14 @@ class ModelCheckpoint(Callback):
             self.best = cur
         if self.verbose:
             print('Epoch %05d: saving model to %s' % (epoch, path))
-        self.model.save(path)
+        if self.background and hasattr(self.model, 'wait_for_saves'):
+            self.model.save(path, background=True)
+        else:
+            self.model.save(path)
+
+    def on_train_end(self, logs=None):
+        if hasattr(self.model, 'wait_for_saves'):
+            self.model.wait_for_saves()
 
 
 class ReduceLROnPlateau(Callback):
@@ -233,6 +269,20 @@ class Model(object):
     def set_weights(self, weights):
         self.engine.set_weights(weights)
 
+    def copy_weights_from(self, other):
+        """set_weights(other.get_weights()) (unet_2d_summary.py:69) without the round trip through 134 host arrays when both
+        are HIP models of the same architecture on one GPU: two device-to-device copies (31 MB + moving statistics)."""
+        a, b = self.engine, getattr(other, 'engine', None)
+        if b is None or a.device != b.device or a.pflat.numel() != b.pflat.numel() or a.sflat.numel() != b.sflat.numel() \
+                or a.nfb != b.nfb or a.upsampling != b.upsampling:
+            return self.set_weights(other.get_weights())
+        with torch.cuda.device(a.device):
+            b._settle_tail()
+            a.pflat.copy_(b.pflat, non_blocking=True)
+            a.sflat.copy_(b.sflat, non_blocking=True)
+        a._packed_dirty = True
+        a._fold_dirty = True
+
     def predict(self, x, batch_size=32, verbose=0):
         """x: (N,H,W) float32 -> (N,H,W) float32 probabilities (learning phase 0: moving stats, no dropout)."""
         x = np.ascontiguousarray(x, dtype=np.float32)
@@ -265,6 +315,17 @@ class Model(object):
         out = self.train_on_device_batch(xd, yd, masks)
         slot['done'].record(torch.cuda.current_stream(eng.device))      # the step's last reader of xd / yd (Adam) is queued
         return out
+
+    def train_on_items(self, batch):
+        """train_on_batch for a DeviceBatch (UNet2DSummary._device_batch_gen): this rank's items are cut out of the resident
+        summaries / masks by dc_crop_augment on the step's own stream -- no pixel crosses PCIe, nothing is staged."""
+        if self.optimizer is None:
+            raise RuntimeError('compile() the model first')
+        if batch.window != self.config['window_shape'][0] or self.config['window_shape'][0] != self.config['window_shape'][1]:
+            raise ValueError('batch of %d^2 windows for a model of input shape %r' % (batch.window, self.config['window_shape']))
+        with torch.cuda.device(self.engine.device):
+            xd, yd = self.engine.crop_batch(batch.items)
+            return self._train_on_device_batch(xd, yd, None)
 
     def _stage(self, xs, ys):
         """numpy slice -> (pinned host buffer -> device buffer) of a 2-deep ring, copied on the copy stream."""
@@ -421,11 +482,14 @@ class Model(object):
                     item = q.get()
                     if isinstance(item, Exception):
                         raise item
-                    xb, yb = item[0], item[1]
+                    xb = item if isinstance(item, DeviceBatch) else item[0]
                     blogs = {'batch': step, 'size': len(xb)}
                     for cb in cbs:
                         cb.on_batch_begin(step, blogs)
-                    vals = self.train_on_batch(xb, yb, presharded=presharded)
+                    if isinstance(item, DeviceBatch):           # items for dc_crop_augment: already this rank's slice
+                        vals = self.train_on_items(item)
+                    else:
+                        vals = self.train_on_batch(xb, item[1], presharded=presharded)
                     for k, v in zip(self.metrics_names, vals):
                         blogs[k] = v
                         totals[k] += v * len(xb)
@@ -458,9 +522,10 @@ class Model(object):
     # -- checkpoints ------------------------------------------------------------------------------------------------------
     # '*.hdf5' / '*.h5' (what ModelCheckpoint passes, unet_2d_summary.py:423): the reference's Keras-2.0.x model-file layout,
     # written in-process (keras_io / hdf5_min); anything else: the build's own .npz container.  Loading sniffs the file.
-    def _optimizer_state(self):
+    def _optimizer_state(self, m=None, v=None, iterations=None, config=None):
         eng = self.engine
-        m, v = eng.mflat.cpu().numpy(), eng.vflat.cpu().numpy()
+        m = eng.mflat.cpu().numpy() if m is None else m
+        v = eng.vflat.cpu().numpy() if v is None else v
         ms, vs = [], []
         for l in eng.layers:
             for key in ('k', 'b', 'gamma', 'beta'):
@@ -469,7 +534,8 @@ class Model(object):
                     n = int(np.prod(shp))
                     ms.append(m[o:o + n].reshape(shp).copy())
                     vs.append(v[o:o + n].reshape(shp).copy())
-        return dict(config=self.optimizer.get_config(), iterations=int(eng.iterations), m=ms, v=vs)
+        return dict(config=config if config is not None else self.optimizer.get_config(),
+                    iterations=int(eng.iterations if iterations is None else iterations), m=ms, v=vs)
 
     def _set_optimizer_state(self, st, loss):
         eng = self.engine
@@ -491,25 +557,81 @@ class Model(object):
         oc = dict((k, st['config'][k]) for k in ('lr', 'beta_1', 'beta_2', 'epsilon') if k in st.get('config', {}))
         self.compile(Adam(**oc), loss or 'binary_crossentropy')
 
-    def save(self, filepath, include_optimizer=True):
+    def save(self, filepath, include_optimizer=True, background=False):
+        """background=True: the parameters, moving statistics and Adam state are copied device -> pinned host memory on the
+        current stream (a snapshot of THIS moment: ~95 MB, a few ms of copy engine time) and a thread serialises and writes the
+        file while training goes on; wait_for_saves() joins it (one snapshot in flight at a time)."""
         eng = self.engine
         with_opt = include_optimizer and self.optimizer is not None
+        if background:
+            self.wait_for_saves()
+            snap = self._snapshot(with_opt)
+            import threading
+            box = []
+
+            def work():
+                try:
+                    snap['event'].synchronize()
+                    self._write(filepath, snap)
+                except BaseException as e:       # surfaced by wait_for_saves()
+                    box.append(e)
+            th = threading.Thread(target=work, daemon=False)
+            self._saving = (th, box, filepath)
+            th.start()
+            return
+        self.wait_for_saves()
+        self._write(filepath, self._snapshot(with_opt, sync=True))
+
+    def wait_for_saves(self):
+        pending, self._saving = getattr(self, '_saving', None), None
+        if pending is not None:
+            th, box, path = pending
+            th.join()
+            if box:
+                raise IOError('writing %s failed: %r' % (path, box[0]))
+
+    def _snapshot(self, with_opt, sync=False):
+        """Host copy of everything a checkpoint holds, taken on the engine's current stream into pinned buffers that are
+        reused from save to save (wait_for_saves() has made sure the previous writer is done with them)."""
+        eng = self.engine
+        with torch.cuda.device(eng.device):
+            eng._settle_tail()
+            bufs = getattr(self, '_snap_bufs', None)
+            if bufs is None:
+                bufs = self._snap_bufs = dict((k, torch.empty(t.numel(), dtype=t.dtype).pin_memory()) for k, t in
+                                              (('p', eng.pflat), ('s', eng.sflat), ('m', eng.mflat), ('v', eng.vflat)))
+            for k, t in (('p', eng.pflat), ('s', eng.sflat)) + ((('m', eng.mflat), ('v', eng.vflat)) if with_opt else ()):
+                bufs[k].copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(eng.device))
+            if sync:
+                ev.synchronize()
+        return dict(event=ev, bufs=bufs, with_opt=with_opt, iterations=int(eng.iterations), loss=self.loss,
+                    metrics=list(self.metrics_names[1:]), opt_config=self.optimizer.get_config() if with_opt else None,
+                    compiled=self.optimizer is not None)
+
+    def _write(self, filepath, snap):
+        eng = self.engine
+        b = snap['bufs']
+        weights = eng.get_weights(p=b['p'].numpy(), s=b['s'].numpy())
+        with_opt = snap['with_opt']
+        tmp = '%s.partial.%d' % (filepath, os.getpid())      # a reader never sees a half-written checkpoint
         if str(filepath).lower().endswith(('.hdf5', '.h5')):
             from . import keras_io
-            keras_io.write_keras_model(filepath, eng.get_weights(), self.config,
-                                       optimizer=self._optimizer_state() if with_opt else None, loss=self.loss,
-                                       metrics=self.metrics_names[1:])
-            return
-        arrays = {'w_%03d' % i: w for i, w in enumerate(eng.get_weights())}
-        meta = dict(format='dcunet-npz-1', config=self.config, compiled=self.optimizer is not None)
-        if with_opt:
-            arrays['opt_m'] = eng.mflat.cpu().numpy()
-            arrays['opt_v'] = eng.vflat.cpu().numpy()
-            meta['optimizer'] = dict(self.optimizer.get_config(), iterations=int(eng.iterations))
-            meta['loss'] = self.loss
-        arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-        with open(filepath, 'wb') as fp:
-            np.savez(fp, **arrays)
+            opt = self._optimizer_state(b['m'].numpy(), b['v'].numpy(), snap['iterations'], snap['opt_config']) if with_opt else None
+            keras_io.write_keras_model(tmp, weights, self.config, optimizer=opt, loss=snap['loss'], metrics=snap['metrics'])
+        else:
+            arrays = {'w_%03d' % i: w for i, w in enumerate(weights)}
+            meta = dict(format='dcunet-npz-1', config=self.config, compiled=snap['compiled'])
+            if with_opt:
+                arrays['opt_m'] = b['m'].numpy().copy()
+                arrays['opt_v'] = b['v'].numpy().copy()
+                meta['optimizer'] = dict(snap['opt_config'], iterations=snap['iterations'])
+                meta['loss'] = snap['loss']
+            arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+            with open(tmp, 'wb') as fp:
+                np.savez(fp, **arrays)
+        os.replace(tmp, filepath)
 
     def load_state(self, filepath, with_optimizer):
         state = read_checkpoint(filepath)

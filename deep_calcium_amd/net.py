@@ -386,10 +386,11 @@ class UNetEngine(object):
                 out += [(l.cout,)] * 4
         return out
 
-    def get_weights(self):
-        """Keras get_weights(): 134 arrays, [kernel, bias, gamma, beta, moving_mean, moving_variance] per layer."""
-        p = self.pflat.cpu().numpy()
-        s = self.sflat.cpu().numpy()
+    def get_weights(self, p=None, s=None):
+        """Keras get_weights(): 134 arrays, [kernel, bias, gamma, beta, moving_mean, moving_variance] per layer.
+        p / s: host copies of pflat / sflat taken earlier (a checkpoint snapshot) instead of the live device buffers."""
+        p = self.pflat.cpu().numpy() if p is None else p
+        s = self.sflat.cpu().numpy() if s is None else s
         out = []
         for l in self.layers:
             for key in ('k', 'b', 'gamma', 'beta'):
@@ -874,6 +875,44 @@ class UNetEngine(object):
             T['dcat%d' % lvl] = torch.empty(N * h * w * (self._cup(lvl) + (nfb << lvl)), dtype=torch.float32, device=dev)
         self._bufs[key] = T
         return T
+
+    # ---- training batches cut on the device (dc_crop_augment) -------------------------------------------------------
+    def set_crop_sources(self, S_list, M_list):
+        """Upload the datasets' normalised summary images (float32) and flattened masks (uint8) ONCE, concatenated in
+        model.crop_layout()'s order: what UNet2DSummary._batch_gen crops on the host per step (unet_2d_summary.py:505-521)
+        is cut out of these by dc_crop_augment from then on."""
+        from .model import crop_layout
+        shapes = [tuple(np.shape(v)) for v in S_list]
+        if [tuple(np.shape(v)) for v in M_list] != shapes or any(len(sh) != 2 for sh in shapes):
+            raise ValueError('summaries and masks must be 2-D arrays of equal shapes per dataset')
+        offs, total = crop_layout(shapes)
+        S, M = np.zeros(total, np.float32), np.zeros(total, np.uint8)
+        for o, (h, w), sv, mv in zip(offs, shapes, S_list, M_list):
+            S[o:o + h * w] = np.asarray(sv, dtype=np.float32).ravel()
+            M[o:o + h * w] = np.asarray(mv).astype(np.uint8).ravel()
+        self._crop = dict(S=torch.from_numpy(S).to(self.device), M=torch.from_numpy(M).to(self.device), total=total)
+
+    @_on_device
+    def crop_batch(self, items):
+        """items: int64 (n, 4) host array (model.DeviceBatch.items) -> (x float32 (n,H,W), y uint8 (n,H,W)) device tensors of
+        this engine, written by dc_crop_augment on the current stream (the step's input buffers: the launch is ordered
+        behind the previous step's last reader of them, the first layer's weight gradient, because adam_step() joins it)."""
+        src = getattr(self, '_crop', None)
+        if src is None:
+            raise RuntimeError('set_crop_sources() first')
+        if self.H != self.W:
+            raise ValueError('device-side batches need a square window')
+        items = np.ascontiguousarray(items, dtype=np.int64)
+        n = int(items.shape[0])
+        key = ('xy_in', n)
+        xy = self._bufs.get(key)
+        if xy is None:
+            xy = self._bufs[key] = (torch.empty((n, self.H, self.W), dtype=torch.float32, device=self.device),
+                                    torch.empty((n, self.H, self.W), dtype=torch.uint8, device=self.device))
+        self._settle_tail()
+        self.L.dc_crop_augment(src['S'].data_ptr(), src['M'].data_ptr(), src['total'], items.ctypes.data, n, self.H,
+                               xy[0].data_ptr(), xy[1].data_ptr(), self._stream())
+        return xy
 
     def _drop_args(self, l, masks, step_seed):
         if l.drop <= 0.0:

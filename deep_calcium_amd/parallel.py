@@ -104,6 +104,19 @@ def all_reduce_max(t):
     return t
 
 
+def all_reduce_sum_host(a):
+    """Sum a host (numpy float64) array over the ranks and return it: through a device tensor under RCCL, a CPU tensor under
+    gloo.  Used for small result tables (per-item validation scores: each item is owned by one rank, the others add 0.0)."""
+    import numpy as np
+    if not exchange_active():
+        return a
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+    if dist.get_backend() == 'nccl':
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy().reshape(np.shape(a))
+
+
 def all_gather_floats(value, device=None):
     """One float per rank -> list over ranks (bench.py: per-rank timings)."""
     if not exchange_active():

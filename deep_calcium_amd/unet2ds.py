@@ -15,7 +15,7 @@ from time import time
 import numpy as np
 
 from . import parallel
-from .model import (Adam, Callback, CSVLogger, ModelCheckpoint, ReduceLROnPlateau, unet_hip,
+from .model import (Adam, Callback, CSVLogger, DeviceBatch, ModelCheckpoint, ReduceLROnPlateau, crop_layout, unet_hip,
                     load_model_with_new_input_shape)
 from .nf_metrics import nf_mask_metrics
 
@@ -65,6 +65,25 @@ _D4 = [lambda a: a, lambda a: a[:, ::-1], lambda a: a[::-1, :], lambda a: np.rot
 _D4_KEYS = {tuple(f(_PROBE).ravel()): f for f in _D4}
 _D4[0] = _SIX[0]
 _D4_KEYS[tuple(_PROBE.ravel())] = _SIX[0]
+
+
+def _d4_bits(f):
+    """f (one of the 8 dihedral maps of a square array) as the 3 bits of dc_crop_augment (include/dcunet.h):
+    f(a)[i][j] = a[r][c] with (r, c) = bit 0 ? (j, i) : (i, j), then r -> n-1-r if bit 1, c -> n-1-c if bit 2.  Found by
+    applying f itself to a row-index and a column-index image: the device cannot disagree with numpy's rot90 / flips."""
+    n = 3
+    R, C = np.meshgrid(np.arange(n), np.arange(n), indexing='ij')
+    fr, fc = np.asarray(f(R)), np.asarray(f(C))
+    for bits in range(8):
+        r, c = (C, R) if bits & 1 else (R, C)
+        r = n - 1 - r if bits & 2 else r
+        c = n - 1 - c if bits & 4 else c
+        if np.array_equal(fr, r) and np.array_equal(fc, c):
+            return bits
+    raise ValueError('not a dihedral map')
+
+
+_D4_BITS = {id(f): _d4_bits(f) for f in _D4}
 
 
 def _compose_six(indices):
@@ -180,25 +199,23 @@ class _ValidationMetricsCB(Callback):
     def on_epoch_end(self, epoch, logs={}):
         logger = logging.getLogger('_ValidationMetricsCB')
         tic = time()
-        eng_val, eng = self.model_val.engine, self.model.engine
-        if parallel.world_size() > 1:
-            parallel.sync_moving_stats(eng.sflat)
-        self.model_val.set_weights(self.model.get_weights())
-        _, hw, ww = self.model_val.input_shape
-        batch = np.stack([np.pad(s, ((0, hw - s.shape[0]), (0, ww - s.shape[1])), 'reflect')
-                          for s in self.S_summ]).astype(np.float32)
-        # one batched forward instead of 6n batch-1 forwards: identical per image in inference mode
-        MP = self.model_val.predict(batch, batch_size=8)
-        pp, rr, ff = [], [], []
-        name_to_f1 = {n: [] for n in self.names}
-        for mp, m, (y0, y1, x0, x1), name in zip(MP, self.M_summ, self.val_coords, self.names):
-            p, r, i, e, f = nf_mask_metrics(m[y0:y1, x0:x1], mp[y0:y1, x0:x1].round())
-            pp.append(p)
-            rr.append(r)
-            ff.append(f)
+        if parallel.world_size() > 1 and getattr(self.model, 'engine', None) is not None:
+            parallel.sync_moving_stats(self.model.engine.sflat)
+        if hasattr(self.model_val, 'copy_weights_from'):
+            self.model_val.copy_weights_from(self.model)          # device to device when both are HIP models on one GPU
+        else:
+            self.model_val.set_weights(self.model.get_weights())  # (:69)
+        n = len(self.S_summ)
+        if getattr(self.model_val, 'engine', None) is not None:
+            scores = self._score_on_device(n)
+        else:
+            scores = self._score_through_predict(n)
+        pp, rr, ff = scores[:, 0].tolist(), scores[:, 1].tolist(), scores[:, 2].tolist()
+        name_to_f1 = {nm: [] for nm in self.names}
+        for p, r, f, name in zip(pp, rr, ff, self.names):
             name_to_f1[name].append(f)
             logger.info('%s p=%.3lf r=%.3lf f=%.3lf' % (name, p, r, f))
-        if self.scores_path:
+        if self.scores_path and parallel.rank() == 0:
             with open(self.scores_path, 'wb') as fp:
                 pickle.dump(name_to_f1, fp)
         eps = 1e-4 * epoch if epoch else 0
@@ -209,6 +226,123 @@ class _ValidationMetricsCB(Callback):
         logs['val_nf_prec'] = np.mean(pp)
         logs['val_nf_reca'] = np.mean(rr)
         logger.info('mean f1 = %.3lf  (validation %.3lf s)' % (logs['val_nf_f1_mean'], time() - tic))
+
+    def _score_through_predict(self, n):
+        """The reference's own sequence (:76-91) for a foreign Keras-shaped model: predict, round, score -- one by one."""
+        _, hw, ww = self.model_val.input_shape
+        out = np.zeros((n, 3))
+        for i, (s, m, (y0, y1, x0, x1)) in enumerate(zip(self.S_summ, self.M_summ, self.val_coords)):
+            batch = np.pad(s, ((0, hw - s.shape[0]), (0, ww - s.shape[1])), 'reflect')[np.newaxis].astype(np.float32)
+            mp = self.model_val.predict(batch)[0]
+            p, r, _, _, f = nf_mask_metrics(m[y0:y1, x0:x1], mp[y0:y1, x0:x1].round())
+            out[i] = (p, r, f)
+        return out
+
+    def _score_on_device(self, n):
+        """The 6 n validation forwards + scorings of one epoch (:76-91), organised for the hardware:
+          * the 6 n reflect-padded images are uploaded ONCE per fit() and stay in HBM (n = 19: 120 MB);
+          * under data parallelism the items are dealt round-robin to the ranks (inference is 'replicas only'),
+            the per-item scores are summed over the ranks -- every item is owned by exactly one rank, the others add 0.0 --,
+            so every rank writes the SAME logs;
+          * forwards run in batches of 8 (inference BatchNorm is per-image), the probabilities never leave the device: the
+            scored stripe `mp[y0:y1, x0:x1].round()` (:91) comes back as one byte per pixel (dc_round_window_u8);
+          * a scoring thread takes each batch as its copy lands and runs the native scorer (dc_host_nf_pairs: bit-identical
+            to nf_mask_metrics, GIL released) while the device is on the next batch."""
+        import threading
+        import torch
+        from .nf_metrics import NativeScorer
+        eng = self.model_val.engine
+        _, hw, ww = self.model_val.input_shape
+        world, rank = parallel.world_size(), parallel.rank()
+        mine = list(range(rank, n, world))
+        st = getattr(self, '_dev', None)
+        if st is None or st['key'] != (hw, ww, n, world, rank):
+            pad = [np.pad(self.S_summ[i], ((0, hw - self.S_summ[i].shape[0]), (0, ww - self.S_summ[i].shape[1])), 'reflect')
+                   for i in mine]
+            truth = [np.ascontiguousarray(np.asarray(self.M_summ[i])[c[0]:c[1], c[2]:c[3]] != 0, dtype=np.uint8)
+                     for i, c in ((i, self.val_coords[i]) for i in mine)]
+            sizes = [t.size for t in truth]
+            offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            with torch.cuda.device(eng.device):
+                x = torch.from_numpy(np.stack(pad).astype(np.float32)).to(eng.device) if mine else None
+                out_dev = torch.empty(max(int(offs[-1]), 1), dtype=torch.uint8, device=eng.device)
+                out_host = torch.empty(max(int(offs[-1]), 1), dtype=torch.uint8).pin_memory()
+            st = self._dev = dict(key=(hw, ww, n, world, rank), x=x, truth=truth, offs=offs, out_dev=out_dev, out_host=out_host,
+                                  scorer=NativeScorer(max(sizes + [1])))
+        scores = np.zeros((n, 3))
+        if mine:
+            chunks = [list(range(k, min(k + 8, len(mine)))) for k in range(0, len(mine), 8)]
+            events, flags = [], []
+            done = []
+
+            def score_chunks():
+                try:
+                    host = st['out_host'].numpy()
+                    for ev, chunk in zip(events_iter(), chunks):
+                        ev.synchronize()
+                        for k in chunk:
+                            c = self.val_coords[mine[k]]
+                            mp = host[st['offs'][k]:st['offs'][k + 1]].reshape(c[1] - c[0], c[3] - c[2])
+                            p, r, _, _, f = st['scorer'](st['truth'][k], mp)
+                            scores[mine[k]] = (p, r, f)
+                except BaseException as e:      # surfaced on the caller's thread
+                    done.append(e)
+
+            cond = threading.Condition()
+
+            def events_iter():
+                for j in range(len(chunks)):
+                    with cond:
+                        while len(events) <= j:
+                            cond.wait()
+                    yield events[j]
+
+            th = threading.Thread(target=score_chunks, daemon=True)
+            th.start()
+            try:
+                self._forward_chunks(eng, st, mine, chunks, events, flags, cond, hw, ww)
+            finally:
+                with cond:                       # never leave the scorer waiting for an event that will not come
+                    while len(events) < len(chunks):
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream(eng.device))
+                        events.append(ev)
+                    cond.notify_all()
+                th.join()
+            if done:
+                raise done[0]
+            if any(float(f) != 0.0 for f in torch.stack(flags).cpu().numpy().ravel()):
+                # an activation left fp16's range under the optimistic guard (never on trained weights): measured bounds, again
+                eng.infer_measured = True
+                return self._score_on_device(n)
+        if world > 1:
+            scores = parallel.all_reduce_sum_host(scores)
+        return scores
+
+    def _forward_chunks(self, eng, st, mine, chunks, events, flags, cond, hw, ww):
+        import torch
+        with torch.cuda.device(eng.device):
+            stream = torch.cuda.current_stream(eng.device)
+            for chunk in chunks:
+                p = eng.forward_infer(st['x'][chunk[0]:chunk[-1] + 1])
+                if eng.mfma == 'f16x3' and eng.range_guard and not eng.infer_measured:
+                    flags.append(eng._ovf[0:1].clone())
+                else:
+                    flags.append(torch.zeros(1, device=eng.device))
+                for j, k in enumerate(chunk):
+                    y0, y1, x0, x1 = self.val_coords[mine[k]]
+                    o0, o1 = int(st['offs'][k]), int(st['offs'][k + 1])
+                    if o1 > o0:
+                        eng.L.dc_round_window_u8(p[j].data_ptr(), 1, hw, ww, int(y0), int(y1), int(x0), int(x1),
+                                                 st['out_dev'].data_ptr() + o0, stream.cuda_stream)
+                o0, o1 = int(st['offs'][chunk[0]]), int(st['offs'][chunk[-1] + 1])
+                if o1 > o0:
+                    st['out_host'][o0:o1].copy_(st['out_dev'][o0:o1], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                with cond:
+                    events.append(ev)
+                    cond.notify_all()
 
 
 class _PreshardedBatches(object):
@@ -276,8 +410,13 @@ class UNet2DSummary(object):
         # data parallel: every rank replays the reference's single RNG stream (rank 0's state, broadcast) but only
         # materialises its own slice of each global batch
         parallel.broadcast_numpy_rng()
-        gen_trn = self._batch_gen(S_summ, M_summ, names, yctrn, batch_size_trn, nb_steps_trn, shape_trn, 15,
-                                  shard=(parallel.rank(), parallel.world_size()))
+        shard = (parallel.rank(), parallel.world_size())
+        if getattr(model, 'engine', None) is not None and os.environ.get('DC_HOST_BATCHES', '0') != '1':
+            # the HIP model: summaries / masks go to HBM once, the generator sends four longs per item (dc_crop_augment)
+            model.engine.set_crop_sources(S_summ, M_summ)
+            gen_trn = self._device_batch_gen(S_summ, M_summ, names, yctrn, batch_size_trn, nb_steps_trn, shape_trn, 15, shard=shard)
+        else:
+            gen_trn = self._batch_gen(S_summ, M_summ, names, yctrn, batch_size_trn, nb_steps_trn, shape_trn, 15, shard=shard)
 
         tic = int(time())
         callbacks = [_ValidationMetricsCB(model_val, S_summ, M_summ, names, ycval)]
@@ -285,7 +424,7 @@ class UNet2DSummary(object):
             callbacks += [
                 CSVLogger('%s/%d_metrics.csv' % (self.cpdir, tic)),
                 ModelCheckpoint('%s/%d_model_{epoch:02d}_{val_nf_f1_mean:.3f}.hdf5' % (self.cpdir, tic), mode='max',
-                                monitor='val_nf_f1_mean', save_best_only=False, verbose=1),
+                                monitor='val_nf_f1_mean', save_best_only=False, verbose=1, background=True),
             ]
         callbacks += [ReduceLROnPlateau(monitor='F1', factor=0.5, patience=5, min_lr=1e-4, mode='max')]
         callbacks += list(keras_callbacks)
@@ -308,8 +447,12 @@ class UNet2DSummary(object):
         return self._batch_gen_impl(S_summ, M_summ, names, y_coords, batch_size, nb_steps, window_shape, nb_max_augment,
                                     scores_path, None)
 
-    def _batch_gen_impl(self, S_summ, M_summ, names, y_coords, batch_size, nb_steps, window_shape, nb_max_augment,
-                        scores_path, mine):
+    def _item_stream(self, S_summ, M_summ, names, y_coords, batch_size, nb_steps, window_shape, nb_max_augment,
+                     scores_path, mine):
+        """Phase 1 of every batch -- the reference's random stream itself (unet_2d_summary.py:479-527): EVERY draw of the
+        global batch is made, in order, from numpy's global RNG; yields the items of this rank's slice `mine` (None: all) as
+        (index in the slice, dataset, y0, y1, x0, x1, augmentation indices).  What is done with them -- numpy crops on the
+        host (_batch_gen_impl) or four longs per item for dc_crop_augment (_device_batch_gen) -- is phase 2."""
         rng = np.random
         b0, b1 = (mine.start, mine.stop) if mine is not None else (0, batch_size)
         hw, ww = window_shape
@@ -320,23 +463,12 @@ class UNet2DSummary(object):
             ys, xs = np.where(m[ymin:ymax, :] == 1)          # NB relative to ymin, used as absolute (:474, :510)
             locs.append(np.stack([ys, xs], axis=1))
         probs = np.ones(n_ds) / n_ds
-        # crop sources in the batch dtypes (the reference's assignment into the float32 / uint8 batch arrays converts
-        # per item; the values are the same)
-        S_src = [np.ascontiguousarray(v, dtype=np.float32) for v in S_summ]
-        M_src = [np.ascontiguousarray(v).astype(np.uint8) for v in M_summ]
-        pool = None
-        if (b1 - b0) * hw * ww >= 8 * 256 * 256:
-            from concurrent.futures import ThreadPoolExecutor
-            pool = ThreadPoolExecutor(max_workers=min(4, b1 - b0))
         while True:
             if scores_path and os.path.exists(scores_path) and (nb_yields - 1) % nb_steps == 0:
                 with open(scores_path, 'rb') as fp:
                     scores = pickle.load(fp)
                 probs = np.array([1 - np.mean(scores[n]) for n in names])
                 probs /= probs.sum()
-            # Phase 1 (sequential: it IS the reference's random stream): every draw of the global batch, in order; items of
-            # other ranks only advance the stream.  Phase 2: the array work of this rank's items -- on a few threads for
-            # big windows (numpy's copies release the GIL), so that the one producer thread keeps up with the GPU step.
             specs = []
             # rng.choice(np.arange(n), p=probs) == searchsorted(cumsum(p) / cumsum(p)[-1], random_sample(), 'right') and
             # rng.choice(6, n) == randint(0, 6, size=n): numpy's own (legacy RandomState) implementation, minus its
@@ -357,6 +489,25 @@ class UNet2DSummary(object):
                 augs = rng.randint(0, len(_SIX), size=rng.randint(0, nb_max_augment + 1))
                 if b0 <= b < b1:
                     specs.append((b - b0, k, y0, y1, x0, x1, augs))
+            nb_yields += 1
+            yield specs
+
+    def _batch_gen_impl(self, S_summ, M_summ, names, y_coords, batch_size, nb_steps, window_shape, nb_max_augment,
+                        scores_path, mine):
+        b0, b1 = (mine.start, mine.stop) if mine is not None else (0, batch_size)
+        hw, ww = window_shape
+        # crop sources in the batch dtypes (the reference's assignment into the float32 / uint8 batch arrays converts
+        # per item; the values are the same)
+        S_src = [np.ascontiguousarray(v, dtype=np.float32) for v in S_summ]
+        M_src = [np.ascontiguousarray(v).astype(np.uint8) for v in M_summ]
+        pool = None
+        if (b1 - b0) * hw * ww >= 8 * 256 * 256:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=min(4, b1 - b0))
+        # Phase 1 (sequential: it IS the reference's random stream) comes from _item_stream.  Phase 2: the array work of this
+        # rank's items -- on a few threads for big windows (numpy's copies release the GIL).
+        for specs in self._item_stream(S_summ, M_summ, names, y_coords, batch_size, nb_steps, window_shape, nb_max_augment,
+                                       scores_path, mine):
             s_batch = np.empty((b1 - b0, hw, ww), dtype=np.float32)
             m_batch = np.empty((b1 - b0, hw, ww), dtype=np.uint8)
 
@@ -383,8 +534,27 @@ class UNet2DSummary(object):
             else:
                 for spec in specs:
                     materialise(spec)
-            nb_yields += 1
             yield s_batch, m_batch
+
+    def _device_batch_gen(self, S_summ, M_summ, names, y_coords, batch_size, nb_steps, window_shape, nb_max_augment=0,
+                          scores_path=None, shard=None):
+        """_batch_gen for the HIP model's fit(): the same random stream, but every item leaves the host as FOUR longs
+        (crop origin, row stride, extents, one of 8 dihedral maps) -- `dc_crop_augment` (include/dcunet.h) cuts, zero-fills
+        and permutes it out of the summaries / masks resident in HBM (UNetEngine.set_crop_sources), straight into the step's
+        input buffers.  No pixel leaves the host per step; the batch is bit-equal to _batch_gen's (tests/test_api_gpu.py).
+        Square windows only (fit() asserts them, :365-366)."""
+        hw, ww = window_shape
+        assert hw == ww
+        offs = crop_layout([np.shape(v) for v in S_summ])[0]
+        mine = parallel.shard_slice(batch_size, *shard) if shard is not None and shard[1] > 1 else None
+        n = (mine.stop - mine.start) if mine is not None else batch_size
+        for specs in self._item_stream(S_summ, M_summ, names, y_coords, batch_size, nb_steps, window_shape, nb_max_augment,
+                                       scores_path, mine):
+            items = np.zeros((n, 4), dtype=np.int64)
+            for i, k, y0, y1, x0, x1, augs in specs:
+                wk = int(np.shape(S_summ[k])[1])
+                items[i] = (offs[k] + y0 * wk + x0, wk, (max(y1 - y0, 0) << 32) | max(x1 - x0, 0), _D4_BITS[id(_compose_six(augs))])
+            yield DeviceBatch(items, hw)
 
     def predict(self, dataset_paths, model_path, window_shape=(512, 512), print_scores=False, save=False,
                 augmentation=False, threshold=0.5):

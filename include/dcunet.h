@@ -8,14 +8,15 @@
  * ctypes binding a maintainer would add is shown in INTEGRATION.md.
  *
  * Conventions
- *   - All pointers are DEVICE pointers (plain pointers, no torch types).
+ *   - All pointers are DEVICE pointers (plain pointers, no torch types); the one
+ *     exception, dc_crop_augment's `items_host`, says so in its name.
  *   - Activations NHWC fp32; conv kernels HWIO (3,3,Cin,Cout); transposed-conv
  *     kernels (2,2,Cout,Cin)  -- Keras `channels_last` layouts.
  *   - "ld" arguments are pixel strides in floats: a tensor argument `p, ld`
  *     addresses channel c of pixel i at p[i*ld + c] (lets producers write into
  *     channel slices of a concat buffer; pass ld == C for a dense tensor).
- *   - The library never allocates, frees or retains memory; workspaces are
- *     caller-allocated (sizes from the *_ws_floats helpers).  There is no
+ *   - The library never allocates, frees or retains DEVICE memory; workspaces
+ *     are caller-allocated (sizes from the *_ws_floats helpers).  There is no
  *     hipMalloc / hipFree / hipStreamSynchronize anywhere in the library.
  *   - Every launch is asynchronous on `stream` (a hipStream_t passed as void*;
  *     NULL = the legacy default stream).  The caller sets the device.
@@ -409,6 +410,39 @@ int dc_adam_step_flat(float* p, const float* g, float* m, float* v, long n, floa
 int dc_gather_maps(const float* in, const int* maps, float* out, int K, long n, dc_stream_t stream);
 int dc_tta_merge(const float* preds, const int* invmaps, int K, int H, int W, int hs, int ws, double threshold,
                  uint8_t* mask, float* mean_out, dc_stream_t stream);
+
+/* ---- training-batch assembly on the device: UNet2DSummary._batch_gen  unet_2d_summary.py:434-530 -----------------
+ * S (float32) / M (uint8): the normalised summary images / flattened masks of ALL datasets, concatenated into one device
+ * buffer each (src_elems elements; same layout for both), uploaded once per fit().  The host draws the reference's random
+ * stream (:479-527) and describes item b by four longs
+ *   items_host[b] = { element offset of the crop origin (y0, x0) in S / M, row stride of that image, eh << 32 | ew, d4 }:
+ * the eh x ew crop is zero-filled to the (hw, hw) window (:505-521) and permuted by the composition of the drawn flips /
+ * rot90s (:524-527), one of 8 dihedral maps:  out[i][j] = win[r][c], (r, c) = (d4 & 1) ? (j, i) : (i, j),
+ * r = (d4 & 2) ? hw-1-r : r, c = (d4 & 4) ? hw-1-c : c.  x: float32 [B][hw][hw], y: uint8 [B][hw][hw].
+ * items_host is the ONE HOST pointer of this ABI: the items are validated against src_elems and travel in the kernel
+ * argument block (chunks of DC_CROP_MAX_ITEMS) -- nothing is staged, copied asynchronously or retained. */
+#define DC_CROP_MAX_ITEMS 64
+int dc_crop_augment(const float* S, const uint8_t* M, long src_elems, const long* items_host, int B, int hw,
+                    float* x, uint8_t* y, dc_stream_t stream);
+/* out[n][r][c] = p[n][y0 + r][x0 + c] > 0.5 (uint8): numpy's `mp[y0:y1, x0:x1].round()` of _ValidationMetricsCB
+ * (unet_2d_summary.py:90-91; half-to-even: 0.5 -> 0) on N probability maps of H x W. */
+int dc_round_window_u8(const float* p, int N, int H, int W, int y0, int y1, int x0, int x1, uint8_t* out,
+                       dc_stream_t stream);
+
+/* ---- host-side Neurofinder scoring of the validation callback  unet_2d_summary.py:90-91 -> datasets/nf.py:153-174 -----
+ * HOST pointers, no device work, no stream: the per-mask scoring _ValidationMetricsCB runs 6 x n times per epoch, as one native
+ * call (the GIL is released around it, so scoring threads run beside the validation forwards).  truth / pred: uint8 [H][W]
+ * (non-zero = foreground).  8-connected components numbered in raster order of their first pixel (skimage.measure.label's
+ * default on 2-D input); neurofinder.centers with `threshold` (5 in the reference's nf_mask_metrics) and neurofinder.shapes
+ * (threshold inf) restated as in deep_calcium_amd/nf_metrics.py, bit-identical to it (tests/test_nf_matching.py).
+ * counts[4] = { regions in truth, regions in pred, centre hits, matched pairs np }; inc[k] / exc[k] (k < np <= cap) =
+ * |A & B| / |A| and |A & B| / |B| of the k-th matched pair in the order of the truth's regions (the caller takes the means:
+ * recall = hits / counts[0], precision = hits / counts[1]).
+ * ws: dc_host_nf_ws_bytes(H, W) bytes of HOST scratch owned by the caller (one per scoring thread; nothing is allocated). */
+long dc_host_nf_ws_bytes(int H, int W);
+int dc_host_nf_pairs(const uint8_t* truth, const uint8_t* pred, int H, int W, double threshold, int* counts,
+                     double* inc, double* exc, int cap, void* ws);
+int dc_host_label8(const uint8_t* mask, int H, int W, int* labels, int* n, void* ws);
 
 /* misc */
 int dc_fill(float* p, long n, float value, dc_stream_t stream);

@@ -147,3 +147,47 @@ def test_matching_is_greedy_in_ground_truth_order_not_optimal():
     assert (p, r, f1) == (0.5, 0.5, 0.5)
     # shapes() runs the same greedy pass with an infinite threshold: A-P1 and then B-P2 pair up, both without overlap
     assert (i, e) == (0.0, 0.0)
+
+
+def _blob_mask(rs, h, w, n):
+    m = np.zeros((h, w))
+    yy, xx = np.ogrid[:h, :w]
+    for _ in range(n):
+        cy, cx, r = rs.randint(0, h), rs.randint(0, w), rs.randint(2, 6)
+        m[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 1
+    return m
+
+
+def test_native_scorer_is_bit_identical_to_the_list_restatement(dclib):
+    """dc_host_nf_pairs (csrc/nf_score.cpp: what the validation callback's scoring thread runs) against nf_metrics' literal
+    region-list restatement of neurofinder.centers / shapes AND against its label-image form, on 300 random mask pairs:
+    shifted / eroded blobs, extra detections, salt noise (snake-like components, label merges), checkerboards and stripes
+    (the worst cases of the union-find), empty masks on either side, 1-pixel-high images.  Equal tuples, not close ones."""
+    from scipy import ndimage
+    from deep_calcium_amd import nf_metrics as nm
+    rs = np.random.RandomState(0)
+    sc = nm.NativeScorer(130 * 520)
+    lab, n = np.zeros(130 * 520, np.int32), np.zeros(1, np.int32)
+    for t in range(300):
+        h, w = rs.randint(1, 130), rs.randint(1, 520)
+        m = _blob_mask(rs, h, w, rs.randint(0, 70))
+        mp = np.roll(m, rs.randint(-4, 5, 2), (0, 1))
+        mp[rs.random_sample(mp.shape) < 0.02] = 0
+        if t % 3 == 0:
+            mp = np.maximum(mp, _blob_mask(rs, h, w, rs.randint(0, 30)))
+        if t % 5 == 0:
+            mp = (rs.random_sample(mp.shape) < 0.3).astype(float)
+        if t % 7 == 0:
+            mp = (np.indices(mp.shape).sum(0) % 2 == 0).astype(float) if t % 14 == 0 else (np.indices(mp.shape)[1] % 2 == 0).astype(float)
+        if t % 17 == 0:
+            mp[:] = 0
+        if t % 19 == 0:
+            m[:] = 0
+        want = nm.nf_mask_metrics_lists(m, mp)
+        assert sc(m, mp) == want, t
+        assert nm.nf_mask_metrics(m, mp) == want, t
+        u = np.ascontiguousarray(mp != 0, dtype=np.uint8)
+        dclib.dc_host_label8(u.ctypes.data, h, w, lab.ctypes.data, n.ctypes.data, sc.ws.ctypes.data)
+        ref, nr = ndimage.label(u, structure=nm._EIGHT)
+        assert nr == n[0] and np.array_equal(ref.ravel(), lab[:h * w]), t
+    assert nm.nf_mask_metrics_native(m, mp) == nm.nf_mask_metrics_lists(m, mp)
