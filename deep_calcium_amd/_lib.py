@@ -7,6 +7,8 @@ the product raises (`DcunetError`); nothing here ever routes to a CPU path.
 import ctypes
 import os
 import re
+import struct
+import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, '..', 'include', 'dcunet.h')
@@ -60,6 +62,108 @@ def header_abi_version(path=HEADER):
     return int(m.group(1))
 
 
+class Var(object):
+    """A launch argument that changes from step to step (a dropout seed, Adam's lr_t, the batch pointers): recorded on a tape
+    by KEY, supplied by value at every replay."""
+    __slots__ = ('key', 'value')
+
+    def __init__(self, key, value):
+        self.key, self.value = key, value
+
+
+MARK = '__mark__'        # a recorded position where the caller runs Python between two replayed segments (a collective)
+
+
+def _bits_of_double(x):
+    return struct.unpack('<q', struct.pack('<d', float(x)))[0]
+
+
+def _pack(value, ctype):
+    """One argument as the signed 8-byte slot dc_tape_append / dc_tape_replay take."""
+    if ctype in (ctypes.c_float, ctypes.c_double):
+        return _bits_of_double(value)
+    if value is None:
+        return 0
+    v = int(value)
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def ops_equal(a, b):
+    """Two recordings of the same phase of a step: the same entry points with the same arguments (Vars: the same keys)."""
+    if len(a) != len(b):
+        return False
+    for (na, xa), (nb, xb) in zip(a, b):
+        if na != nb:
+            return False
+        if na == MARK:
+            if xa != xb:
+                return False
+            continue
+        if len(xa) != len(xb):
+            return False
+        for u, v in zip(xa, xb):
+            if type(u) is Var or type(v) is Var:
+                if type(u) is not type(v) or u.key != v.key:
+                    return False
+            elif u != v:
+                return False
+    return True
+
+
+class Tape(object):
+    """A recorded enqueue sequence [(entry point name, args) | (MARK, tag)] as a dc_tape_* object (include/dcunet.h):
+    replay(values) re-issues it from C -- values: {Var key: current value} --, calling on_mark(tag) between the segments."""
+
+    def __init__(self, lib, ops):
+        self.lib = lib
+        self.handle = ctypes.c_void_p()
+        lib.dc_tape_create(ctypes.byref(self.handle))
+        self.keys, self.ctypes_of, self.segments = [], [], []
+        slot_of = {}
+        n = first = 0
+        for name, args in ops:
+            if name == MARK:
+                self.segments.append((first, n - first, args))
+                first = n
+                continue
+            argtypes = lib.protos[name][1]
+            packed, patches = [], []
+            for i, (a, t) in enumerate(zip(args, argtypes)):
+                if type(a) is Var:
+                    if a.key not in slot_of:
+                        slot_of[a.key] = len(self.keys)
+                        self.keys.append(a.key)
+                        self.ctypes_of.append(t)
+                    patches.append((i, slot_of[a.key]))
+                    a = a.value
+                packed.append(_pack(a, t))
+            lib.dc_tape_append(self.handle, name.encode(), (ctypes.c_long * len(packed))(*packed), len(packed))
+            for i, slot in patches:
+                lib.dc_tape_patch(self.handle, n, i, slot)
+            n += 1
+        self.segments.append((first, n - first, None))
+        self.n = n
+        self._vals = (ctypes.c_long * max(len(self.keys), 1))()
+        self._replay = lib.dc_tape_replay
+
+    def replay(self, values, on_mark=None):
+        vals = self._vals
+        for i, (k, t) in enumerate(zip(self.keys, self.ctypes_of)):
+            vals[i] = _pack(values[k], t)
+        nv = len(self.keys)
+        for first, count, tag in self.segments:
+            if count:
+                self._replay(self.handle, first, count, vals, nv)
+            if tag is not None:
+                on_mark(tag)
+
+    def __del__(self):
+        try:
+            self.lib.cdll.dc_tape_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class _Lib(object):
     def __init__(self, path=LIB_PATH):
         if not os.path.exists(path):
@@ -82,13 +186,36 @@ class _Lib(object):
             fn = getattr(self.cdll, name)             # AttributeError here = ABI/header mismatch
             fn.restype = restype
             fn.argtypes = argtypes
+        self._tl = threading.local()                  # per-thread recording list (Tape): None = launches are not recorded
+
+    # ---- recording (deep_calcium_amd/net.py _taped): every checked launch of THIS thread is also appended to a list ----
+    def record_begin(self):
+        self._tl.rec = []
+
+    def record_end(self):
+        rec, self._tl.rec = self._tl.rec, None
+        return rec
+
+    def recording(self):
+        return getattr(self._tl, 'rec', None) is not None
+
+    def mark(self, tag):
+        rec = getattr(self._tl, 'rec', None)
+        if rec is not None:
+            rec.append((MARK, tag))
 
     def __getattr__(self, name):
         fn = getattr(self.cdll, name)
         if name in self._plain:
             return fn
 
+        tl = self._tl
+
         def checked(*args):
+            rec = getattr(tl, 'rec', None)
+            if rec is not None:
+                rec.append((name, args))
+                args = tuple(a.value if type(a) is Var else a for a in args)
             rc = fn(*args)
             if rc != 0:
                 raise DcunetError('%s failed (%d): %s' % (name, rc, self.cdll.dc_last_error().decode()))

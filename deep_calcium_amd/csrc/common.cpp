@@ -32,6 +32,20 @@ extern "C" int dc_event_create(void** ev) {
   *ev = (void*)e;
   return DC_OK;
 }
+extern "C" int dc_event_create_sync(void** ev) {
+  DC_REQUIRE(ev, DC_EINVAL, "dc_event_create_sync: null");
+  hipEvent_t e;
+  hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  DC_REQUIRE(rc == hipSuccess, DC_EHIP, "hipEventCreateWithFlags: %s", hipGetErrorString(rc));
+  *ev = (void*)e;
+  return DC_OK;
+}
+extern "C" int dc_stream_wait_event(dc_stream_t stream, void* ev) {
+  DC_REQUIRE(ev, DC_EINVAL, "dc_stream_wait_event: null event");
+  hipError_t rc = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0);
+  DC_REQUIRE(rc == hipSuccess, DC_EHIP, "hipStreamWaitEvent: %s", hipGetErrorString(rc));
+  return DC_OK;
+}
 extern "C" int dc_event_record(void* ev, dc_stream_t stream) {
   hipError_t rc = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
   DC_REQUIRE(rc == hipSuccess, DC_EHIP, "hipEventRecord: %s", hipGetErrorString(rc));

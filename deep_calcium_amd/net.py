@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import parallel
-from ._lib import lib, DcunetError
+from ._lib import lib, DcunetError, Tape, Var, ops_equal
 
 BN_EPS = 1e-3
 
@@ -315,6 +315,13 @@ class UNetEngine(object):
         self.abound = torch.zeros(o, dtype=torch.float32, device=dev)
         self._ovf = torch.zeros(4, dtype=torch.float32, device=dev)
         self._bufs = {}
+        # launch tapes (csrc/tape.cpp): the enqueue sequence of each phase of a steady-state train step, recorded once (and
+        # verified against a second recording) per key, then replayed from C.  DC_TAPES=0: every launch from Python.
+        self.use_tapes = os.environ.get('DC_TAPES', '1') != '0'
+        self._tapes = {}
+        self.tape_replays = 0
+        self._evpool, self._ev_i = [], 0
+        self._tail = None
         self._packed_dirty = True
         self._fold_dirty = True
         self.iterations = 0
@@ -441,6 +448,63 @@ class UNetEngine(object):
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    # ---- stream choreography through the C ABI (so that a tape records it like any launch) -----------------------------
+    def _ev(self):
+        """The next ordering-only event of this step: a pool of persistent library events handed out in call order (the k-th
+        hand-off of every step uses the same event: a recorded tape stays valid)."""
+        i = self._ev_i
+        self._ev_i = i + 1
+        if i == len(self._evpool):
+            import ctypes
+            h = ctypes.c_void_p()
+            rc = self.L.cdll.dc_event_create_sync(ctypes.byref(h))
+            if rc != 0:
+                raise DcunetError('dc_event_create_sync failed (%d): %s' % (rc, self.L.cdll.dc_last_error().decode()))
+            self._evpool.append(h.value)
+        return self._evpool[i]
+
+    def _record(self, stream_h):
+        ev = self._ev()
+        self.L.dc_event_record(ev, stream_h)
+        return ev
+
+    def _wait(self, stream_h, ev):
+        self.L.dc_stream_wait_event(stream_h, ev)
+
+    def _wait_stream(self, dst_h, src_h):
+        """work queued on dst from here on runs after everything queued on src so far"""
+        self._wait(dst_h, self._record(src_h))
+
+    def _v(self, key, value):
+        """A per-step launch argument: wrapped for the tape while one is being recorded."""
+        return Var(key, value) if self.L.recording() else value
+
+    def _taped(self, key, body, values, post_attrs=(), on_mark=None):
+        """Run one phase of a step: body() enqueues it launch by launch (and is what gets recorded); once two consecutive
+        recordings under `key` agree, the phase is replayed from C with `values()` = {Var key: this step's value}.  `key` must
+        hold every piece of state body()'s control flow reads; post_attrs: attributes body() leaves behind (restored after a
+        replay)."""
+        if not self.use_tapes or not hasattr(self.L, 'record_begin'):
+            return body()
+        ent = self._tapes.get(key)
+        if ent is not None and ent['tape'] is not None:
+            self.tape_replays += 1
+            ent['tape'].replay(values(), on_mark)
+            for a, v in ent['post'].items():
+                setattr(self, a, v)
+            return ent['ret']
+        self.L.record_begin()
+        try:
+            ret = body()
+        finally:
+            ops = self.L.record_end()
+        post = dict((a, getattr(self, a)) for a in post_attrs)
+        if ent is not None and ent['post'] == post and ops_equal(ent['ops'], ops):
+            ent.update(tape=Tape(self.L, ops), ret=ret)
+        else:
+            self._tapes[key] = dict(ops=ops, tape=None, post=post, ret=ret)
+        return ret
 
     def buf(self, name, numel, dtype=torch.float32):
         t = self._bufs.get(name)
@@ -924,7 +988,7 @@ class UNetEngine(object):
             return m.data_ptr(), keep, 0
         h, w = self._hw(l.lvl)
         seed = (step_seed * 1000003 + l.index * 7919) & 0xFFFFFFFFFFFFFFFF
-        return None, keep, parallel.shard_drop_seed(seed, self._last[0] * h * w * l.cout)
+        return None, keep, self._v(('seed', l.name), parallel.shard_drop_seed(seed, self._last[0] * h * w * l.cout))
 
     def _up_drop_args(self, lvl, masks, step_seed):
         rate = self.up_drop[lvl]
@@ -936,7 +1000,7 @@ class UNetEngine(object):
             return m.data_ptr(), 1.0 - rate, 0
         h, w = self._hw(lvl)
         seed = (step_seed * 1000003 + (100 + lvl) * 7919) & 0xFFFFFFFFFFFFFFFF
-        return None, 1.0 - rate, parallel.shard_drop_seed(seed, self._last[0] * h * w * self._cup(lvl))
+        return None, 1.0 - rate, self._v(('useed', lvl), parallel.shard_drop_seed(seed, self._last[0] * h * w * self._cup(lvl)))
 
     @_on_device
     def forward_train(self, x_dev, y_dev, masks=None, update_moving=True):
@@ -954,14 +1018,42 @@ class UNetEngine(object):
                     if rate > 0.0:
                         h, w = self._hw(lvl)
                         self._check_input("masks['u%d']" % lvl, masks.get('u%d' % lvl), torch.uint8, (N, h, w, self._cup(lvl)))
-        L, st = self.L, self._stream()
         self._settle_tail()
-        self.repack()
-        A, T = self._acts(N), self._train_bufs(N)
+        self._acts(N), self._train_bufs(N)
         step_seed = self.drop_seed + self.iterations
         self._last = (N, masks, step_seed, x_dev, y_dev)
         world = parallel.world_size()
         sync = self.bn_mode == 'sync' and world > 1
+
+        def body():
+            return self._forward_train_body(x_dev, y_dev, masks, update_moving)
+        if masks is not None or sync:          # explicit mask pointers / collectives between the launches: not taped
+            return body()
+        key = ('fwd', N, bool(update_moving), self.loss_kind, self._stream(), self._packed_dirty, world, parallel.rank())
+        return self._taped(key, body, lambda: self._step_values(x_dev, y_dev, step_seed),
+                           post_attrs=('_packed_dirty', '_fold_dirty', '_head_bwd_done'))
+
+    def _step_values(self, x_dev, y_dev, step_seed):
+        """This step's value of every per-step launch argument (_v keys) of the forward / backward tapes."""
+        vals = {'x': _ptr(x_dev), 'y': y_dev.data_ptr()}
+        for l in self.layers:
+            if l.drop > 0.0:
+                vals[('seed', l.name)] = self._drop_args(l, None, step_seed)[2]
+        if self.upsampling:
+            for lvl, rate in self.up_drop.items():
+                if rate > 0.0:
+                    vals[('useed', lvl)] = self._up_drop_args(lvl, None, step_seed)[2]
+        return vals
+
+    def _forward_train_body(self, x_dev, y_dev, masks, update_moving):
+        N = x_dev.shape[0]
+        L, st = self.L, self._stream()
+        self.repack()
+        A, T = self._acts(N), self._train_bufs(N)
+        step_seed = self._last[2]
+        world = parallel.world_size()
+        sync = self.bn_mode == 'sync' and world > 1
+        xp, yp = self._v('x', _ptr(x_dev)), self._v('y', y_dev.data_ptr())
         plan = self._plan(A)
         pooled_with_block = False
         for si, step in enumerate(plan):
@@ -988,7 +1080,7 @@ class UNetEngine(object):
             xin, bn = (bsrc[0], bsrc[1]) if bsrc is not None else (_ptr(src) if src is not None else None, None)
             if l.kind == 'conv' and l.cin == 1:
                 tiles = L.dc_conv3x3_c1_tiles(N, h, w, l.cout)
-                L.dc_conv3x3_c1_fwd(_ptr(x_dev), self.pview(self.pflat, l, 'k'), bias, _ptr(z), l.cout, stats,
+                L.dc_conv3x3_c1_fwd(xp, self.pview(self.pflat, l, 'k'), bias, _ptr(z), l.cout, stats,
                                     None, None, 0, None, 0, N, h, w, l.cout, st)
             elif l.kind == 'conv':
                 tiles = L.dc_conv3x3_tiles(N, h, w, l.cout)
@@ -1053,17 +1145,17 @@ class UNetEngine(object):
             ld0 = self.by_name['d0b']
             red = hsrc is not None
             L.dc_head_fwd_bwd(a_in, sc_in, sh_in, self.pview(self.pflat, lo, 'k'), self.pview(self.pflat, lo, 'b'),
-                              y_dev.data_ptr(), _ptr(A['p']), _ptr(T['part_ws']), _ptr(T['g'][0]), _ptr(T['head_gpart']),
+                              yp, _ptr(A['p']), _ptr(T['part_ws']), _ptr(T['g'][0]), _ptr(T['head_gpart']),
                               self.loss_kind, self.stat_ptr(ld0, 0) if red else None, self.stat_ptr(ld0, 1) if red else None,
                               _ptr(T['part_ws2']) if red else None, _ptr(T['amax_ws2']) if red else None, pixels, self.nfb, st)
             self._head_bwd_done = True
         elif hsrc is not None:
             L.dc_head_fwd_bnin(hsrc[0], hsrc[1][0], hsrc[1][1], self.pview(self.pflat, lo, 'k'),
-                               self.pview(self.pflat, lo, 'b'), y_dev.data_ptr(), _ptr(A['p']), _ptr(T['part_ws']),
+                               self.pview(self.pflat, lo, 'b'), yp, _ptr(A['p']), _ptr(T['part_ws']),
                                pixels, self.nfb, st)
         else:
             L.dc_head_fwd(_ptr(A['d0b']), self.pview(self.pflat, lo, 'k'), self.pview(self.pflat, lo, 'b'),
-                          y_dev.data_ptr(), _ptr(A['p']), _ptr(T['part_ws']), pixels, self.nfb, st)
+                          yp, _ptr(A['p']), _ptr(T['part_ws']), pixels, self.nfb, st)
         L.dc_reduce_partials_f64(_ptr(T['part_ws']), hb, 12, T['sums'].data_ptr(), st)
         return A['p']
 
@@ -1105,9 +1197,33 @@ class UNetEngine(object):
         gradients go to a side stream.  Hand-offs are stream events; what a weight gradient reads (dz or the table, and
         `da`) rotates over SLOTS buffers guarded by the event of the weight gradient that read it last."""
         N, masks, step_seed, x_dev, y_dev = self._last
+        self._settle_tail()
+        if getattr(self, '_side_stream', None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side = self._side_stream if self.streams == 2 else torch.cuda.current_stream(self.device)
+        world = parallel.world_size()
+        sync = self.bn_mode == 'sync' and world > 1
+
+        def body():
+            return self._backward_body(bucket_cb, defer_tail)
+
+        def on_mark(i):                      # replay: the same hand-over of a finished gradient range to the collective
+            with torch.cuda.stream(side):
+                bucket_cb(*self.grad_buckets()[i])
+        if masks is not None or sync:
+            return body()
+        key = ('bwd', N, self.loss_kind, self._stream(), side.cuda_stream, self._head_bwd_done, bool(defer_tail),
+               bucket_cb is not None, world, parallel.rank())
+        return self._taped(key, body, lambda: self._step_values(x_dev, y_dev, step_seed),
+                           post_attrs=('_tail', '_head_bwd_done', '_ev_i'), on_mark=on_mark)
+
+    def _backward_body(self, bucket_cb, defer_tail):
+        N, masks, step_seed, x_dev, y_dev = self._last
         L, st = self.L, self._stream()
         A, T = self._acts(N), self._train_bufs(N)
-        self._settle_tail()
+        self._ev_i = 0
+        self._tail = None
+        xp, yp = self._v('x', _ptr(x_dev)), self._v('y', y_dev.data_ptr())
         nfb = self.nfb
         f16 = self.mfma == 'f16x3'
         pixels0 = N * self.H * self.W
@@ -1124,24 +1240,23 @@ class UNetEngine(object):
                 fused_d0b = (_ptr(T['part_ws2']), _ptr(T['amax_ws2']), hb)
         elif hsrc is not None:
             ld0 = self.by_name['d0b']
-            L.dc_head_bwd_bnin_bnred(hsrc[0], hsrc[1][0], hsrc[1][1], _ptr(A['p']), y_dev.data_ptr(),
+            L.dc_head_bwd_bnin_bnred(hsrc[0], hsrc[1][0], hsrc[1][1], _ptr(A['p']), yp,
                                      self.pview(self.pflat, lo, 'k'), _ptr(gb[0]), _ptr(T['part_ws']), self.loss_kind,
                                      T['sums'].data_ptr(), self.stat_ptr(ld0, 0), self.stat_ptr(ld0, 1),
                                      _ptr(T['part_ws2']), _ptr(T['amax_ws2']), pixels0, nfb, st)
             fused_d0b = (_ptr(T['part_ws2']), _ptr(T['amax_ws2']), hb)
         else:
-            L.dc_head_bwd(_ptr(A['d0b']), _ptr(A['p']), y_dev.data_ptr(), self.pview(self.pflat, lo, 'k'),
+            L.dc_head_bwd(_ptr(A['d0b']), _ptr(A['p']), yp, self.pview(self.pflat, lo, 'k'),
                           _ptr(gb[0]), _ptr(T['part_ws']), self.loss_kind, T['sums'].data_ptr(), pixels0, nfb, st)
         L.dc_head_grad_finalize(_ptr(gpart), hb, nfb, self.pview(self.gflat, lo, 'k'),
                                 self.pview(self.gflat, lo, 'b'), st)
 
         main = torch.cuda.current_stream(self.device)
-        if getattr(self, '_side_stream', None) is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
         side = self._side_stream if self.streams == 2 else main
         two = side is not main
+        mh, sh_ = main.cuda_stream, side.cuda_stream          # raw handles: the hand-offs below go through the C ABI (tape-able)
         if two:
-            side.wait_stream(main)        # everything queued so far (forward, head) precedes the first wgrad
+            self._wait_stream(sh_, mh)    # everything queued so far (forward, head) precedes the first wgrad
         S = self.SLOTS
         slot_free = [None] * S            # event of the weight gradient that last read slot k's dz / table
         g_free = [None] * S               # event of the weight gradient that last read g[k] as `da` (dz on load)
@@ -1157,7 +1272,7 @@ class UNetEngine(object):
             that read it as `da` three blocks ago has finished."""
             k = (state['g'] + 1) % S
             if two and g_free[k] is not None:
-                main.wait_event(g_free[k])
+                self._wait(mh, g_free[k])
                 g_free[k] = None
             return k
 
@@ -1187,7 +1302,7 @@ class UNetEngine(object):
                                    _ptr(T['part_ws']), _ptr(T['amax_ws']) if dzin else None, pixels, l.cout, st)
                 fused = (_ptr(T['part_ws']), _ptr(T['amax_ws']), L.dc_bn_bwd_blocks(pixels, l.cout))
             if two and slot_free[k] is not None:
-                main.wait_event(slot_free[k])       # the weight gradient that last read this slot has finished
+                self._wait(mh, slot_free[k])        # the weight gradient that last read this slot has finished
                 slot_free[k] = None
             count = float((world if sync else 1) * pixels)
             gg = None
@@ -1239,15 +1354,12 @@ class UNetEngine(object):
                     L.dc_conv3x3_dgrad_dzin_f16x3(da_ptr, _ptr(z), coef, _ptr(self.wp_dgrad[l.name]), dx_ptr, *rargs,
                                                   N, h, w, l.cin, l.cout, st)
                 if two:
-                    ready = torch.cuda.Event()
-                    ready.record(main)
-                    side.wait_event(ready)
-                sw = side.cuda_stream
+                    self._wait_stream(sh_, mh)
+                sw = sh_
                 L.dc_conv3x3_wgrad_dzin_f16x3(xa[0], xa[1], xa[2], self._ab_in(l), da_ptr, _ptr(z), coef, dk, ws,
                                               N, h, w, l.cin, l.cout, sw)
                 if two:
-                    ev = torch.cuda.Event()
-                    ev.record(side)
+                    ev = self._record(sh_)
                     slot_free[k] = ev
                     if da_g is not None:
                         g_free[da_g] = ev
@@ -1313,10 +1425,8 @@ class UNetEngine(object):
             if after:
                 fused_next = dgrad()
             if two:
-                ready = torch.cuda.Event()
-                ready.record(main)
-                side.wait_event(ready)
-            sw = side.cuda_stream
+                self._wait_stream(sh_, mh)
+            sw = sh_
             if side_fin:
                 finalize(sw)
             if bsrc is not None and l.kind == 'conv':
@@ -1335,9 +1445,7 @@ class UNetEngine(object):
             else:
                 L.dc_convT2x2_wgrad(x_in, dz, dk, ws, N, h // 2, w // 2, l.cin, l.cout, sw)
             if two:
-                ev = torch.cuda.Event()
-                ev.record(side)
-                slot_free[k] = ev
+                slot_free[k] = self._record(sh_)
             if dx_ptr is not None and not after:
                 fused_next = dgrad()
             return fused_next
@@ -1370,7 +1478,8 @@ class UNetEngine(object):
             if bucket_cb is None:
                 return
             if two:
-                side.wait_stream(main)      # dbias / dgamma / dbeta / head gradients are written on the main stream
+                self._wait_stream(sh_, mh)  # dbias / dgamma / dbeta / head gradients are written on the main stream
+            L.mark(i)                       # (a tape is cut here: the collective is issued from Python between two segments)
             with torch.cuda.stream(side):
                 bucket_cb(*self.grad_buckets()[i])
 
@@ -1404,26 +1513,25 @@ class UNetEngine(object):
             state['g'] = ko
             if lvl == 0:
                 if two and defer_tail and bucket_cb is None:
-                    self._tail = torch.cuda.Event()       # everything the side stream has been given so far
-                    self._tail.record(side)
-                block_bwd(la, _ptr(x_dev), _ptr(gb[ko]), c, None, fused=fa, da_g=ko)
+                    self._tail = self._record(sh_)        # everything the side stream has been given so far
+                block_bwd(la, xp, _ptr(gb[ko]), c, None, fused=fa, da_g=ko)
             else:
                 kn = g_next()
                 block_bwd(la, _ptr(A['pool%d' % (lvl - 1)]), _ptr(gb[ko]), c, _ptr(gb[kn]), fused=fa, da_g=ko)
                 state['g'] = kn
-        if two and getattr(self, '_tail', None) is None:
-            main.wait_stream(side)        # gflat is complete once both streams have drained
+        if two and self._tail is None:
+            self._wait_stream(mh, sh_)    # gflat is complete once both streams have drained
 
     def _join_side(self):
         side = getattr(self, '_side_stream', None)
         if side is not None:
-            torch.cuda.current_stream(self.device).wait_stream(side)
+            self._wait_stream(self._stream(), side.cuda_stream)
 
     def _settle_tail(self):
         """backward(defer_tail=True) returns with the weight-gradient stream still on the first layer's dW / db (it reads
         x, z, g buffers and writes gflat); only adam_step() joins it underneath its own work.  Anything else that follows --
         another forward_train / backward (an exception between the two calls of a step), grads() -- joins here first."""
-        if getattr(self, '_tail', None) is not None:
+        if self._tail is not None:
             self._tail = None
             self._join_side()
 
@@ -1431,13 +1539,24 @@ class UNetEngine(object):
     def adam_step(self, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-8, grad_scale=1.0):
         """Keras-2.0.6 Adam over the flat buffers; `iterations` counts completed steps."""
         t = self.iterations + 1
-        lr_t = lr * np.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t)
+        lr_t = float(lr * np.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t))
+        side = getattr(self, '_side_stream', None)
+        key = ('adam', self._stream(), side.cuda_stream if side is not None else 0, self._tail is not None, float(beta_1),
+               float(beta_2), float(epsilon), float(grad_scale), self._packed_dirty)
+        self._taped(key, lambda: self._adam_body(lr_t, beta_1, beta_2, epsilon, grad_scale), lambda: {'lr_t': lr_t},
+                    post_attrs=('_packed_dirty', '_tail', '_ev_i'))
+        self.iterations = t
+        self._fold_dirty = True
+
+    def _adam_body(self, lr_t, beta_1, beta_2, epsilon, grad_scale):
+        st = self._stream()
+        lr_v = self._v('lr_t', lr_t)
 
         def adam(lo, hi):
             if hi > lo:
                 self.L.dc_adam_step_flat(_ptr(self.pflat, lo), _ptr(self.gflat, lo), _ptr(self.mflat, lo), _ptr(self.vflat, lo),
-                                         hi - lo, float(lr_t), beta_1, beta_2, epsilon, float(grad_scale), self._stream())
-        tail, self._tail = getattr(self, '_tail', None), None
+                                         hi - lo, lr_v, beta_1, beta_2, epsilon, float(grad_scale), st)
+        tail, self._tail = self._tail, None
         l0 = self.layers[0]
         lo = l0.off['k'][0]
         hi = l0.off['b'][0] + l0.cout
@@ -1446,21 +1565,18 @@ class UNetEngine(object):
             # (228 us at the benchmark size, with nothing left for the main stream).  Everything else is complete at `tail`:
             # its Adam update and the re-pack of the split-fp16 weight images (the first layer has none) run underneath,
             # the first layer's 320 parameters follow the join.
-            main = torch.cuda.current_stream(self.device)
-            main.wait_event(tail)
+            self._wait(st, tail)
             adam(0, lo)
             adam(hi, self.n_train)
             self._packed_dirty = True
             self.repack()
-            main.wait_stream(self._side_stream)
+            self._wait_stream(st, self._side_stream.cuda_stream)
             adam(lo, hi)
         else:
             if tail is not None:
-                torch.cuda.current_stream(self.device).wait_stream(self._side_stream)
+                self._wait_stream(st, self._side_stream.cuda_stream)
             adam(0, self.n_train)
             self._packed_dirty = True
-        self.iterations = t
-        self._fold_dirty = True
 
     def read_sums(self):
         """Host copy of the 12 loss/metric sums of the last forward_train (synchronises the stream)."""

@@ -36,7 +36,7 @@ typedef void* dc_stream_t;
 
 /* ABI revision: dc_version() of the loaded library must EQUAL the DC_ABI_VERSION of the header the caller was built /
  * bound against (argument lists change between revisions; the Python binding refuses a mismatch). */
-#define DC_ABI_VERSION 102
+#define DC_ABI_VERSION 103
 int dc_version(void);
 const char* dc_last_error(void);
 
@@ -453,9 +453,33 @@ int dc_scale_flat(float* p, long n, float s, dc_stream_t stream);
  * these wrap hipEventCreate/Record/Synchronize/ElapsedTime on the given stream (so bench.py measures on the
  * stream the kernels are launched on). */
 int dc_event_create(void** ev);
+/* an event for stream ordering only (hipEventDisableTiming): what the engine's two-stream backward hands between its streams */
+int dc_event_create_sync(void** ev);
+/* hipStreamWaitEvent(stream, ev): work queued on `stream` after this call waits for the work `ev` was last recorded behind */
+int dc_stream_wait_event(dc_stream_t stream, void* ev);
 int dc_event_record(void* ev, dc_stream_t stream);
 int dc_event_elapsed_ms(void* start, void* stop, float* ms);
 int dc_event_destroy(void* ev);
+
+/* ---- launch tape: a step's enqueue sequence, recorded once, replayed from C --------------------------------------------
+ * The reference's train loop calls train_on_batch once per step (model.fit_generator, unet_2d_summary.py:429-430); here a
+ * step is ~230 asynchronous launches whose sequence is FIXED once the engine is warm -- same entry points, pointers and
+ * shapes; only a few scalars (dropout seeds, Adam's lr_t, the batch pointers) change.  A tape holds such a sequence as
+ * (entry point name, arguments) and replays it with ONE call: every operation goes through its entry point unchanged
+ * (argument checks, status codes); `dc_tape_patch` marks the arguments that take a per-replay value.  HOST memory only; the
+ * tape retains the recorded pointer VALUES (the caller keeps those buffers alive and in place, as for any launch).
+ *   dc_tape_append: fn = the name of an int-returning launch entry point of this header (not: size / routing queries,
+ *     dc_crop_augment and dc_host_* [host data read at call time], the event create / elapsed / destroy helpers);
+ *     args8 = its arguments as 8-byte slots in declaration order: integers and pointers as longs, float / double
+ *     arguments as the bit pattern of a double.
+ *   dc_tape_patch(op, arg, slot): argument `arg` of operation `op` is values[slot] at replay (call in operation order).
+ *   dc_tape_replay(first, count, values, nvalues): operations [first, first + count); stops at the first failing one. */
+int dc_tape_create(void** tape);
+int dc_tape_destroy(void* tape);
+int dc_tape_append(void* tape, const char* fn, const long* args8, int nargs);
+int dc_tape_patch(void* tape, int op, int arg, int slot);
+int dc_tape_replay(void* tape, int first, int count, const long* values, int nvalues);
+int dc_tape_len(void* tape);
 
 #ifdef __cplusplus
 }

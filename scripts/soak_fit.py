@@ -1,7 +1,9 @@
 """Soak: the example's own training configuration (128x128 windows, batch 20, 100 steps per epoch, validation at 512x512 every
 epoch) for a few epochs on a synthetic Neurofinder directory; reports steps/s per epoch, device / host memory growth and the loss.
-    python scripts/soak_fit.py [epochs=3] [steps=100] [window=128] [batch=20]
-window 512, batch 16: the benchmark configuration through fit() -- the dz-on-load / joint backward kernels inside real training."""
+    python scripts/soak_fit.py [epochs=3] [steps=100] [window=128] [batch=20] [datasets=2]
+window 512, batch 16: the benchmark configuration through fit() -- the dz-on-load / joint backward kernels inside real training.
+datasets 19: the reference example's own run (all 19 Neurofinder training sets: 114 validation forwards + scorings per epoch).
+Prints, per epoch, the wall time split into training steps and the epoch-end callbacks (validation, CSV, checkpoint)."""
 import os, resource, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
@@ -17,20 +19,31 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 window = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 batch = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 hw = max(512, (window * 3 // 2 + 15) // 16 * 16)           # the training crop comes from the upper 75 % of the image
+nds = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 tmp = tempfile.mkdtemp(prefix='dc_soak_')
-for k, name in enumerate(('neurofinder.01.00', 'neurofinder.02.00')):
-    make_neurofinder_dir(tmp, name, hw=(hw, hw), seed=5 + k)
-paths = nf_load_hdf5('neurofinder.01.00,neurofinder.02.00', datasets_dir=tmp)
+from deep_calcium_amd.nf_datasets import NEUROFINDER_NAMES
+ds_names = [n for n in NEUROFINDER_NAMES if '.test' not in n][:nds]
+for k, name in enumerate(ds_names):
+    make_neurofinder_dir(tmp, name, hw=(hw, hw), seed=5 + k, frames=3)
+paths = nf_load_hdf5(','.join(ds_names), datasets_dir=tmp)
 
 
 class Probe(Callback):
+    """Last in the callback list: on_epoch_end runs after validation / CSV / checkpoint / LR plateau; on_batch_end of the
+    epoch's last step marks where the training steps end (host time: the step's metrics are back)."""
     def on_epoch_begin(self, epoch, logs=None):
         self.t = time.time()
 
+    def on_batch_end(self, batch, logs=None):
+        if batch == steps - 1:
+            self.t_steps = time.time()
+
     def on_epoch_end(self, epoch, logs=None):
         torch.cuda.synchronize()
-        print('epoch %d: %.1f steps/s incl. validation, loss %.4f F1 %.3f val_nf_f1 %.3f | device %.2f GB allocated, %.2f GB reserved, host RSS %.2f GB'
-              % (epoch, steps / (time.time() - self.t), logs['loss'], logs['F1'], logs.get('val_nf_f1_mean', float('nan')),
+        now = time.time()
+        print('epoch %d: %.1f steps/s incl. validation (%.2f ms/step: steps %.1f ms + epoch end %.1f ms), loss %.4f F1 %.3f val_nf_f1 %.3f | device %.2f GB allocated, %.2f GB reserved, host RSS %.2f GB'
+              % (epoch, steps / (now - self.t), (now - self.t) / steps * 1e3, (self.t_steps - self.t) * 1e3, (now - self.t_steps) * 1e3,
+                 logs['loss'], logs['F1'], logs.get('val_nf_f1_mean', float('nan')),
                  torch.cuda.memory_allocated() / 2 ** 30, torch.cuda.memory_reserved() / 2 ** 30,
                  resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20), flush=True)
 

@@ -62,13 +62,14 @@ def test_device_batches_equal_the_host_generator(hw, B, world):
     m = UNet2DSummary.__new__(UNet2DSummary)
     eng = _engine_for(S, M, hw)
     for r in range(world):
-        np.random.seed(7)
+        np.random.seed(7)                # (both draw from numpy's GLOBAL stream: one generator at a time)
         host = m._batch_gen(S, M, ['a', 'b', 'c'], yc, B, 10, (hw, hw), 15, shard=(r, world))
+        want = [next(host) for _ in range(4)]
         np.random.seed(7)
         devg = m._device_batch_gen(S, M, ['a', 'b', 'c'], yc, B, 10, (hw, hw), 15, shard=(r, world))
         seen = set()
         for i in range(4):
-            xs, ys = next(host)
+            xs, ys = want[i]
             b = next(devg)
             seen.update(int(v) for v in b.items[:, 3])
             x, y = eng.crop_batch(b.items)

@@ -1,0 +1,98 @@
+"""Launch tapes (include/dcunet.h dc_tape_*, csrc/tape.cpp, UNetEngine._taped): a train step replayed from C must be THE step --
+the same launches with the same arguments on the same streams -- so a taped run and a launch-by-launch run of the same seeded
+training are bit-identical, whatever changes between steps (dropout seeds, Adam's lr_t, the learning rate itself, the batch
+buffers, a set_weights() in between).  The reference's loop is model.fit_generator -> train_on_batch
+(/root/reference/deepcalcium/models/neurons/unet_2d_summary.py:429-430)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+def _pair(hw, nfb, **kw):
+    from deep_calcium_amd.model import Model, Adam
+    a, b = Model((hw, hw), nfb, **kw), Model((hw, hw), nfb, **kw)
+    for m in (a, b):
+        m.compile(Adam(0.002), 'binary_crossentropy')
+    b.engine.use_tapes = False
+    assert a.engine.use_tapes
+    return a, b
+
+
+def _batches(n, B, hw, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        x = torch.from_numpy(rs.standard_normal((B, hw, hw)).astype(np.float32)).cuda()
+        y = torch.from_numpy((rs.random_sample((B, hw, hw)) < 0.15).astype(np.uint8)).cuda()
+        out.append((x, y))
+    return out
+
+
+@pytest.mark.parametrize('hw,nfb,B', [(32, 8, 4), (64, 32, 3), (128, 32, 20)])
+def test_taped_training_is_bit_identical_to_launch_by_launch(hw, nfb, B):
+    a, b = _pair(hw, nfb)
+    data = _batches(3, B, hw, 5)                 # three (x, y) buffer pairs in rotation: the batch pointers are tape values
+    hist = [[], []]
+    for step in range(9):
+        if step == 6:                            # ReduceLROnPlateau halves the rate
+            a.optimizer.lr = b.optimizer.lr = 0.001
+        x, y = data[step % 3]
+        for k, m in enumerate((a, b)):
+            hist[k].append(m.train_on_device_batch(x, y))
+    torch.cuda.synchronize()
+    assert a.engine.tape_replays >= 3 * 6 and b.engine.tape_replays == 0      # steps 2.. of (forward, backward, adam) were replayed
+    assert hist[0] == hist[1]                    # loss + 7 metrics of every step (RNG dropout active: the seeds were patched)
+    assert torch.equal(a.engine.pflat, b.engine.pflat) and torch.equal(a.engine.sflat, b.engine.sflat)
+    assert torch.equal(a.engine.mflat, b.engine.mflat) and torch.equal(a.engine.vflat, b.engine.vflat)
+    # a set_weights() between two steps dirties the packed weight images: the next forward must re-pack (another tape key)
+    W = a.get_weights()
+    for m in (a, b):
+        m.set_weights([w * np.float32(0.5) if w.ndim == 4 else w for w in W])
+        for step in range(3):
+            m.train_on_device_batch(*data[step])
+    torch.cuda.synchronize()
+    assert torch.equal(a.engine.pflat, b.engine.pflat)
+    # the un-deferred backward (what grads() / the data-parallel path use) next to the deferred one
+    for m in (a, b):
+        for _ in range(3):
+            m.engine.forward_train(*data[0])
+            m.engine.backward()
+    ga, gb = a.engine.grads(), b.engine.grads()
+    for name in ga:
+        for u, v in zip(ga[name], gb[name]):
+            assert np.array_equal(u, v), name
+
+
+def test_tape_failure_names_the_operation(dclib):
+    """A replayed operation goes through its entry point's own checks: the failing one is named, its message kept."""
+    from deep_calcium_amd._lib import Tape, DcunetError
+    t = Tape(dclib, [('dc_fill', (torch.zeros(8, device='cuda').data_ptr(), 8, 1.0, None)),
+                     ('dc_conv3x3_dgrad', (None, None, None, 1, 8, 8, 8, 8, None))])
+    with pytest.raises(DcunetError, match=r'operation 1 \(dc_conv3x3_dgrad\) failed: dc_conv3x3_dgrad: null pointer'):
+        t.replay({})
+    with pytest.raises(DcunetError, match='not a tape-able entry point'):
+        Tape(dclib, [('dc_crop_augment', (0,) * 9)])
+
+
+def test_fit_through_tapes_and_device_batches_reaches_the_same_history(tmp_path, monkeypatch):
+    """UNet2DSummary.fit(): tapes on (default) and DC_TAPES=0 give the same history (RNG dropout on: prop_dropout_base 0.25)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_api_gpu import _make_datasets
+    from deep_calcium_amd import UNet2DSummary, unet_hip
+    paths = _make_datasets(tmp_path, n=2)
+
+    def run(tag):
+        np.random.seed(865)
+        u = UNet2DSummary(cpdir=str(tmp_path / tag), net_builder_func=lambda ws: unet_hip(ws, nb_filters_base=8))
+        hist, _ = u.fit(paths, shape_trn=(32, 32), shape_val=(96, 96), batch_size_trn=6, nb_steps_trn=8, nb_epochs=2)
+        return hist, u.model.engine.tape_replays
+
+    h1, r1 = run('taped')
+    monkeypatch.setenv('DC_TAPES', '0')
+    h0, r0 = run('plain')
+    assert r1 >= 3 * 12 and r0 == 0
+    assert h1 == h0
