@@ -5,10 +5,30 @@
 `UNet2DSummary` keeps the reference's fit()/predict() surface; `unet_hip` is the drop-in `net_builder_func`.
 Every tensor op runs as a hand-written gfx950 HIP kernel behind the C ABI in include/dcunet.h; there is no
 CPU fallback (importing is cheap and GPU-free, constructing a model requires the GPU and libdcunet.so).
+The public names are resolved on first use (PEP 562): importing a torch-free submodule (`deep_calcium_amd.keras_io`,
+`.nf_metrics`, `.layers` -- what the background checkpoint-writer process loads) does not import torch.
 """
 __version__ = '0.1.0'
 
-from .model import (Model, Adam, Callback, CSVLogger, ModelCheckpoint, ReduceLROnPlateau, History,  # noqa: F401
-                    unet_hip, load_model_with_new_input_shape, metrics_from_sums)
-from .unet2ds import UNet2DSummary, INVERTIBLE_2D_AUGMENTATIONS, _ValidationMetricsCB  # noqa: F401
-from .nf_metrics import nf_mask_metrics  # noqa: F401
+_EXPORTS = {
+    'model': ('Model', 'Adam', 'Callback', 'CSVLogger', 'ModelCheckpoint', 'ReduceLROnPlateau', 'History', 'unet_hip',
+              'load_model_with_new_input_shape', 'metrics_from_sums'),
+    'unet2ds': ('UNet2DSummary', 'INVERTIBLE_2D_AUGMENTATIONS', '_ValidationMetricsCB'),
+    'nf_metrics': ('nf_mask_metrics',),
+}
+_WHERE = dict((name, mod) for mod, names in _EXPORTS.items() for name in names)
+__all__ = sorted(_WHERE)
+
+
+def __getattr__(name):
+    mod = _WHERE.get(name)
+    if mod is None:
+        raise AttributeError('module %r has no attribute %r' % (__name__, name))
+    import importlib
+    value = getattr(importlib.import_module('.' + mod, __name__), name)
+    globals()[name] = value
+    return value
+
+
+def __dir__():
+    return sorted(list(globals()) + list(_WHERE))

@@ -559,28 +559,71 @@ class Model(object):
 
     def save(self, filepath, include_optimizer=True, background=False):
         """background=True: the parameters, moving statistics and Adam state are copied device -> pinned host memory on the
-        current stream (a snapshot of THIS moment: ~95 MB, a few ms of copy engine time) and a thread serialises and writes the
-        file while training goes on; wait_for_saves() joins it (one snapshot in flight at a time)."""
-        eng = self.engine
+        current stream (a snapshot of THIS moment: ~95 MB, a few ms of copy-engine time); a feeder thread dumps them raw
+        (one GIL-free write) and the checkpoint-writer PROCESS (deep_calcium_amd/_ckpt_writer.py) serialises the file while
+        training goes on, off this process's GIL.  wait_for_saves() collects the result (one snapshot in flight at a time)."""
         with_opt = include_optimizer and self.optimizer is not None
-        if background:
-            self.wait_for_saves()
-            snap = self._snapshot(with_opt)
-            import threading
-            box = []
-
-            def work():
-                try:
-                    snap['event'].synchronize()
-                    self._write(filepath, snap)
-                except BaseException as e:       # surfaced by wait_for_saves()
-                    box.append(e)
-            th = threading.Thread(target=work, daemon=False)
-            self._saving = (th, box, filepath)
-            th.start()
-            return
         self.wait_for_saves()
-        self._write(filepath, self._snapshot(with_opt, sync=True))
+        snap = self._snapshot(with_opt, sync=not background)
+        if not background:
+            from ._ckpt_writer import write_checkpoint
+            b = snap['bufs']
+            write_checkpoint(filepath, self.config, b['p'].numpy(), b['s'].numpy(), b['m'].numpy() if with_opt else None,
+                             b['v'].numpy() if with_opt else None, snap['meta'])
+            return
+        import threading
+        box = []
+
+        def feed():
+            try:
+                snap['event'].synchronize()
+                proc = self._writer_process()
+                b = snap['bufs']
+                parts = [b['p'].numpy(), b['s'].numpy()] + ([b['m'].numpy(), b['v'].numpy()] if with_opt else [])
+                raw = os.path.join('/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else
+                                   (os.path.dirname(os.path.abspath(filepath)) or '.'),
+                                   'dcunet_ckpt_%d_%d.raw' % (os.getpid(), id(self)))
+                with open(raw, 'wb') as fp:
+                    for a in parts:
+                        a.tofile(fp)
+                job = dict(raw=raw, path=os.path.abspath(filepath), config=self.config, meta=snap['meta'],
+                           sizes=[int(a.size) for a in parts] + ([0, 0] if not with_opt else []))
+                proc.stdin.write((json.dumps(job) + '\n').encode())
+                proc.stdin.flush()
+                reply = proc.stdout.readline().decode().strip()
+                if not reply.startswith('ok '):
+                    raise IOError(reply or 'the checkpoint writer process died')
+            except BaseException as e:       # surfaced by wait_for_saves()
+                box.append(e)
+        th = threading.Thread(target=feed, daemon=False)
+        self._saving = (th, box, filepath)
+        th.start()
+
+    def _writer_process(self):
+        proc = getattr(self, '_writer', None)
+        if proc is None or proc.poll() is not None:
+            import subprocess
+            import sys
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+            # a child that only ever runs numpy: it must never open the GPU (HIP_VISIBLE_DEVICES hides it anyway)
+            env['HIP_VISIBLE_DEVICES'] = ''
+            proc = self._writer = subprocess.Popen([sys.executable, '-m', 'deep_calcium_amd._ckpt_writer'], stdin=subprocess.PIPE,
+                                                   stdout=subprocess.PIPE, env=env, close_fds=True)
+            import atexit
+            import weakref
+            ref = weakref.ref(proc)
+
+            def stop():
+                pr = ref()
+                if pr is not None and pr.poll() is None:
+                    try:
+                        pr.stdin.close()
+                        pr.wait(timeout=10)
+                    except Exception:
+                        pr.kill()
+            atexit.register(stop)
+        return proc
 
     def wait_for_saves(self):
         pending, self._saving = getattr(self, '_saving', None), None
@@ -606,32 +649,9 @@ class Model(object):
             ev.record(torch.cuda.current_stream(eng.device))
             if sync:
                 ev.synchronize()
-        return dict(event=ev, bufs=bufs, with_opt=with_opt, iterations=int(eng.iterations), loss=self.loss,
-                    metrics=list(self.metrics_names[1:]), opt_config=self.optimizer.get_config() if with_opt else None,
-                    compiled=self.optimizer is not None)
-
-    def _write(self, filepath, snap):
-        eng = self.engine
-        b = snap['bufs']
-        weights = eng.get_weights(p=b['p'].numpy(), s=b['s'].numpy())
-        with_opt = snap['with_opt']
-        tmp = '%s.partial.%d' % (filepath, os.getpid())      # a reader never sees a half-written checkpoint
-        if str(filepath).lower().endswith(('.hdf5', '.h5')):
-            from . import keras_io
-            opt = self._optimizer_state(b['m'].numpy(), b['v'].numpy(), snap['iterations'], snap['opt_config']) if with_opt else None
-            keras_io.write_keras_model(tmp, weights, self.config, optimizer=opt, loss=snap['loss'], metrics=snap['metrics'])
-        else:
-            arrays = {'w_%03d' % i: w for i, w in enumerate(weights)}
-            meta = dict(format='dcunet-npz-1', config=self.config, compiled=snap['compiled'])
-            if with_opt:
-                arrays['opt_m'] = b['m'].numpy().copy()
-                arrays['opt_v'] = b['v'].numpy().copy()
-                meta['optimizer'] = dict(snap['opt_config'], iterations=snap['iterations'])
-                meta['loss'] = snap['loss']
-            arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-            with open(tmp, 'wb') as fp:
-                np.savez(fp, **arrays)
-        os.replace(tmp, filepath)
+        meta = dict(iterations=int(eng.iterations), loss=self.loss, metrics=list(self.metrics_names[1:]),
+                    opt_config=self.optimizer.get_config() if with_opt else None, compiled=self.optimizer is not None)
+        return dict(event=ev, bufs=bufs, with_opt=with_opt, meta=meta)
 
     def load_state(self, filepath, with_optimizer):
         state = read_checkpoint(filepath)
@@ -665,7 +685,7 @@ def read_checkpoint(path):
         it = int(oc.pop('iterations'))
         m, v = z['opt_m'], z['opt_v']
         ms, vs, o = [], [], 0
-        from .net import build_layer_table
+        from .layers import build_layer_table
         cfg = meta['config']
         for l in build_layer_table(cfg['nb_filters_base'], cfg.get('prop_dropout_base', 0.25),
                                    cfg.get('upsampling_or_transpose', 'transpose') != 'transpose'):

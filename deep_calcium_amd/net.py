@@ -44,44 +44,7 @@ def _on_device(fn):
     return wrapped
 
 
-class LayerSpec(object):
-    __slots__ = ('name', 'kind', 'cin', 'cout', 'mom', 'lvl', 'drop', 'off', 'soff', 'index')
-
-    def __init__(self, name, kind, cin, cout, mom, lvl, drop, index):
-        self.name, self.kind, self.cin, self.cout, self.mom, self.lvl, self.drop, self.index = \
-            name, kind, cin, cout, mom, lvl, drop, index
-        self.off = {}    # trainable: 'k','b','gamma','beta' -> (offset, shape) in pflat
-        self.soff = {}   # moving stats: 'mmean','mvar' -> offset in sflat
-
-    @property
-    def kshape(self):
-        if self.kind == 'conv':
-            return (3, 3, self.cin, self.cout)
-        if self.kind == 'convT':
-            return (2, 2, self.cout, self.cin)
-        return (1, 1, self.cin, self.cout)
-
-
-def build_layer_table(nfb=32, drp=0.25, upsampling=False):
-    """Weighted layers in graph-creation order (= Keras get_weights order), unet_2d_summary.py:172-221.
-    upsampling=True: the UpSampling2D branch (:160-161) -- no up-conv layers, first decoder conv sees 3c inputs."""
-    enc = [nfb << i for i in range(5)]
-    rates = {'e1b': drp, 'e2b': 2 * drp, 'e3b': 2 * drp, 'u3': 2 * drp, 'u2': 2 * drp, 'u1': 2 * drp, 'u0': drp}
-    L = []
-    cin = 1
-    for lvl, c in enumerate(enc):
-        tag = 'b' if lvl == 4 else 'e%d' % lvl
-        for sfx, ci in (('a', cin), ('b', c)):
-            L.append(LayerSpec(tag + sfx, 'conv', ci, c, 0.99, lvl, rates.get(tag + sfx, 0.0), len(L)))
-        cin = c
-    for lvl in (3, 2, 1, 0):
-        c = enc[lvl]
-        if not upsampling:
-            L.append(LayerSpec('u%d' % lvl, 'convT', 2 * c, c, 0.5, lvl, rates.get('u%d' % lvl, 0.0), len(L)))
-        L.append(LayerSpec('d%da' % lvl, 'conv', 3 * c if upsampling else 2 * c, c, 0.99, lvl, 0.0, len(L)))
-        L.append(LayerSpec('d%db' % lvl, 'conv', c, c, 0.99, lvl, 0.0, len(L)))
-    L.append(LayerSpec('out', 'head', nfb, 2, None, 0, 0.0, len(L)))
-    return L
+from .layers import LayerSpec, build_layer_table, assign_offsets, split_weights      # noqa: E402,F401  (torch-free: the checkpoint writer process imports them)
 
 
 _PINNED = collections.OrderedDict()      # key -> [pinned tensor, event of the last async H2D copy that read it | None]
@@ -255,16 +218,7 @@ class UNetEngine(object):
                 nm += ['bb', 'd3b', 'd2b', 'd1b']          # feed a Conv2DTranspose
         self.nm = frozenset(n for n in nm if self.by_name[n].drop <= 0.0)
         # ---- flat parameter layout -----------------------------------------------------------------
-        off = 0
-        soff = 0
-        for l in self.layers:
-            l.off['k'] = (off, l.kshape); off += int(np.prod(l.kshape))
-            l.off['b'] = (off, (l.cout,)); off += l.cout
-            if l.kind != 'head':
-                l.off['gamma'] = (off, (l.cout,)); off += l.cout
-                l.off['beta'] = (off, (l.cout,)); off += l.cout
-                l.soff['mmean'] = soff; soff += l.cout
-                l.soff['mvar'] = soff; soff += l.cout
+        off, soff = assign_offsets(self.layers)
         self.n_train = off
         self.n_stats = soff
         npad = (off + 3) // 4 * 4
@@ -398,16 +352,7 @@ class UNetEngine(object):
         p / s: host copies of pflat / sflat taken earlier (a checkpoint snapshot) instead of the live device buffers."""
         p = self.pflat.cpu().numpy() if p is None else p
         s = self.sflat.cpu().numpy() if s is None else s
-        out = []
-        for l in self.layers:
-            for key in ('k', 'b', 'gamma', 'beta'):
-                if key in l.off:
-                    o, shp = l.off[key]
-                    out.append(p[o:o + int(np.prod(shp))].reshape(shp).copy())
-            if l.kind != 'head':
-                out.append(s[l.soff['mmean']:l.soff['mmean'] + l.cout].copy())
-                out.append(s[l.soff['mvar']:l.soff['mvar'] + l.cout].copy())
-        return out
+        return split_weights(self.layers, p, s)
 
     def set_weights(self, weights):
         shapes = self.weight_shapes()
