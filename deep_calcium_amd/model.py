@@ -173,6 +173,10 @@ class ModelCheckpoint(Callback):
         else:
             self.model.save(path)
 
+    def on_train_begin(self, logs=None):
+        if self.background and hasattr(self.model, '_writer_process'):
+            self.model._writer_process()        # started now: its interpreter start-up overlaps the first epoch, not the second
+
     def on_train_end(self, logs=None):
         if hasattr(self.model, 'wait_for_saves'):
             self.model.wait_for_saves()
