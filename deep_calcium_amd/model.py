@@ -638,19 +638,30 @@ class Model(object):
                 raise IOError('writing %s failed: %r' % (path, box[0]))
 
     def _snapshot(self, with_opt, sync=False):
-        """Host copy of everything a checkpoint holds, taken on the engine's current stream into pinned buffers that are
-        reused from save to save (wait_for_saves() has made sure the previous writer is done with them)."""
+        """Host copy of everything a checkpoint holds, as of THIS point of the engine's stream.  Two hops: device -> device
+        scratch on the current stream (124 MB at HBM speed: ~0.1 ms in front of the next step), then scratch -> pinned host
+        memory on a separate copy stream (~4 ms of PCIe that the next epoch's first steps no longer wait for).  Both sets of
+        buffers are reused from save to save (wait_for_saves() has made sure the previous writer is done with them)."""
         eng = self.engine
         with torch.cuda.device(eng.device):
             eng._settle_tail()
+            srcs = (('p', eng.pflat), ('s', eng.sflat)) + ((('m', eng.mflat), ('v', eng.vflat)) if with_opt else ())
             bufs = getattr(self, '_snap_bufs', None)
             if bufs is None:
                 bufs = self._snap_bufs = dict((k, torch.empty(t.numel(), dtype=t.dtype).pin_memory()) for k, t in
                                               (('p', eng.pflat), ('s', eng.sflat), ('m', eng.mflat), ('v', eng.vflat)))
-            for k, t in (('p', eng.pflat), ('s', eng.sflat)) + ((('m', eng.mflat), ('v', eng.vflat)) if with_opt else ()):
-                bufs[k].copy_(t, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(eng.device))
+                self._snap_dev = dict((k, torch.empty_like(t)) for k, t in
+                                      (('p', eng.pflat), ('s', eng.sflat), ('m', eng.mflat), ('v', eng.vflat)))
+                self._snap_stream = torch.cuda.Stream(device=eng.device)
+            main = torch.cuda.current_stream(eng.device)
+            for k, t in srcs:
+                self._snap_dev[k].copy_(t, non_blocking=True)
+            self._snap_stream.wait_stream(main)
+            with torch.cuda.stream(self._snap_stream):
+                for k, t in srcs:
+                    bufs[k].copy_(self._snap_dev[k], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._snap_stream)
             if sync:
                 ev.synchronize()
         meta = dict(iterations=int(eng.iterations), loss=self.loss, metrics=list(self.metrics_names[1:]),
