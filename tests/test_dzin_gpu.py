@@ -289,8 +289,8 @@ def test_dzin_bound_when_dy_follows_xhat(dclib, noise):
     M = N * H * W
     rs = np.random.RandomState(5)
     x, z, mean, invstd, gamma, beta, _ = _block_case(rs, N, H, W, Cin, Cout)
-    gamma = np.abs(gamma) + 0.5                       # every gate's sign follows xhat's
-    beta = (np.abs(beta) + 3.0).astype(np.float32)    # gates open nearly everywhere: dy = da
+    gamma = (np.abs(gamma) * 0.3 + 0.5).astype(np.float32)
+    beta = (np.abs(beta) + 10.0).astype(np.float32)   # y = gamma xhat + beta > 0 for every |xhat| < 6: all gates open, dy = da
     xh = (z.astype(np.float64) - mean.astype(np.float64)) * invstd.astype(np.float64)
     s_c = 3e-3 * (rs.random_sample(Cout) + 0.5)
     da = (s_c * (xh + noise * rs.standard_normal(z.shape))).astype(np.float32)
