@@ -493,9 +493,14 @@ def main():
     timer.enabled = True
     eng.use_tapes = False                 # the instrumented steps issue every launch from Python, through the timer proxy
     model.ar_events = []                  # also bracket the part of the gradient exchange the step waits for
+    eng.sync_events = [] if eng._sync_bn() else None      # ... and the per-layer 'sync' BatchNorm messages
     for _ in range(2):
         model.train_on_device_batch(xd, yd)
     torch.cuda.synchronize()
+    syncbn = None
+    if eng.sync_events:
+        syncbn = (sum(a.elapsed_time(b) for a, b in eng.sync_events) / 2, len(eng.sync_events) // 2)
+    eng.sync_events = None
     n_launch, k_ms, k_flops = timer.summarize()
     k_bytes = timer.last_bytes
     ar_exposed = [a.elapsed_time(b) for a, b in model.ar_events]
@@ -556,6 +561,11 @@ def main():
                          'achieved_without_concurrent_wgrad_stream': round(iso_flops / (iso_ms * 1e-3) / 1e12, 3) if iso_ms > 0 else None,
                          'streams': streams, 'traffic_note': traffic_note},
         }
+        if syncbn is not None:
+            # 'sync' BatchNorm: the (forward: sum, sum of squares; backward: dgamma, dbeta) messages of <= 8 KB between two
+            # launches of every BatchNorm layer -- stream time from the launch in front of each all-reduce to its end
+            out['syncbn_allreduce_ms'] = round(syncbn[0], 3)
+            out['syncbn_allreduces_per_step'] = syncbn[1]
         if parallel.exchange_active():
             backend = torch.distributed.get_backend()
             out['rccl_ranks'] = world if backend == 'nccl' else 0      # ranks whose gradients travelled over RCCL (0: gloo run)

@@ -181,7 +181,7 @@ class _Lib(object):
                               '(`python -m deep_calcium_amd._build --force`)' % (path, got, want))
         # names whose int return is a count/size, not a status code
         self._plain = set(n for n, (rt, _, _) in self.protos.items()
-                          if rt is not ctypes.c_int or n.endswith('_tiles') or n.endswith('_blocks') or n.endswith('_floats') or n == 'dc_version')
+                          if rt is not ctypes.c_int or n.endswith('_tiles') or n.endswith('_blocks') or n.endswith('_floats') or n.endswith('_rows') or n == 'dc_version')
         for name, (restype, argtypes, _) in self.protos.items():
             fn = getattr(self.cdll, name)             # AttributeError here = ABI/header mismatch
             fn.restype = restype

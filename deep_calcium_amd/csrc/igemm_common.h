@@ -70,5 +70,9 @@ struct IgemmParams {
   // the BatchNorm partials of the same tile rows.
   float* splitWs;
   long splitSlab;
+  // role-split kernel only, forward launches with BatchNorm partials: 1 = every (workgroup, consumer set) Chan-merges the
+  // tiles it computes and writes ONE row stats[2 * blockIdx.x + set][Ncols][2] (dcunet.h dc_conv3x3_stats_rows) instead of one
+  // row per pixel tile
+  int statsPerWg;
 };
 

@@ -633,6 +633,7 @@ static int igemm_h_launch(IgemmParams p, hipStream_t st, const char* name, long*
 
 // Same tile-shape choice (and therefore the same `tiles` count for the BN partials) as the fp32 kernel.
 bool dc_igemm_pp_serves(const IgemmParams& p);                         // igemm_pp.hip: persistent role-split variant
+int dc_igemm_pp_stats_rows(const IgemmParams& p);
 int dc_igemm_pp_launch(IgemmParams p, hipStream_t st, const char* name);
 static int conv3x3_h_launch(IgemmParams p, hipStream_t st, long* query = nullptr) {
   if (query) *query = 0;
@@ -822,8 +823,36 @@ static int check_h(const char* fn, const void* a, const void* b, const void* c, 
   return DC_OK;
 }
 
+// BatchNorm-partial rows of a forward launch with stats_rows = this value (dcunet.h): one row per (workgroup, consumer set) where
+// the role-split kernel serves the launch, one per pixel tile elsewhere.
+static int stats_rows_of(int N, int H, int W, int Cin, int Cout) {
+  double dstat = 0.0;
+  IgemmParams p{};
+  p.N = N; p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W; p.Cin = Cin; p.Ncols = Cout; p.stats = &dstat;
+  p.biasMod = Cout; p.outLd = Cout;
+  const int tiles = dc_conv3x3_tiles(N, H, W, Cout);
+  if (!dc_igemm_pp_serves(p)) return tiles;
+  const int rows = dc_igemm_pp_stats_rows(p);
+  return rows > 0 && rows < tiles ? rows : tiles;
+}
+extern "C" int dc_conv3x3_stats_rows(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  return stats_rows_of(N, H, W, Cin, Cout);
+}
+// -> IgemmParams::statsPerWg for a caller-given stats_rows (0 / tiles: per tile), or an error
+static int stats_mode(const char* fn, const double* stats, int stats_rows, int N, int H, int W, int Cin, int Cout, int* per_wg) {
+  *per_wg = 0;
+  if (stats == nullptr || stats_rows == 0) return DC_OK;
+  const int tiles = dc_conv3x3_tiles(N, H, W, Cout);
+  if (stats_rows == tiles) return DC_OK;
+  DC_REQUIRE(stats_rows == stats_rows_of(N, H, W, Cin, Cout), DC_EINVAL,
+             "%s: stats_rows=%d is neither dc_conv3x3_tiles()=%d nor dc_conv3x3_stats_rows()", fn, stats_rows, tiles);
+  *per_wg = 1;
+  return DC_OK;
+}
+
 extern "C" int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld,
-                                    double* stats, const float* scale, const float* shift, int relu,
+                                    double* stats, int stats_rows, const float* scale, const float* shift, int relu,
                                     const float* in_abound, long in_abound_ld, float* out_absmax, long out_absmax_ld,
                                     float* splitk_ws, int N, int H, int W, int Cin, int Cout,
                                     dc_stream_t stream) {
@@ -838,6 +867,7 @@ extern "C" int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const floa
   p.outAbsmax = out_absmax; p.outAbsmaxLd = out_absmax_ld;
   p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = Cout;
   p.relu = relu; p.scatterCo = 0; p.biasMod = Cout; p.outLd = z_ld; p.splitWs = splitk_ws;
+  if ((rc = stats_mode("dc_conv3x3_fwd_f16x3", stats, stats_rows, N, H, W, Cin, Cout, &p.statsPerWg))) return rc;
   return conv3x3_h_launch(p, (hipStream_t)stream);
 }
 
@@ -869,7 +899,7 @@ extern "C" long dc_convT2x2_dgrad_splitk_ws_floats(int N, int H, int W, int Cin,
 }
 
 extern "C" int dc_conv3x3_fwd_bnin_f16x3(const float* z_in, const float* in_sc, const float* in_sh, const float* in_abound,
-    const void* wp16, const float* bias, float* z, long z_ld, double* stats, const float* scale,
+    const void* wp16, const float* bias, float* z, long z_ld, double* stats, int stats_rows, const float* scale,
                                          const float* shift, int relu, float* splitk_ws, int N, int H, int W, int Cin,
                                          int Cout, dc_stream_t stream) {
   int rc = check_h("dc_conv3x3_fwd_bnin_f16x3", z_in, wp16, z, N, H, W, Cin, Cout);
@@ -882,6 +912,7 @@ extern "C" int dc_conv3x3_fwd_bnin_f16x3(const float* z_in, const float* in_sc, 
   p.scale = scale; p.shift = shift; p.inSc = in_sc; p.inSh = in_sh; p.inAbound = in_abound;
   p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Hout = H; p.Wout = W; p.Ncols = Cout;
   p.relu = relu; p.scatterCo = 0; p.biasMod = Cout; p.outLd = z_ld; p.splitWs = splitk_ws;
+  if ((rc = stats_mode("dc_conv3x3_fwd_bnin_f16x3", stats, stats_rows, N, H, W, Cin, Cout, &p.statsPerWg))) return rc;
   return conv3x3_h_launch(p, (hipStream_t)stream);
 }
 

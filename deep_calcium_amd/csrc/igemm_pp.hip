@@ -103,7 +103,7 @@ struct Item {          // one output tile x column block (wave-uniform)
 // DZIN: the data-gradient launch whose input operand dz is formed on load from (da, z) -- see IgemmParams::in2.
 template <int MB_, int NB_, int VARIANT = 0, bool DZIN = false>
 __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p) {
-  constexpr bool BNRED = VARIANT == 1, POOL = VARIANT == 2;
+  constexpr bool BNRED = VARIANT == 1, POOL = VARIANT == 2, PERWG = VARIANT == 3;
   using namespace pp;
   using C = Cfg<MB_, NB_>;
   constexpr int MB = C::MB, NB = C::NB, RPM = C::RPM, TH = C::TH, BN = C::BN, THI = C::THI, TWI = C::TWI, NPIXH = C::NPIXH;
@@ -115,6 +115,11 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
   float* lds_sc = reinterpret_cast<float*>(smem + FIXED_LDS);                 // BN-on-load (scale, shift) per input channel
   float* lds_ep = reinterpret_cast<float*>(smem + FIXED_LDS + TABLE_BYTES);   // epilogue bias | scale | shift per column
   float* lds_dz = lds_ep + 3 * EP_COLS;                                       // DZIN: sc | sh | mu | A | D | E per input channel
+  // statsPerWg (forward launches with BatchNorm partials; never DZIN: the same LDS): running moments of this workgroup's tiles,
+  // [consumer set][column] -- column n is only ever touched by thread n % BN of its set
+  // Its own instantiation (VARIANT 3), like the other epilogue variants: the base kernel stays the verified code (DESIGN 5c:
+  // one more epilogue path compiled INTO it once pushed hipcc over an SGPR-spill cliff; tests/test_abi.py).
+#define PP_RUN_M (reinterpret_cast<DcMoments*>(smem + FIXED_LDS + TABLE_BYTES + 3 * EP_COLS * 4))
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..11
@@ -155,6 +160,8 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
     for (int i = tid; i < p.Cin; i += THREADS) { lds_sc[i] = p.inSc[i]; lds_sc[Cinp + i] = p.inSh[i]; }
   // per-column epilogue parameters live in LDS for the whole launch: a global load inside an epilogue slice would make the
   // slice wait (vmcnt counts stores too) for the previous slice's stores to drain
+  if constexpr (PERWG)
+    for (int i = tid; i < 2 * EP_COLS; i += THREADS) PP_RUN_M[i] = DcMoments{0.f, 0.f, 0.f};
   for (int i = tid; i < p.Ncols; i += THREADS) {
     lds_ep[i] = p.bias ? p.bias[i] : 0.f;
     lds_ep[EP_COLS + i] = p.scale ? p.scale[i] : 1.f;
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
   // (mode 2), stores.  Slices run in the order (nb 0: mb 0, 1), (nb 1: mb 0, 1); the per-column shifted sums of a column
   // block live in four registers across its two slices and go to LDS after the second; the cross-wave merge of the tile's
   // partials happens one step later (merge_pending), whatever that step is for this set.
-  const int mode = BNRED ? 4 : (p.outAbsmax ? 2 : ((p.stats && !POOL) ? 1 : 0));          // wave-uniform
+  const int mode = BNRED ? 4 : (PERWG ? 1 : (p.outAbsmax ? 2 : ((p.stats && !POOL) ? 1 : 0)));          // wave-uniform
   float e_s1 = 0.f, e_s2 = 0.f, e_cnt = 0.f, e_K = 0.f;
   auto epi_values = [&](auto nb_tag, auto mb_tag, auto interior_tag, auto mode_tag) __attribute__((always_inline)) {
     constexpr int nb = decltype(nb_tag)::value;
@@ -570,7 +577,10 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
 #pragma unroll
         for (int wm = 1; wm < WAVES_M; ++wm) m = dc_moments_merge(m, red[(wm * NB + nb) * 32 + l]);
         const int n = mitem.n0 + nb * 32 + l;
-        if (n < p.Ncols) dc_moments_store(p.stats + ((long)mitem.tile_id * p.Ncols + n) * 2, m);
+        if (n < p.Ncols) {
+          if constexpr (PERWG) PP_RUN_M[role * EP_COLS + n] = dc_moments_merge(PP_RUN_M[role * EP_COLS + n], m);   // tile order: deterministic
+          else dc_moments_store(p.stats + ((long)mitem.tile_id * p.Ncols + n) * 2, m);
+        }
       }
     } else if (BNRED) {
       const int ts = tid & 255;
@@ -599,6 +609,9 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
     auto run = [&](auto nb_tag, auto mb_tag) __attribute__((always_inline)) {
       if constexpr (BNRED) {
         if (interior) epi_values(nb_tag, mb_tag, std::true_type{}, T4{});
+        else epi_values(nb_tag, mb_tag, std::false_type{}, T3{});
+      } else if constexpr (PERWG) {
+        if (interior) epi_values(nb_tag, mb_tag, std::true_type{}, T1{});
         else epi_values(nb_tag, mb_tag, std::false_type{}, T3{});
       } else if (interior) {
         if (mode == 0) epi_values(nb_tag, mb_tag, std::true_type{}, T0{});
@@ -664,6 +677,11 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
     __syncthreads();
     PP_TRACE();
   }
+  if constexpr (PERWG)
+    if (role < 2)
+      for (int n = tid & 255; n < p.Ncols; n += 256)
+        dc_moments_store(p.stats + ((long)(2 * blockIdx.x + role) * p.Ncols + n) * 2, PP_RUN_M[role * EP_COLS + n]);
+#undef PP_RUN_M
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -689,11 +707,15 @@ template <int MB_, int NB_, int VARIANT, bool DZIN = false>
 static int pp_launch(IgemmParams p, hipStream_t st, const char* name) {
   using C = pp::Cfg<MB_, NB_>;
   static_assert(C::RPM == 1, "the pooled epilogue pairs block rows mb - 1, mb");
+  static_assert(!(DZIN && VARIANT == 3), "the per-workgroup running moments use the dz-on-load table's LDS");
   auto kern = igemm_pp_kernel<MB_, NB_, VARIANT, DZIN>;
   static DcLdsAttr lds_attr;
-  const int lds = C::FIXED_LDS + pp::TABLE_BYTES + 3 * pp::EP_COLS * 4 + (DZIN ? pp::DZ_BYTES : 0);
+  static_assert(2 * pp::EP_COLS * (int)sizeof(DcMoments) <= pp::DZ_BYTES, "the per-workgroup running moments live in the dz-on-load table's LDS");
+  const int lds = C::FIXED_LDS + pp::TABLE_BYTES + 3 * pp::EP_COLS * 4 + ((DZIN || VARIANT == 3) ? pp::DZ_BYTES : 0);
   static_assert(C::FIXED_LDS + pp::TABLE_BYTES + 3 * pp::EP_COLS * 4 + pp::DZ_BYTES <= 160 * 1024, "LDS budget");
-  if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), lds, name)) return rc;
+  // (the attribute is set once per device: with the most this instantiation ever asks for)
+  constexpr int lds_max = C::FIXED_LDS + pp::TABLE_BYTES + 3 * pp::EP_COLS * 4 + pp::DZ_BYTES;
+  if (int rc = dc_func_max_lds(lds_attr, reinterpret_cast<const void*>(kern), lds_max, name)) return rc;
   p.tilesX = dc_cdiv(p.Wout, pp::TW);
   p.tilesY = dc_cdiv(p.Hout, C::TH);
   p.walk = dc_tile_walk();
@@ -714,6 +736,17 @@ static int pp_launch(IgemmParams p, hipStream_t st, const char* name) {
   return DC_OK;
 }
 
+// Rows of the per-workgroup BatchNorm partials (IgemmParams::statsPerWg) = 2 x the grid pp_launch() would use; 0 when the
+// device's CU count cannot be read (no GPU).
+int dc_igemm_pp_stats_rows(const IgemmParams& p) {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
+  const int th = p.Ncols <= 32 ? pp::Cfg<4, 1>::TH : pp::Cfg<2, 2>::TH, bn = p.Ncols <= 32 ? 32 : 64;
+  const long total = (long)p.N * dc_cdiv(p.Wout, pp::TW) * dc_cdiv(p.Hout, th) * dc_cdiv(p.Ncols, bn);
+  return 2 * (int)(total < n ? total : n);
+}
+
 // same tile-shape choice as igemm_f16x3.hip's conv3x3 dispatch (and therefore the same BatchNorm-partial tile count)
 int dc_igemm_pp_launch(IgemmParams p, hipStream_t st, const char* name) {
   if (p.dzCoef) {
@@ -723,5 +756,6 @@ int dc_igemm_pp_launch(IgemmParams p, hipStream_t st, const char* name) {
   }
   if (p.bnPartial) return p.Ncols <= 32 ? pp_launch<4, 1, 1>(p, st, name) : pp_launch<2, 2, 1>(p, st, name);
   if (p.poolOut) return p.Ncols <= 32 ? pp_launch<4, 1, 2>(p, st, name) : pp_launch<2, 2, 2>(p, st, name);
+  if (p.statsPerWg && p.stats) return p.Ncols <= 32 ? pp_launch<4, 1, 3>(p, st, name) : pp_launch<2, 2, 3>(p, st, name);
   return p.Ncols <= 32 ? pp_launch<4, 1, 0>(p, st, name) : pp_launch<2, 2, 0>(p, st, name);
 }

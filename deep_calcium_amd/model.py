@@ -370,7 +370,7 @@ class Model(object):
         eng = self.engine
         eng.forward_train(xd, yd, masks)
         world = parallel.world_size()
-        sync = world > 1 and eng.bn_mode == 'sync'
+        sync = eng._sync_bn()
         # The loss / metric sums are complete once the forward's head kernel has run: their (all-reduced) copy goes to
         # pinned host memory right away and the host only waits for THAT copy -- backward and Adam of this step are still
         # executing when the call returns, so the next step's launches queue up behind them with no idle gap.

@@ -271,6 +271,7 @@ class UNetEngine(object):
         self._bufs = {}
         # launch tapes (csrc/tape.cpp): the enqueue sequence of each phase of a steady-state train step, recorded once (and
         # verified against a second recording) per key, then replayed from C.  DC_TAPES=0: every launch from Python.
+        self.stats_per_wg = True          # BatchNorm partials: one row per (workgroup, consumer set) of the role-split kernel (A/B: False)
         self.use_tapes = os.environ.get('DC_TAPES', '1') != '0'
         self._tapes = {}
         self.tape_replays = 0
@@ -421,6 +422,23 @@ class UNetEngine(object):
         """work queued on dst from here on runs after everything queued on src so far"""
         self._wait(dst_h, self._record(src_h))
 
+    def _sync_bn(self):
+        """'sync' BatchNorm is live when there is more than one rank -- or under DC_DIST_FORCE=1 (a one-rank process group: the
+        44 per-layer all-reduces then run over RCCL inside the real step, which is how their cost is priced on one GPU)."""
+        return self.bn_mode == 'sync' and (parallel.world_size() > 1 or parallel.exchange_active())
+
+    def _sync_all_reduce(self, t):
+        """One of the per-layer 'sync' BatchNorm messages (<= 8 KB); bench.py brackets them with events (sync_events)."""
+        rec = getattr(self, 'sync_events', None)
+        if rec is None:
+            return parallel.all_reduce_sum(t)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        parallel.all_reduce_sum(t)
+        e1.record()
+        rec.append((e0, e1))
+        return t
+
     def _v(self, key, value):
         """A per-step launch argument: wrapped for the tape while one is being recorded."""
         return Var(key, value) if self.L.recording() else value
@@ -512,7 +530,7 @@ class UNetEngine(object):
             return self._ab_in(l, True) + self._ab_out(l, True)
         return None, 0, self._ovf.data_ptr(), -1
 
-    def _conv_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None, measured=False, splitk=None):
+    def _conv_fwd(self, x, l, bias, z, z_ld, stats, sc, sh, relu, N, h, w, st, bnin=None, measured=False, splitk=None, stats_rows=0):
         """bnin = (scale_ptr, shift_ptr): x is the producer's pre-BN tensor, BN + ReLU are applied on load.
         measured: inference -- the input bound is a measured one (8 replicas) and the epilogue folds max |output| per
         channel into the output's replicas (the next layer's range-guard bound)."""
@@ -522,9 +540,9 @@ class UNetEngine(object):
             ab_in, ab_in_ld, ab_out, ab_out_ld = self._ab_in(l), 0, None, 0
         if bnin is not None:
             self.L.dc_conv3x3_fwd_bnin_f16x3(x, bnin[0], bnin[1], self._ab_in(l), _ptr(self.wp_fwd[l.name]), bias, z, z_ld,
-                                             stats, sc, sh, relu, splitk, N, h, w, l.cin, l.cout, st)
+                                             stats, stats_rows, sc, sh, relu, splitk, N, h, w, l.cin, l.cout, st)
         elif self.mfma == 'f16x3':
-            self.L.dc_conv3x3_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu, ab_in, ab_in_ld,
+            self.L.dc_conv3x3_fwd_f16x3(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, stats_rows, sc, sh, relu, ab_in, ab_in_ld,
                                         ab_out, ab_out_ld, splitk, N, h, w, l.cin, l.cout, st)
         else:
             self.L.dc_conv3x3_fwd(x, _ptr(self.wp_fwd[l.name]), bias, z, z_ld, stats, sc, sh, relu,
@@ -968,7 +986,7 @@ class UNetEngine(object):
         step_seed = self.drop_seed + self.iterations
         self._last = (N, masks, step_seed, x_dev, y_dev)
         world = parallel.world_size()
-        sync = self.bn_mode == 'sync' and world > 1
+        sync = self._sync_bn()
 
         def body():
             return self._forward_train_body(x_dev, y_dev, masks, update_moving)
@@ -997,7 +1015,7 @@ class UNetEngine(object):
         A, T = self._acts(N), self._train_bufs(N)
         step_seed = self._last[2]
         world = parallel.world_size()
-        sync = self.bn_mode == 'sync' and world > 1
+        sync = self._sync_bn()
         xp, yp = self._v('x', _ptr(x_dev)), self._v('y', y_dev.data_ptr())
         plan = self._plan(A)
         pooled_with_block = False
@@ -1028,8 +1046,12 @@ class UNetEngine(object):
                 L.dc_conv3x3_c1_fwd(xp, self.pview(self.pflat, l, 'k'), bias, _ptr(z), l.cout, stats,
                                     None, None, 0, None, 0, N, h, w, l.cout, st)
             elif l.kind == 'conv':
-                tiles = L.dc_conv3x3_tiles(N, h, w, l.cout)
-                self._conv_fwd(xin, l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h, w, st, bnin=bn, splitk=_ptr(T['splitk_ws']))
+                # BatchNorm-partial rows: one per (workgroup, consumer set) where the role-split kernel serves the launch (<= 512
+                # rows for the finalize launch instead of up to 8 192 tiles), one per pixel tile elsewhere
+                tiles = (L.dc_conv3x3_stats_rows(N, h, w, l.cin, l.cout) if self.mfma == 'f16x3' and self.stats_per_wg
+                         else L.dc_conv3x3_tiles(N, h, w, l.cout))
+                self._conv_fwd(xin, l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h, w, st, bnin=bn, splitk=_ptr(T['splitk_ws']),
+                               stats_rows=tiles)
             else:
                 tiles = (L.dc_convT2x2_f16x3_tiles if self.mfma == 'f16x3' else L.dc_convT2x2_tiles)(N, h // 2, w // 2, l.cout)
                 groups = 4
@@ -1040,7 +1062,7 @@ class UNetEngine(object):
                 # 'sync' BatchNorm: per-channel (sum, sum of squares) -> all-reduce over the ranks -> statistics
                 bs = T['bn_sums'][:2 * l.cout]
                 L.dc_bn_stats_reduce(stats, tiles, groups, l.cout, bs.data_ptr(), st)
-                parallel.all_reduce_sum(bs)
+                self._sync_all_reduce(bs)
                 nm_l = l.name in self.nm
                 L.dc_bn_stats_finalize_sums(bs.data_ptr(), l.cout, float(world * pixels), BN_EPS, mom,
                                             self.stat_ptr(l, 0), self.stat_ptr(l, 1), self.sview(l, 'mmean'),
@@ -1147,7 +1169,7 @@ class UNetEngine(object):
             self._side_stream = torch.cuda.Stream(device=self.device)
         side = self._side_stream if self.streams == 2 else torch.cuda.current_stream(self.device)
         world = parallel.world_size()
-        sync = self.bn_mode == 'sync' and world > 1
+        sync = self._sync_bn()
 
         def body():
             return self._backward_body(bucket_cb, defer_tail)
@@ -1207,7 +1229,7 @@ class UNetEngine(object):
         g_free = [None] * S               # event of the weight gradient that last read g[k] as `da` (dz on load)
         state = {'slot': 0, 'g': 0}       # next block slot; index of the buffer holding the current activation gradient
         world = parallel.world_size()
-        sync = self.bn_mode == 'sync' and world > 1
+        sync = self._sync_bn()
 
         def g_cur():
             return gb[state['g']]
@@ -1259,7 +1281,7 @@ class UNetEngine(object):
                 g0, _ = l.off['gamma']
                 gg = T['bn_gsum'][:2 * l.cout]
                 gg.copy_(self.gflat[g0:g0 + 2 * l.cout])
-                parallel.all_reduce_sum(gg)
+                self._sync_all_reduce(gg)
 
             if dzin:
                 # ---- dz on load: table -> data gradient (main) -> weight gradient (side); no dz tensor ------------------

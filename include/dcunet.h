@@ -36,7 +36,7 @@ typedef void* dc_stream_t;
 
 /* ABI revision: dc_version() of the loaded library must EQUAL the DC_ABI_VERSION of the header the caller was built /
  * bound against (argument lists change between revisions; the Python binding refuses a mismatch). */
-#define DC_ABI_VERSION 103
+#define DC_ABI_VERSION 104
 int dc_version(void);
 const char* dc_last_error(void);
 
@@ -112,7 +112,14 @@ int dc_pack_weights_f16x3_batch(const long* jobs_dev, int njobs, int total_block
  * data gradient (dgrad != 0). */
 long dc_conv3x3_splitk_ws_floats(int N, int H, int W, int Cin, int Cout, int dgrad);
 long dc_convT2x2_dgrad_splitk_ws_floats(int N, int H, int W, int Cin, int Cout);
-int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, double* stats,
+/* BatchNorm-partial rows of a split-fp16 conv3x3 forward.  stats_rows == 0 (or dc_conv3x3_tiles()): one row per pixel tile,
+ * double[dc_conv3x3_tiles()][Cout][2].  stats_rows == dc_conv3x3_stats_rows(): where the persistent role-split kernel serves the
+ * launch, every (workgroup, consumer set) Chan-merges the tiles it computes and writes ONE row -- at most 2 x #CUs rows instead
+ * of up to 8 192, so the finalize launch that follows reads KBs instead of MBs (86 -> < 10 us at 512^2 x 16); the per-channel
+ * statistics they finalize to are the same up to fp32 rounding of the merges.  For launches the role-split kernel does not
+ * serve the query returns dc_conv3x3_tiles().  Needs the current device's CU count: call it on the GPU box. */
+int dc_conv3x3_stats_rows(int N, int H, int W, int Cin, int Cout);
+int dc_conv3x3_fwd_f16x3(const float* x, const void* wp16, const float* bias, float* z, long z_ld, double* stats, int stats_rows,
                          const float* scale, const float* shift, int relu, const float* in_abound, long in_abound_ld,
                          float* out_absmax, long out_absmax_ld, float* splitk_ws, int N, int H, int W, int Cin, int Cout,
                          dc_stream_t stream);
@@ -155,7 +162,7 @@ int dc_bn_stats_finalize_affine(const double* partial, int parts, int groups, in
                                 const float* gamma, const float* beta, float* scale, float* shift, float* abound,
                                 dc_stream_t stream);
 int dc_conv3x3_fwd_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const float* in_abound,
-                              const void* wp16, const float* bias, float* z, long z_ld, double* stats, const float* scale,
+                              const void* wp16, const float* bias, float* z, long z_ld, double* stats, int stats_rows, const float* scale,
                               const float* shift, int relu, float* splitk_ws, int N, int H, int W, int Cin, int Cout,
                               dc_stream_t stream);
 int dc_convT2x2_fwd_bnin_f16x3(const float* z_in, const float* in_scale, const float* in_shift, const float* in_abound,

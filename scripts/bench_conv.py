@@ -24,7 +24,7 @@ for HW, Ci, Co in shapes:
     L.dc_pack_weights_f16x3(Kd.data_ptr(), wp16.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
     z32 = torch.empty(N, HW, HW, Co, device='cuda'); z16 = torch.empty_like(z32)
     f32 = lambda: L.dc_conv3x3_fwd(x.data_ptr(), wp.data_ptr(), None, z32.data_ptr(), Co, None, None, None, 0, N, HW, HW, Ci, Co, None)
-    f16 = lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp16.data_ptr(), None, z16.data_ptr(), Co, None, None, None, 0, None, 0, None, 0, None, N, HW, HW, Ci, Co, None)
+    f16 = lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp16.data_ptr(), None, z16.data_ptr(), Co, None, 0, None, None, 0, None, 0, None, 0, None, N, HW, HW, Ci, Co, None)
     t32, t16 = timeit(f32), timeit(f16)
     fl = 2.0 * 9 * Ci * Co * N * HW * HW
     # accuracy on image 0 vs float64

@@ -23,7 +23,7 @@ zc = torch.empty(N, HW, HW, Co, device='cuda')
 fw = lambda: L.dc_conv3x3_wgrad_f16x3(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), None, None, N, HW, HW, Ci, Co, s1.cuda_stream)
 fb = lambda: L.dc_bn_bwd_apply(da.data_ptr(), C, z.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(),
                                None, 1.0, 0, v[4].data_ptr(), v[5].data_ptr(), dzo.data_ptr(), p2.data_ptr(), am.data_ptr(), pixels, C, s2.cuda_stream)
-fc = lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp16.data_ptr(), None, zc.data_ptr(), Co, None, None, None, 0, None, 0, None, 0, None, N, HW, HW, Ci, Co, s1.cuda_stream)
+fc = lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp16.data_ptr(), None, zc.data_ptr(), Co, None, 0, None, None, 0, None, 0, None, 0, None, N, HW, HW, Ci, Co, s1.cuda_stream)
 out = torch.zeros(2, dtype=torch.int64, device='cuda')
 for name, fns in [('idle', []), ('wgrad', [fw]), ('bn_apply', [fb]), ('wgrad + bn_apply', [fw, fb]), ('conv fwd (pp)', [fc]), ('conv fwd + bn_apply', [fc, fb])]:
     for rep in range(2):

@@ -36,7 +36,7 @@ def worker(lib_path, HW, Ci, Co, mask=0):
     trace = torch.zeros(8 * 3 * 512, dtype=torch.int64, device='cuda')
     fn = L.cdll.dc_debug_set_pp_trace
     fn.argtypes = [ctypes.c_void_p]
-    run = lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp16.data_ptr(), None, z.data_ptr(), Co, stats.data_ptr(), None, None, 0,
+    run = lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp16.data_ptr(), None, z.data_ptr(), Co, stats.data_ptr(), 0, None, None, 0,
                                          None, 0, None, 0, None, N, HW, HW, Ci, Co, None)
     fn(None)
     for _ in range(3): run()

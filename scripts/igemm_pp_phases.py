@@ -37,7 +37,7 @@ fn.argtypes = [ctypes.c_void_p]
 
 
 def run():
-    L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp16.data_ptr(), None, z.data_ptr(), Co, stats.data_ptr(), None, None, 0, None, 0,
+    L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp16.data_ptr(), None, z.data_ptr(), Co, stats.data_ptr(), 0, None, None, 0, None, 0,
                            None, 0, None, N, HW, HW, Ci, Co, None)
 
 

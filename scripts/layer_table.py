@@ -29,7 +29,7 @@ for HW, Ci, Co in shapes:
     z = torch.empty(N, HW, HW, Co, device='cuda'); dx = torch.empty(N, HW, HW, Ci, device='cuda')
     stats = torch.zeros(L.dc_conv3x3_tiles(N, HW, HW, Co) * 2 * Co + 1024, device='cuda', dtype=torch.float64)
     dw = torch.empty(9 * Ci * Co, device='cuda'); ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, HW, HW, Ci, Co), device='cuda')
-    f = lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wf.data_ptr(), None, z.data_ptr(), Co, stats.data_ptr() if stats is not None else None, None, None, 0, None, 0, None, 0, None, N, HW, HW, Ci, Co, None)
+    f = lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wf.data_ptr(), None, z.data_ptr(), Co, stats.data_ptr() if stats is not None else None, 0, None, None, 0, None, 0, None, 0, None, N, HW, HW, Ci, Co, None)
     d = lambda: L.dc_conv3x3_dgrad_f16x3(dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), one.data_ptr(), None, 0, None, N, HW, HW, Ci, Co, None)
     w = lambda: L.dc_conv3x3_wgrad_f16x3(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), one.data_ptr(), None, N, HW, HW, Ci, Co, None)
     tf, td, tw = timeit(f), timeit(d), timeit(w)

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512, 1) void wino_fwd(const float* __restrict__ x, 
 
 typedef int (*pack_fn)(const float*, void*, int, int, int, long, long, long, int, void*);
 typedef long (*floats_fn)(int, int, int);
-typedef int (*conv_fn)(const float*, const void*, const float*, float*, long, double*, const float*, const float*, int, const float*, long,
+typedef int (*conv_fn)(const float*, const void*, const float*, float*, long, double*, int, const float*, const float*, int, const float*, long,
                        float*, long, float*, int, int, int, int, int, void*);
 
 int main(int argc, char** argv) {
@@ -259,12 +259,12 @@ int main(int argc, char** argv) {
     if (dc_conv) {
       void* wp; CK(hipMalloc(&wp, dc_floats(9, C, K) * 4));
       dc_pack(dw, wp, 9, C, K, (long)C * K, K, 1, 0, nullptr);
-      dc_conv(dx, wp, nullptr, dyb, K, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, N, H, W, C, K, nullptr);
+      dc_conv(dx, wp, nullptr, dyb, K, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, N, H, W, C, K, nullptr);
       CK(hipDeviceSynchronize());
       bbest = 1e9f;
       for (int r = 0; r < reps; ++r) {
         CK(hipEventRecord(e0, 0));
-        dc_conv(dx, wp, nullptr, dyb, K, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, N, H, W, C, K, nullptr);
+        dc_conv(dx, wp, nullptr, dyb, K, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, N, H, W, C, K, nullptr);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); bbest = fminf(bbest, ms); bsum += ms;
       }

@@ -10,5 +10,5 @@ wp16 = torch.empty(L.dc_pack_weights_f16x3_floats(9, Ci, Co), device='cuda')
 L.dc_pack_weights_f16x3(K.data_ptr(), wp16.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
 z = torch.empty(N, HW, HW, Co, device='cuda')
 for _ in range(iters):
-    L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp16.data_ptr(), None, z.data_ptr(), Co, None, None, None, 0, None, 0, None, 0, None, N, HW, HW, Ci, Co, None)
+    L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp16.data_ptr(), None, z.data_ptr(), Co, None, 0, None, None, 0, None, 0, None, 0, None, N, HW, HW, Ci, Co, None)
 torch.cuda.synchronize()

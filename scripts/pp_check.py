@@ -38,9 +38,9 @@ def worker(out):
         dx = torch.full((N, H, W, Ci), float('nan'), device='cuda')
         dzs = torch.ones(1, device='cuda') * 4.0
         runs = {
-            'fwd_stats': lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, stats.data_ptr(), None, None, 0, None, 0, None, 0, None, N, H, W, Ci, Co, None),
-            'fwd_bnin': lambda: L.dc_conv3x3_fwd_bnin_f16x3(x.data_ptr(), sc.data_ptr(), sh.data_ptr(), ab.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, stats.data_ptr(), None, None, 0, None, N, H, W, Ci, Co, None),
-            'infer': lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), None, z.data_ptr(), Co, None, sc[:1].expand(Co).contiguous().data_ptr() if False else b.data_ptr(), b.data_ptr(), 1, None, 0, flag.data_ptr(), -1, None, N, H, W, Ci, Co, None),
+            'fwd_stats': lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, stats.data_ptr(), 0, None, None, 0, None, 0, None, 0, None, N, H, W, Ci, Co, None),
+            'fwd_bnin': lambda: L.dc_conv3x3_fwd_bnin_f16x3(x.data_ptr(), sc.data_ptr(), sh.data_ptr(), ab.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, stats.data_ptr(), 0, None, None, 0, None, N, H, W, Ci, Co, None),
+            'infer': lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), None, z.data_ptr(), Co, None, 0, sc[:1].expand(Co).contiguous().data_ptr() if False else b.data_ptr(), b.data_ptr(), 1, None, 0, flag.data_ptr(), -1, None, N, H, W, Ci, Co, None),
             'dgrad': lambda: L.dc_conv3x3_dgrad_f16x3(z.data_ptr(), wpd.data_ptr(), dx.data_ptr(), dzs.data_ptr(), None, 0, None, N, H, W, Ci, Co, None),
         }
         for name, fn in runs.items():

@@ -187,7 +187,7 @@ def test_role_split_kernel_moments_per_tile_at_batch_16(HW, Ci, Co):
     outs = []
     for _ in range(3):
         stats = torch.full((tiles * Co * 2,), float('nan'), dtype=torch.float64, device='cuda')
-        L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, stats.data_ptr(), None, None, 0, None, 0,
+        L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, stats.data_ptr(), 0, None, None, 0, None, 0,
                                None, 0, None, Nb, HW, HW, Ci, Co, None)
         torch.cuda.synchronize()
         outs.append(stats.cpu().numpy().reshape(tiles, Co, 2))
@@ -266,7 +266,7 @@ def test_inference_conv_with_pooled_output_at_batch_8(HW, Ci, Co):
     z0 = torch.empty(Nb, HW, HW, Co, device='cuda')
     p0 = torch.empty(Nb, HW // 2, HW // 2, Co, device='cuda')
     flag = torch.zeros(4, device='cuda')
-    L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), None, z0.data_ptr(), Co, None, sc.data_ptr(), sh.data_ptr(), 1, None, 0,
+    L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), None, z0.data_ptr(), Co, None, 0, sc.data_ptr(), sh.data_ptr(), 1, None, 0,
                            flag.data_ptr(), -1, None, Nb, HW, HW, Ci, Co, None)
     L.dc_maxpool2x2_fwd(z0.data_ptr(), Co, p0.data_ptr(), None, Nb, HW, HW, Co, None)
     for _ in range(3):

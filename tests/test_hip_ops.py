@@ -142,7 +142,7 @@ def test_conv3x3_f16x3_fwd_dgrad(dclib, N, H, W, Ci, Co):
     if W > 16:
         assert skf == 0 and skd == 0
     skws = torch.full((max(skf, skd, 4),), float('nan'), device='cuda')
-    L.dc_conv3x3_fwd_f16x3(dev(x).data_ptr(), wp.data_ptr(), dev(b).data_ptr(), z.data_ptr(), Co, stats.data_ptr(),
+    L.dc_conv3x3_fwd_f16x3(dev(x).data_ptr(), wp.data_ptr(), dev(b).data_ptr(), z.data_ptr(), Co, stats.data_ptr(), 0,
                            None, None, 0, None, 0, None, 0, skws.data_ptr(), N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert rel_err(z.cpu().numpy(), z_ref) < 2e-5
@@ -152,7 +152,7 @@ def test_conv3x3_f16x3_fwd_dgrad(dclib, N, H, W, Ci, Co):
     if skf > 0:      # no workspace: ONE un-split launch -- same values up to the summation order, same statistics rows
         z1 = torch.full((N, H, W, Co), float('nan'), device='cuda')
         stats1 = torch.zeros(tiles * Co * 2, device='cuda', dtype=torch.float64)
-        L.dc_conv3x3_fwd_f16x3(dev(x).data_ptr(), wp.data_ptr(), dev(b).data_ptr(), z1.data_ptr(), Co, stats1.data_ptr(),
+        L.dc_conv3x3_fwd_f16x3(dev(x).data_ptr(), wp.data_ptr(), dev(b).data_ptr(), z1.data_ptr(), Co, stats1.data_ptr(), 0,
                                None, None, 0, None, 0, None, 0, None, N, H, W, Ci, Co, None)
         torch.cuda.synchronize()
         assert rel_err(z1.cpu().numpy(), z_ref) < 2e-5 and not torch.equal(z, z1)
@@ -226,10 +226,10 @@ def test_bn_relu_on_load_conv_convT_wgrad_head(dclib, N, H, W, Ci, Co):
     wp = torch.empty(L.dc_pack_weights_f16x3_floats(9, Ci, Co), device='cuda')
     L.dc_pack_weights_f16x3(Kd.data_ptr(), wp.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
     z1 = torch.full((N, H, W, Co), float('nan'), device='cuda'); z2 = torch.full_like(z1, float('nan'))
-    L.dc_conv3x3_fwd_f16x3(a.data_ptr(), wp.data_ptr(), None, z1.data_ptr(), Co, None, None, None, 0, ab.data_ptr(), 0, None, 0, None,
+    L.dc_conv3x3_fwd_f16x3(a.data_ptr(), wp.data_ptr(), None, z1.data_ptr(), Co, None, 0, None, None, 0, ab.data_ptr(), 0, None, 0, None,
                            N, H, W, Ci, Co, None)
     L.dc_conv3x3_fwd_bnin_f16x3(dev(zin).data_ptr(), sc.data_ptr(), sh.data_ptr(), ab.data_ptr(), wp.data_ptr(), None,
-                                z2.data_ptr(), Co, None, None, None, 0, None, N, H, W, Ci, Co, None)
+                                z2.data_ptr(), Co, None, 0, None, None, 0, None, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert torch.equal(z1, z2)                       # same operand bits -> same result bits
     z_ref = on.conv3x3_fwd(a_ref, K.astype(np.float64), np.zeros(Co))
@@ -654,7 +654,7 @@ def test_inference_conv_with_pooled_output_equals_conv_then_pool(dclib, N, H, W,
             L.dc_conv3x3_fwd_pool_f16x3(x.data_ptr(), wp.data_ptr(), None, cat.data_ptr() + 4 * Cout, ld, sc.data_ptr(), sh.data_ptr(), 1,
                                         flag.data_ptr(), pool.data_ptr(), N, H, W, Cin, Cout, None)
         else:
-            L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), None, cat.data_ptr() + 4 * Cout, ld, None, sc.data_ptr(), sh.data_ptr(), 1,
+            L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), None, cat.data_ptr() + 4 * Cout, ld, None, 0, sc.data_ptr(), sh.data_ptr(), 1,
                                    None, 0, flag.data_ptr(), -1, None, N, H, W, Cin, Cout, None)
             L.dc_maxpool2x2_fwd(cat.data_ptr() + 4 * Cout, ld, pool.data_ptr(), None, N, H, W, Cout, None)
         torch.cuda.synchronize()
@@ -939,6 +939,57 @@ def test_reduce_partials_deterministic(dclib):
         assert np.allclose(out1.cpu().numpy(), 0.5 * x.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('N,H,W,Ci,Co,bias_sigmas', [(2, 64, 64, 64, 64, 0), (3, 40, 72, 128, 96, 0), (16, 128, 128, 64, 64, 1000),
+                                                     (1, 32, 32, 64, 32, 0), (16, 256, 256, 64, 64, 0), (4, 64, 96, 256, 512, 3)])
+def test_conv3x3_bn_partials_per_workgroup(dclib, N, H, W, Ci, Co, bias_sigmas):
+    """dc_conv3x3_stats_rows(): where the persistent role-split kernel serves the forward launch every (workgroup, consumer set)
+    Chan-merges its tiles and writes ONE row of BatchNorm partials.  Same z bit for bit, at most 2 x #CUs rows, the statistics
+    they finalize to equal the per-tile rows' (and the float64 oracle's) -- also at |mean| = 1000 sigma --, bit-reproducible."""
+    L = dclib
+    rs = np.random.RandomState(N + H + Co)
+    x = rs.standard_normal((N, H, W, Ci)).astype(np.float32)
+    K = (rs.standard_normal((3, 3, Ci, Co)) * np.sqrt(2.0 / (9 * Ci))).astype(np.float32)
+    b = (rs.standard_normal(Co) + bias_sigmas * np.sqrt(2.0)).astype(np.float32)
+    xd, bd = dev(x), dev(b)
+    wp = torch.empty(L.dc_pack_weights_f16x3_floats(9, Ci, Co), device='cuda')
+    L.dc_pack_weights_f16x3(dev(K).data_ptr(), wp.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
+    tiles, rows = L.dc_conv3x3_tiles(N, H, W, Co), L.dc_conv3x3_stats_rows(N, H, W, Ci, Co)
+    assert 0 < rows <= tiles
+    if L.dc_conv3x3_pp_blocks(N, H, W, Ci, Co, 0, 1) > 0:
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        assert rows == 2 * min(cus, L.dc_conv3x3_pp_blocks(N, H, W, Ci, Co, 0, 1) * ((Co + 63) // 64 if Co > 32 else 1)) or rows == tiles
+    else:
+        assert rows == tiles
+
+    def run(stats_rows):
+        z = torch.full((N, H, W, Co), float('nan'), device='cuda')
+        st = torch.full((max(stats_rows, tiles) * Co * 2,), float('nan'), device='cuda', dtype=torch.float64)
+        L.dc_conv3x3_fwd_f16x3(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), z.data_ptr(), Co, st.data_ptr(), stats_rows, None, None, 0,
+                               None, 0, None, 0, None, N, H, W, Ci, Co, None)
+        n = stats_rows if stats_rows else tiles
+        mean, invstd = torch.empty(Co, device='cuda'), torch.empty(Co, device='cuda')
+        mm, mv = torch.zeros(Co, device='cuda'), torch.ones(Co, device='cuda')
+        L.dc_bn_stats_finalize(st.data_ptr(), n, 1, Co, float(N * H * W), 1e-3, 0.99, mean.data_ptr(), invstd.data_ptr(), mm.data_ptr(),
+                               mv.data_ptr(), None)
+        torch.cuda.synchronize()
+        assert torch.isfinite(st[:n * Co * 2]).all()
+        return z, st[:n * Co * 2].clone(), mean.cpu().numpy().astype(np.float64), invstd.cpu().numpy().astype(np.float64)
+
+    z0, _, mean0, is0 = run(0)
+    z1, st1, mean1, is1 = run(rows)
+    z2, st2, _, _ = run(rows)
+    assert torch.equal(z0, z1) and torch.equal(st1, st2) and torch.equal(z1, z2)
+    zr = z0.cpu().numpy().astype(np.float64).reshape(-1, Co)
+    mu, var = zr.mean(0), zr.var(0)
+    isr = 1.0 / np.sqrt(var + 1e-3)
+    tol_m = 2e-6 * np.abs(mu).max() + 1e-6 * np.sqrt(var).max()
+    assert np.abs(mean1 - mu).max() < tol_m and np.abs(mean0 - mu).max() < tol_m
+    assert np.abs(is1 / isr - 1).max() < 2e-5 and np.abs(is0 / isr - 1).max() < 2e-5
+    with pytest.raises(Exception, match='stats_rows'):
+        L.dc_conv3x3_fwd_f16x3(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), z0.data_ptr(), Co, st1.data_ptr(), 7, None, None, 0,
+                               None, 0, None, 0, None, N, H, W, Ci, Co, None)
+
+
 def test_split_k_workspace_is_caller_owned_one_per_stream(dclib):
     """Split-K launches (narrow layers) keep their slabs in the CALLER's workspace (dc_conv3x3_splitk_ws_floats): the same
     convolution issued on two streams at once, each with its own workspace, then a larger one, must give the bits of the
@@ -965,7 +1016,7 @@ def test_split_k_workspace_is_caller_owned_one_per_stream(dclib):
         tiles = L.dc_conv3x3_tiles(N, H, W, Co)
         z = torch.full((N, H, W, Co), float('nan'), device='cuda')
         stats = torch.full((tiles * Co * 2,), float('nan'), device='cuda', dtype=torch.float64)
-        L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, stats.data_ptr(), None, None, 0,
+        L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, stats.data_ptr(), 0, None, None, 0,
                                None, 0, None, 0, ws.data_ptr(), N, H, W, Ci, Co, stream.cuda_stream if stream is not None else None)
         return z, stats
 
@@ -989,7 +1040,7 @@ def test_split_k_workspace_is_caller_owned_one_per_stream(dclib):
         N, H, W, Ci, Co = shapes[0]
         x, wp, b = data[0]
         z = torch.empty((N, H, W, Co), device='cuda')
-        L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, None, None, None, 0,
+        L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, None, 0, None, None, 0,
                                None, 0, None, 0, wss[0].data_ptr() + 4, N, H, W, Ci, Co, None)
 
 

@@ -59,7 +59,7 @@ def test_kernel_magnitude_does_not_matter(dclib, wscale):
     assert ws == 2.0 ** (10 - np.floor(np.log2(np.abs(K).max())))          # trailer = the exact power-of-two scale
     z = torch.full((N, H, W, Co), float('nan'), device='cuda')
     dx = torch.full((N, H, W, Ci), float('nan'), device='cuda')
-    L.dc_conv3x3_fwd_f16x3(dev(x).data_ptr(), wp.data_ptr(), None, z.data_ptr(), Co, None, None, None, 0, None, 0, None, 0, None,
+    L.dc_conv3x3_fwd_f16x3(dev(x).data_ptr(), wp.data_ptr(), None, z.data_ptr(), Co, None, 0, None, None, 0, None, 0, None, 0, None,
                            N, H, W, Ci, Co, None)
     L.dc_conv3x3_dgrad_f16x3(dev(dz).data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, None, 0, None, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
@@ -79,7 +79,7 @@ def test_all_zero_kernel_packs_and_runs(dclib):
     N, H, W, Ci, Co = 1, 16, 16, 32, 32
     wp = pack16(L, np.zeros((3, 3, Ci, Co), np.float32), 9, Ci, Co, Ci * Co, Co, 1, 0)
     z = torch.full((N, H, W, Co), float('nan'), device='cuda')
-    L.dc_conv3x3_fwd_f16x3(dev(np.ones((N, H, W, Ci), np.float32)).data_ptr(), wp.data_ptr(), None, z.data_ptr(), Co, None,
+    L.dc_conv3x3_fwd_f16x3(dev(np.ones((N, H, W, Ci), np.float32)).data_ptr(), wp.data_ptr(), None, z.data_ptr(), Co, None, 0,
                            None, None, 0, None, 0, None, 0, None, N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert float(wp[-4].item()) == 1.0 and (z == 0).all()
@@ -104,7 +104,7 @@ def test_activation_magnitude_guard(dclib, amag):
     wp = pack16(L, K, 9, Ci, Co, Ci * Co, Co, 1, 0)
     ad, bd = dev(a), dev(bound)
     z = torch.full((N, H, W, Co), float('nan'), device='cuda')
-    L.dc_conv3x3_fwd_f16x3(ad.data_ptr(), wp.data_ptr(), None, z.data_ptr(), Co, None, None, None, 0, bd.data_ptr(), 0, None, 0, None,
+    L.dc_conv3x3_fwd_f16x3(ad.data_ptr(), wp.data_ptr(), None, z.data_ptr(), Co, None, 0, None, None, 0, bd.data_ptr(), 0, None, 0, None,
                            N, H, W, Ci, Co, None)
     torch.cuda.synchronize()
     assert torch.isfinite(z).all() and rel_err(z.cpu().numpy(), z_ref) < 2e-5
@@ -132,7 +132,7 @@ def test_activation_magnitude_guard(dclib, amag):
     _, gK_ref, _ = on.convT2x2_bwd(a.astype(np.float64), KT.astype(np.float64), dzt.astype(np.float64))
     assert torch.isfinite(g).all() and rel_err(g.cpu().numpy(), gK_ref) < 2e-5
     if amag > 65504:
-        L.dc_conv3x3_fwd_f16x3(ad.data_ptr(), wp.data_ptr(), None, z.data_ptr(), Co, None, None, None, 0, None, 0, None, 0, None,
+        L.dc_conv3x3_fwd_f16x3(ad.data_ptr(), wp.data_ptr(), None, z.data_ptr(), Co, None, 0, None, None, 0, None, 0, None, 0, None,
                                N, H, W, Ci, Co, None)
         torch.cuda.synchronize()
         assert not torch.isfinite(z).all()
@@ -158,7 +158,7 @@ def test_bn_statistics_at_mean_1000_sigma(dclib):
         tiles = L.dc_conv3x3_tiles(N, H, W, Co)
         stats = torch.zeros(tiles * Co * 2, device='cuda', dtype=torch.float64)
         if entry == 'f16x3':
-            L.dc_conv3x3_fwd_f16x3(dev(x).data_ptr(), wp.data_ptr(), dev(b).data_ptr(), z.data_ptr(), Co, stats.data_ptr(),
+            L.dc_conv3x3_fwd_f16x3(dev(x).data_ptr(), wp.data_ptr(), dev(b).data_ptr(), z.data_ptr(), Co, stats.data_ptr(), 0,
                                    None, None, 0, None, 0, None, 0, None, N, H, W, Ci, Co, None)
         else:
             wp32 = torch.empty(9 * Ci * Co, device='cuda')
