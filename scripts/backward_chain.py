@@ -68,3 +68,21 @@ for r in bwd:
         n += 1
         if n >= 40:
             break
+
+# ---- round 5 (review item 6b): where do the weight-gradient slab reductions (reduce_stage1 / reduce_stage2, side queue) sit
+# relative to the MAIN queue -- do they ever hold a data gradient back?  The main queue waits for the side queue only through the
+# slot / buffer events recorded behind a weight gradient AND its reductions; a wait shows up as main-queue idle time.
+main_q = bwd[0]['Queue_Id']
+M = sorted([(r['s'], r['e'], r['k']) for r in bwd if r['Queue_Id'] == main_q])
+R = [(r['s'], r['e']) for r in bwd if r['k'].startswith('reduce_stage')]
+Wside = [(r['s'], r['e']) for r in bwd if is_w(r['k'])]
+gaps = [(M[i][1], M[i + 1][0], M[i + 1][2]) for i in range(len(M) - 1) if M[i + 1][0] - M[i][1] > 0]
+idle = sum(e - s for s, e, _ in gaps)
+idle_r = overlap([(s, e) for s, e, _ in gaps], R)
+idle_w = overlap([(s, e) for s, e, _ in gaps], Wside)
+print('\nslab reductions: %d launches, %.3f ms (sum) on the side queue; beside a main-queue kernel for %.1f %% of their time'
+      % (len(R), sum(e - s for s, e in R) / 1e6, 100.0 * overlap(R, [(s, e) for s, e, _ in M]) / max(1, sum(e - s for s, e in R))))
+print('main queue idle inside the backward: %.3f ms in %d gaps (%.1f %% of the span); a slab reduction is running during %.3f ms of it, '
+      'a weight gradient during %.3f ms' % (idle / 1e6, len(gaps), 100.0 * idle / span, idle_r / 1e6, idle_w / 1e6))
+big = sorted(gaps, key=lambda g: g[0] - g[1])[:8]
+print('largest main-queue gaps (us): ' + ', '.join('%.1f before %s' % ((e - s) / 1e3, k[:28]) for s, e, k in big))

@@ -6,7 +6,7 @@
 //   x [N][H][W][C] fp32 NHWC, w [3][3][C][K] HWIO  ->  y [N][H][W][K]   ('same', zero padding), H, W multiples of 16, C % 16 == 0, K % 64 == 0
 //   U[xi] = G g G^T  (16 x [C x K], packed once: fp16 hi/lo pairs, power-of-two scale)          -- pack kernel
 //   V[xi] = B^T d B  per 4x4 input tile (stride 2), M[xi] = V[xi] U[xi] (16 GEMMs), Y = A^T M A  -- main kernel
-// Main kernel: 512 threads, one workgroup = 8 x 8 tiles (16 x 16 output pixels of one image) x 64 output channels, K loop over 16-channel
+// Main kernel (v2): 512 threads, one workgroup = 8 x 8 tiles (16 x 16 output pixels of one image) x 64 output channels, K loop over 16-channel
 // chunks.  Per chunk: the raw 18 x 18 x 16 patch goes global -> registers (one chunk ahead) -> LDS; every thread transforms one
 // (tile, channel quad, half of the 4 x 4) in fp32 (adds only), splits into fp16 hi/lo (exact: hi + lo = 22 significant bits) and writes
 // V to LDS as [xi][hi|lo][8-channel group][tile] 16-byte slots; wave (i, nb) = row i of the 4 x 4 (xi = 4 i + j) x 32 output channels x
@@ -29,11 +29,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-constexpr int TT = 8, NT = TT * TT, KB = 64, CKC = 16, RW = 2 * TT + 2, NPX = RW * RW;
-constexpr int RAW_BYTES = NPX * CKC * 4;                       // 20 736
-constexpr int V_BYTES = 16 * 2 * 2 * NT * 16;                  // 65 536: [xi][hi|lo][cg][tile] x 16 B
+constexpr int TT = 8, NT = TT * TT, KB = 64, CKC = 16, RW = 2 * TT + 2, RWP = RW + 1, NPXP = RW * RWP;   // raw rows padded to an ODD slot count
+constexpr int RAW_BYTES = 4 * NPXP * 16;                       // [channel quad][padded px] 16-byte slots: 21 888
+constexpr int V_BYTES = 16 * 2 * 2 * NT * 16;                  // one stage: [xi][hi|lo][cg][tile] x 16 B = 65 536
 constexpr int EX_BYTES = 4 * 2 * NT * KB * 4;                  // 131 072: [i][b][tile][cout] floats
-constexpr int LDS_BYTES = EX_BYTES > RAW_BYTES + V_BYTES ? EX_BYTES : RAW_BYTES + V_BYTES;
+constexpr int LDS_BYTES = RAW_BYTES + 2 * V_BYTES;             // 152 960 (the epilogue exchange aliases it)
+static_assert(EX_BYTES <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // ---- weights: U = G g G^T, scaled by a power of two, split into fp16 hi / lo: Up[xi][c/8][hi|lo][k][8]
 __global__ void wino_pack(const float* __restrict__ w, _Float16* __restrict__ up, int C, int K, float scale) {
@@ -62,83 +63,104 @@ __global__ void wino_pack(const float* __restrict__ w, _Float16* __restrict__ up
   }
 }
 
-__device__ __forceinline__ void split4(const f32x4 v, float s, f16x4& hi, f16x4& lo) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float x = v[e] * s;
-    const _Float16 h = (_Float16)x;
-    hi[e] = h;
-    lo[e] = (_Float16)(x - (float)h);
-  }
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// hi = fp16(x*s), lo = fp16(x*s - hi): two v_fma_mix per element (as csrc/igemm_pp.hip split)
+__device__ __forceinline__ void split4(const f32x4 v, float s, u32x2& hi, u32x2& lo) {
+  unsigned h01, h23, l01, l23;
+  asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+      "v_fma_mixlo_f16 %1, %6, %8, 0\n\t"
+      "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+      "v_fma_mixhi_f16 %1, %7, %8, 0\n\t"
+      "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(s));
+  hi = u32x2{h01, h23};
+  lo = u32x2{l01, l23};
 }
 
+// v2 schedule: V is double-buffered and the two waves of every SIMD run the chunk's two phases in OPPOSITE order -- waves 0-3
+// issue the MFMAs of chunk k-1 and then transform their share of chunk k, waves 4-7 transform first and multiply second -- so the
+// matrix pipe of a SIMD works for one wave while the other wave's VALU / LDS transform runs (v1 ran the phases one after the other
+// for everybody: 241 us).  Raw patch as [channel quad][px] slots with an odd padded row: the transform's reads spread over all banks.
+// ABL (ablation, wrong results on purpose): 1 no transform, 2 no MFMAs, 4 no B-fragment loads, 8 no raw-patch loads, 16 no epilogue
+// SCHED: 0 = both phases in the same order for all waves (v1), 1 = opposite order for the two waves of a SIMD (v2)
+template <int SCHED, int ABL>
 __global__ __launch_bounds__(512, 1) void wino_fwd(const float* __restrict__ x, const _Float16* __restrict__ up, float* __restrict__ y,
                                                    int N, int H, int W, int C, int K, float in_scale, float out_scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* raw = reinterpret_cast<float*>(smem);                                  // [px][16]
-  char* vbase = smem + RAW_BYTES;                                               // V slots
-  float* exch = reinterpret_cast<float*>(smem);                                 // epilogue (aliases both)
+  f32x4* raw = reinterpret_cast<f32x4*>(smem);                                  // [q][py * RWP + px]
+  char* vstage = smem + RAW_BYTES;                                              // 2 x V
+  float* exch = reinterpret_cast<float*>(smem);                                 // epilogue (aliases everything)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
   const int regs_x = W / (2 * TT), regs_y = H / (2 * TT), regs = N * regs_y * regs_x;
-  const int kb = blockIdx.x / regs, reg = blockIdx.x % regs;                    // output-channel block slowest: co-running workgroups share U
+  // output-channel block FASTEST: the K / 64 workgroups of one region run side by side and share its input patch in L2 (block slowest,
+  // v1 / v2: the input came from HBM once per column block -- removing the raw loads saved 85 of 290 us)
+  const int nkb = K / KB, kb = blockIdx.x % nkb, reg = blockIdx.x / nkb;
   const int rx = reg % regs_x, ry = (reg / regs_x) % regs_y, img = reg / (regs_x * regs_y);
   const int oy0 = ry * 2 * TT, ox0 = rx * 2 * TT, k0 = kb * KB;
   const float* ximg = x + (long)img * H * W * C;
 
-  // ---- raw patch loader: 324 px x 4 float4 = 1296 items, 3 per thread (the last round partly idle)
+  // ---- raw patch loader: 324 px x 4 quads = 1296 float4 items, 3 per thread (the last round partly idle)
   f32x4 rv[3];
+  int roff[3], rdst[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int it = tid + 512 * s;
+    roff[s] = -1; rdst[s] = -1;
+    if (it < RW * RW * 4) {
+      const int px = it >> 2, q = it & 3, py = px / RW, pxx = px % RW;
+      const int iy = oy0 - 1 + py, ix = ox0 - 1 + pxx;
+      rdst[s] = q * NPXP + py * RWP + pxx;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) roff[s] = (iy * W + ix) * C + 4 * q;
+    }
+  }
   auto raw_load = [&](int c0) {
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const int it = tid + 512 * s;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (it < NPX * 4) {
-        const int px = it >> 2, f4 = it & 3, py = px / RW, pxx = px % RW;
-        const int iy = oy0 - 1 + py, ix = ox0 - 1 + pxx;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const f32x4*>(ximg + ((long)iy * W + ix) * C + c0 + 4 * f4);
-      }
-      rv[s] = v;
-    }
+    for (int s = 0; s < 3; ++s) rv[s] = (roff[s] >= 0 && !(ABL & 8)) ? *reinterpret_cast<const f32x4*>(ximg + roff[s] + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto raw_store = [&]() {
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const int it = tid + 512 * s;
-      if (it < NPX * 4) *reinterpret_cast<f32x4*>(raw + it * 4) = rv[s];
-    }
+    for (int s = 0; s < 3; ++s)
+      if (rdst[s] >= 0) raw[rdst[s]] = rv[s];
   };
-  // ---- transform item of this thread: (tile, channel quad, half)
-  const int tq = tid & 3, thalf = (tid >> 2) & 1, ttile = tid >> 3, tty = ttile / TT, ttx = ttile % TT;
-  auto transform = [&]() {
+  // ---- transform item of this thread: (tile, channel quad, half of the 4 x 4)
+  // (the half is wave-uniform: waves 0-3 rows 0-1 of the 4 x 4, waves 4-7 rows 2-3 -- no per-lane selects in the row transform)
+  const int tq = tid & 3, thalf = __builtin_amdgcn_readfirstlane(tid >> 8), ttile = (tid >> 2) & 63, tty = ttile / TT, ttx = ttile % TT;
+  const f32x4* rsrc = raw + tq * NPXP + (2 * tty + thalf) * RWP + 2 * ttx;
+  const int vdst = ((tq >> 1) * NT + ttile) * 16 + (tq & 1) * 8;
+  auto transform = [&](char* vbase) {
+    if (ABL & 1) return;
     // rows of B^T d: half 0 -> (d0 - d2, d1 + d2), half 1 -> (d2 - d1, d1 - d3); raw rows needed: half 0: 0,1,2; half 1: 1,2,3
     f32x4 d[3][4];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int cx = 0; cx < 4; ++cx)
-        d[r][cx] = *reinterpret_cast<const f32x4*>(raw + (((2 * tty + thalf + r) * RW) + 2 * ttx + cx) * CKC + 4 * tq);
-    f32x4 t[2][4];
-#pragma unroll
-    for (int cx = 0; cx < 4; ++cx) {
-      if (thalf == 0) { t[0][cx] = d[0][cx] - d[2][cx]; t[1][cx] = d[1][cx] + d[2][cx]; }
-      else            { t[0][cx] = d[1][cx] - d[0][cx]; t[1][cx] = d[0][cx] - d[2][cx]; }
-    }
+      for (int cx = 0; cx < 4; ++cx) d[r][cx] = rsrc[r * RWP + cx];
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
-      const f32x4 v[4] = {t[ii][0] - t[ii][2], t[ii][1] + t[ii][2], t[ii][2] - t[ii][1], t[ii][1] - t[ii][3]};
+      f32x4 t[4];
+#pragma unroll
+      for (int cx = 0; cx < 4; ++cx) {
+        if (thalf == 0) t[cx] = ii == 0 ? d[0][cx] - d[2][cx] : d[1][cx] + d[2][cx];
+        else            t[cx] = ii == 0 ? d[1][cx] - d[0][cx] : d[0][cx] - d[2][cx];
+      }
+      const f32x4 v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int xi = (2 * thalf + ii) * 4 + j;
-        f16x4 hi, lo;
+        u32x2 hi, lo;
         split4(v[j], in_scale, hi, lo);
-        char* dst = vbase + ((((xi * 2 + 0) * 2 + (tq >> 1)) * NT + ttile) * 16) + (tq & 1) * 8;
-        *reinterpret_cast<f16x4*>(dst) = hi;
-        *reinterpret_cast<f16x4*>(dst + 2 * NT * 16) = lo;
+        char* dst = vbase + (xi * 2 * 2 * NT * 16) + vdst;
+        *reinterpret_cast<u32x2*>(dst) = hi;
+        *reinterpret_cast<u32x2*>(dst + 2 * NT * 16) = lo;
       }
     }
   };
   // ---- consumer role of this wave: row i of the 4 x 4, output-channel block nb
-  const int wi = wave & 3, wnb = wave >> 2;
+  const int wi = wave & 3, wnb = (wave >> 2) & 1;
   f32x16 acc[4][2];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -148,25 +170,21 @@ __global__ __launch_bounds__(512, 1) void wino_fwd(const float* __restrict__ x, 
       for (int r = 0; r < 16; ++r) acc[j][tb][r] = 0.f;
   const int C8 = C / 8;
   f16x8 bf[4][2];
+  const _Float16* bsrc = up + ((long)((wi * 4) * C8 + h) * 2 * K + k0 + wnb * 32 + li) * 8;
   auto b_load = [&](int c0) {
+    if (ABL & 4) {
+      if (c0 == 0)
+        for (int j = 0; j < 4; ++j) for (int hl = 0; hl < 2; ++hl) for (int e = 0; e < 8; ++e) bf[j][hl][e] = (_Float16)(0.001f * (lane + e));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int hl = 0; hl < 2; ++hl) {
-        const long slot = ((long)(((wi * 4 + j) * C8 + c0 / 8 + h) * 2 + hl)) * K + k0 + wnb * 32 + li;
-        bf[j][hl] = *reinterpret_cast<const f16x8*>(up + slot * 8);
-      }
+      for (int hl = 0; hl < 2; ++hl)
+        bf[j][hl] = *reinterpret_cast<const f16x8*>(bsrc + ((long)((j * C8 + c0 / 8) * 2 + hl) * K) * 8);
   };
-
-  const int nch = C / CKC;
-  raw_load(0);
-  for (int ch = 0; ch < nch; ++ch) {
-    raw_store();
-    b_load(ch * CKC);                                          // in flight across the transform
-    if (ch + 1 < nch) raw_load((ch + 1) * CKC);
-    __syncthreads();
-    transform();
-    __syncthreads();
+  auto mfma_phase = [&](const char* vbase) {
+    if (ABL & 2) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int xi = wi * 4 + j;
@@ -179,9 +197,35 @@ __global__ __launch_bounds__(512, 1) void wino_fwd(const float* __restrict__ x, 
         acc[j][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bf[j][0], acc[j][tb], 0, 0, 0);
       }
     }
+  };
+
+  const int nch = C / CKC;
+  const bool mfma_first = SCHED == 0 || wave < 4;              // SCHED 1: one wave of each kind per SIMD (waves w and w + 4 share SIMD w % 4)
+  raw_load(0);
+  // iteration k: transform chunk k (k < nch) into stage k & 1; multiply chunk k - 1 (k >= 1) from stage (k - 1) & 1
+  for (int k = 0; k <= nch; ++k) {
+    if (k < nch) raw_store();
+    __syncthreads();                                           // raw(k) visible; V stage (k - 1) & 1 complete (barrier below)
+    if (k + 1 < nch) raw_load((k + 1) * CKC);
+    char* vt = vstage + (k & 1) * V_BYTES;
+    const char* vm = vstage + ((k - 1) & 1) * V_BYTES;
+    if (mfma_first) {
+      if (k >= 1) mfma_phase(vm);
+      if (k < nch) { b_load(k * CKC); transform(vt); }
+    } else {
+      if (k < nch) transform(vt);
+      if (k >= 1) mfma_phase(vm);
+      if (k < nch) b_load(k * CKC);
+    }
+    __syncthreads();                                           // V stage k & 1 complete; raw and stage (k - 1) & 1 free
   }
-  __syncthreads();                                             // every wave is done reading V: the exchange area may overwrite it
   // ---- output transform: R[i][b] = sum_j M[i][j] A[j][b] in registers, Y[a][b] = sum_i A^T[a][i] R[i][b] through LDS
+  if (ABL & 16) {
+    float sacc = 0.f;
+    for (int j = 0; j < 4; ++j) for (int tb = 0; tb < 2; ++tb) for (int r = 0; r < 16; ++r) sacc += acc[j][tb][r];
+    if (sacc == 12345.f) y[tid] = sacc;
+    return;
+  }
 #pragma unroll
   for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
@@ -194,14 +238,16 @@ __global__ __launch_bounds__(512, 1) void wino_fwd(const float* __restrict__ x, 
     }
   __syncthreads();
   float* yimg = y + (long)img * H * W * K;
-#pragma unroll 4
-  for (int s = 0; s < 16; ++s) {
-    const int idx = tid + 512 * s, co = idx & 63, b = (idx >> 6) & 1, tile = idx >> 7;
-    const float q0 = exch[((0 * 2 + b) * NT + tile) * KB + co], q1 = exch[((1 * 2 + b) * NT + tile) * KB + co];
-    const float q2 = exch[((2 * 2 + b) * NT + tile) * KB + co], q3 = exch[((3 * 2 + b) * NT + tile) * KB + co];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int idx = tid + 512 * s, c4 = (idx & 15) * 4, b = (idx >> 4) & 1, tile = idx >> 5;
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(exch + ((0 * 2 + b) * NT + tile) * KB + c4);
+    const f32x4 q1 = *reinterpret_cast<const f32x4*>(exch + ((1 * 2 + b) * NT + tile) * KB + c4);
+    const f32x4 q2 = *reinterpret_cast<const f32x4*>(exch + ((2 * 2 + b) * NT + tile) * KB + c4);
+    const f32x4 q3 = *reinterpret_cast<const f32x4*>(exch + ((3 * 2 + b) * NT + tile) * KB + c4);
     const int oy = oy0 + 2 * (tile / TT), ox = ox0 + 2 * (tile % TT) + b;
-    yimg[((long)oy * W + ox) * K + k0 + co] = (q0 + q1 + q2) * out_scale;
-    yimg[((long)(oy + 1) * W + ox) * K + k0 + co] = (q1 - q2 - q3) * out_scale;
+    *reinterpret_cast<f32x4*>(yimg + ((long)oy * W + ox) * K + k0 + c4) = (q0 + q1 + q2) * out_scale;
+    *reinterpret_cast<f32x4*>(yimg + ((long)(oy + 1) * W + ox) * K + k0 + c4) = (q1 - q2 - q3) * out_scale;
   }
 }
 
@@ -212,14 +258,20 @@ typedef int (*conv_fn)(const float*, const void*, const float*, float*, long, do
 
 int main(int argc, char** argv) {
   struct Shape { int N, HW, C, K; };
-  const Shape shapes[] = {{16, 64, 256, 256}, {16, 32, 512, 512}, {16, 128, 128, 128}};
+  const Shape shapes[] = {{16, 64, 256, 256}, {16, 32, 512, 512}};
   void* lib = dlopen("deep_calcium_amd/lib/libdcunet.so", RTLD_NOW);
   if (!lib) lib = dlopen("../../deep_calcium_amd/lib/libdcunet.so", RTLD_NOW);
   pack_fn dc_pack = lib ? (pack_fn)dlsym(lib, "dc_pack_weights_f16x3") : nullptr;
   floats_fn dc_floats = lib ? (floats_fn)dlsym(lib, "dc_pack_weights_f16x3_floats") : nullptr;
   conv_fn dc_conv = lib ? (conv_fn)dlsym(lib, "dc_conv3x3_fwd_f16x3") : nullptr;
   if (!dc_conv) printf("(libdcunet.so not found: no baseline)\n");
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  typedef void (*kern_t)(const float*, const _Float16*, float*, int, int, int, int, int, float, float);
+  struct Var { const char* name; kern_t fn; };
+  const Var vars[] = {{"v3 (opposite phase order per SIMD, column blocks side by side, uniform halves, 16-byte stores)", wino_fwd<1, 0>}, {"v1 order (same phases for all waves)", wino_fwd<0, 0>},
+                      {"v2 - transform", wino_fwd<1, 1>}, {"v2 - MFMAs", wino_fwd<1, 2>}, {"v2 - B loads", wino_fwd<1, 4>},
+                      {"v2 - raw loads", wino_fwd<1, 8>}, {"v2 - epilogue", wino_fwd<1, 16>}, {"v2 - transform - MFMAs (loads + barriers)", wino_fwd<1, 3>},
+                      {"v2 - MFMAs - B - raw (transform alone)", wino_fwd<1, 14>}, {"v2 - transform - B - raw (MFMAs alone)", wino_fwd<1, 13>}};
+  for (const Var& v : vars) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   for (const Shape& s : shapes) {
     const int N = s.N, H = s.HW, W = s.HW, C = s.C, K = s.K;
     const long nx = (long)N * H * W * C, ny = (long)N * H * W * K, nw = 9L * C * K;
@@ -241,8 +293,9 @@ int main(int argc, char** argv) {
     const float wscale = exp2f(floorf(log2f(1024.f / (wmax * 2.25f)))), in_scale = 1024.f;
     hipLaunchKernelGGL(wino_pack, dim3((unsigned)(((long)C * K + 255) / 256)), dim3(256), 0, 0, dw, dup, C, K, wscale);
     const int grid = N * (H / 16) * (W / 16) * (K / KB);
+    kern_t cur = vars[0].fn;
     auto run = [&]() {
-      hipLaunchKernelGGL(wino_fwd, dim3(grid), dim3(512), LDS_BYTES, 0, dx, dup, dy, N, H, W, C, K, in_scale, 1.f / (wscale * in_scale));
+      hipLaunchKernelGGL(cur, dim3(grid), dim3(512), LDS_BYTES, 0, dx, dup, dy, N, H, W, C, K, in_scale, 1.f / (wscale * in_scale));
     };
     run();
     CK(hipDeviceSynchronize());
@@ -304,6 +357,16 @@ int main(int argc, char** argv) {
            N, H, C, K, gf, best * 1e3, sum / reps * 1e3, gf / best, bbest * 1e3, bsum / reps * 1e3, gf / bbest, bbest / best);
     printf("    max rel error vs float64 at %zu points: winograd %.2e, baseline %.2e (bar 2e-5); winograd vs baseline over the whole tensor: %.2e\n",
            pts.size(), ew / ymax, eb / ymax, dc_conv ? dmax / allmax : 0.0);
+    for (size_t vi = 1; vi < sizeof(vars) / sizeof(vars[0]); ++vi) {          // schedule / ablation variants (ablations compute garbage)
+      cur = vars[vi].fn;
+      run(); CK(hipDeviceSynchronize());
+      float vb = 1e9f;
+      for (int r = 0; r < 10; ++r) {
+        CK(hipEventRecord(e0, 0)); run(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); vb = fminf(vb, ms);
+      }
+      printf("      %-48s %.1f us\n", vars[vi].name, vb * 1e3);
+    }
     CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dy)); CK(hipFree(dyb)); CK(hipFree(dup));
   }
   return 0;

@@ -34,6 +34,18 @@ def test_local_mode_step_equals_independent_shards(tmp_path):
     assert res['seeds_distinct'] and res['rng_same'], res
 
 
+def test_validation_logs_identical_on_every_rank(tmp_path):
+    """_ValidationMetricsCB under data parallelism (round 5): the 6 n validation items are dealt round-robin to the ranks (inference
+    is 'replicas only'), every rank forwards and scores its share, the per-item scores are summed over the ranks (each item is owned
+    by exactly one rank) -- so both ranks write the SAME val_nf_* into their logs, equal to what one rank computes alone.  2 ranks on
+    one GPU over gloo; reference: /root/reference/deepcalcium/models/neurons/unet_2d_summary.py:62-120."""
+    res = _run_ranks('_val_logs_worker.py', str(tmp_path / 'val.json'), 29571)
+    assert res['world'] == 2 and res['nonzero']
+    a, b = res['logs']
+    assert a == b and set(a) == {'val_nf_f1_mean', 'val_nf_f1_median', 'val_nf_f1_min', 'val_nf_f1_adj', 'val_nf_prec', 'val_nf_reca'}
+    assert a['val_nf_f1_mean'] == res['alone']['f1_mean'] and a['val_nf_prec'] == res['alone']['prec'] and a['val_nf_reca'] == res['alone']['reca']
+
+
 two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: RCCL between two devices over xGMI')
 
 
