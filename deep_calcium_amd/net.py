@@ -151,7 +151,16 @@ class _TtaJob(object):
 
 
 class UNetEngine(object):
-    SLOTS = 3       # rotation depth of the backward's per-block buffers (dz / dz-on-load table / activation gradient)
+    # Rotation depth of the backward's per-block buffers (dz / dz-on-load table / activation gradient).  The weight gradients run on
+    # a side stream, so a buffer may only be rewritten once the weight gradient that read it has finished: with 3 buffers the main
+    # stream WAITS on that weight gradient's event three blocks later -- always long satisfied, and still a cross-queue barrier
+    # packet that costs the main queue ~12 us each time (`scripts/backward_chain.py`: 33 such gaps per step, 0.28 ms at 512^2 x 16,
+    # 0.36 ms of a 3.1-ms step at 128^2 x 20).  With one buffer per block (SLOTS_DEEP >= the ~26 blocks / hand-overs of a step) no
+    # buffer is reused inside a step and the waits disappear; 288 GB of HBM pay for it (2 x 32 x 0.54 GB at the benchmark batch).
+    # Falls back to 3 when that would exceed SLOTS_DEEP_MAX_BYTES (very large batches).
+    SLOTS = 3
+    SLOTS_DEEP = 32
+    SLOTS_DEEP_MAX_BYTES = 48 << 30
 
     def __init__(self, window_shape, nb_filters_base=32, prop_dropout_base=0.25, device=None, seed=7535, mfma=None,
                  upsampling=False, bn_mode=None, conv_kernel_init='he_normal'):
@@ -271,6 +280,7 @@ class UNetEngine(object):
         self._bufs = {}
         # launch tapes (csrc/tape.cpp): the enqueue sequence of each phase of a steady-state train step, recorded once (and
         # verified against a second recording) per key, then replayed from C.  DC_TAPES=0: every launch from Python.
+        self.deep_slots = True            # one backward buffer set per block instead of a rotation of 3 (A/B: False; set before the first step)
         self.stats_per_wg = True          # BatchNorm partials: one row per (workgroup, consumer set) of the role-split kernel (A/B: False)
         self.use_tapes = os.environ.get('DC_TAPES', '1') != '0'
         self._tapes = {}
@@ -875,13 +885,16 @@ class UNetEngine(object):
         T['head_gpart'] = torch.empty(hb * (nfb + 4), dtype=torch.float32, device=dev)
         # per dz buffer: the apply pass' per-block max |dz| and conv-bias-gradient partials (read by the finalize launch on the
         # weight-gradient stream and by the data gradient: they rotate with the dz buffer they describe)
-        T['absmax'] = [torch.empty(4096, dtype=torch.float32, device=dev) for _ in range(self.SLOTS)]
+        big = N * self.H * self.W * nfb
+        S = self.SLOTS_DEEP if (self.deep_slots and 2 * self.SLOTS_DEEP * big * 4 <= self.SLOTS_DEEP_MAX_BYTES) else self.SLOTS
+        T['slots'] = S
+        T['absmax'] = [torch.empty(4096, dtype=torch.float32, device=dev) for _ in range(S)]
         dpart = max(L.dc_bn_bwd_blocks(N * self._hw(l.lvl)[0] * self._hw(l.lvl)[1], l.cout) * l.cout
                     for l in self.layers if l.kind != 'head')
-        T['dbias_part'] = [torch.empty(dpart, dtype=torch.float32, device=dev) for _ in range(self.SLOTS)]
-        T['dz_scale'] = torch.ones(self.SLOTS * 4, dtype=torch.float32, device=dev)      # one (16-B aligned) scalar per dz buffer
+        T['dbias_part'] = [torch.empty(dpart, dtype=torch.float32, device=dev) for _ in range(S)]
+        T['dz_scale'] = torch.ones(S * 4, dtype=torch.float32, device=dev)      # one (16-B aligned) scalar per dz buffer
         cmax = max(l.cout for l in self.layers if l.kind != 'head')
-        T['dz_coef'] = [torch.zeros(7 * cmax, dtype=torch.float32, device=dev) for _ in range(self.SLOTS)]   # dz-on-load tables
+        T['dz_coef'] = [torch.zeros(7 * cmax, dtype=torch.float32, device=dev) for _ in range(S)]   # dz-on-load tables
         T['red_tmp'] = torch.empty(32 * 1024, dtype=torch.float32, device=dev)
         T['wgrad_ws'] = torch.empty(ws_floats, dtype=torch.float32, device=dev)
         # the joint data- + weight-gradient kernel of the 32 -> 32 blocks runs on the MAIN stream: its own slab workspace
@@ -895,8 +908,8 @@ class UNetEngine(object):
         # dz rotates over 3 buffers: the weight-gradient kernels run on a side stream and may still be reading the
         # dz of block L while the main stream already produces the dz of block L-1 / L-2.  The activation gradients
         # rotate over 3 buffers for the same reason: with dz formed on load the weight gradient of block L reads `da`.
-        T['dz'] = [torch.empty(big, dtype=torch.float32, device=dev) for _ in range(self.SLOTS)]
-        T['g'] = [torch.empty(big, dtype=torch.float32, device=dev) for _ in range(self.SLOTS)]
+        T['dz'] = [torch.empty(big, dtype=torch.float32, device=dev) for _ in range(S)]
+        T['g'] = [torch.empty(big, dtype=torch.float32, device=dev) for _ in range(S)]
         for lvl in range(4):
             h, w = self._hw(lvl)
             T['dcat%d' % lvl] = torch.empty(N * h * w * (self._cup(lvl) + (nfb << lvl)), dtype=torch.float32, device=dev)
@@ -1224,7 +1237,7 @@ class UNetEngine(object):
         mh, sh_ = main.cuda_stream, side.cuda_stream          # raw handles: the hand-offs below go through the C ABI (tape-able)
         if two:
             self._wait_stream(sh_, mh)    # everything queued so far (forward, head) precedes the first wgrad
-        S = self.SLOTS
+        S = T['slots']
         slot_free = [None] * S            # event of the weight gradient that last read slot k's dz / table
         g_free = [None] * S               # event of the weight gradient that last read g[k] as `da` (dz on load)
         state = {'slot': 0, 'g': 0}       # next block slot; index of the buffer holding the current activation gradient

@@ -38,16 +38,19 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'at::native' not in r['K
 for r in rows:
     r['s'], r['e'], r['k'] = int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name'])
 rows.sort(key=lambda r: r['s'])
-adam = [i for i, r in enumerate(rows) if r['k'].startswith('adam_kernel')]
-# bench.py's LAST two steps run with one stream (roofline instrumentation): take a step of the timed region
+# step boundaries: the head kernel (forward's last / backward's first launch) of consecutive steps; a step's backward ends with its
+# last adam_kernel (the deferred tail issues two or three Adam launches per step)
+heads = [i for i, r in enumerate(rows) if r['k'].startswith('head_fwd_bwd') or r['k'].startswith('head_bwd')]
+# bench.py's LAST steps run with one stream / launch by launch (roofline instrumentation): take a step of the timed region
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-a0, a1 = adam[k], adam[k + 1]
-step = rows[a0 + 1:a1 + 1]
-head = [i for i, r in enumerate(step) if r['k'].startswith('head_fwd_bwd') or r['k'].startswith('head_bwd')]
-bwd = step[head[0]:]
+h0, h1 = heads[k], heads[k + 1]
+last_adam = max(i for i in range(h0, h1) if rows[i]['k'].startswith('adam_kernel'))
+prev_adam = max(i for i in range(heads[k - 1], h0) if rows[i]['k'].startswith('adam_kernel'))
+fwd = rows[prev_adam + 1:h0]
+bwd = rows[h0:last_adam + 1]
+step = fwd + bwd
 t0, t1 = bwd[0]['s'], bwd[-1]['e']
-fwd = step[:head[0]]
-print('step %.3f ms = forward %.3f + backward (head .. adam) %.3f' % ((step[-1]['e'] - rows[a0]['e']) / 1e6, (fwd[-1]['e'] - rows[a0]['e']) / 1e6, (t1 - t0) / 1e6))
+print('step %.3f ms = forward %.3f + backward (head .. adam) %.3f' % ((bwd[-1]['e'] - rows[prev_adam]['e']) / 1e6, (fwd[-1]['e'] - rows[prev_adam]['e']) / 1e6, (t1 - t0) / 1e6))
 is_w = lambda k: k.startswith('wgrad') or k.startswith('conv_c1_wgrad')
 is_d = lambda k: (k.startswith('igemm') and True)
 W = [(r['s'], r['e']) for r in bwd if is_w(r['k'])]
