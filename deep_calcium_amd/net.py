@@ -156,8 +156,10 @@ class UNetEngine(object):
     # stream WAITS on that weight gradient's event three blocks later -- always long satisfied, and still a cross-queue barrier
     # packet that costs the main queue ~12 us each time (`scripts/backward_chain.py`: 33 such gaps per step, 0.28 ms at 512^2 x 16,
     # 0.36 ms of a 3.1-ms step at 128^2 x 20).  With one buffer per block (SLOTS_DEEP >= the ~26 blocks / hand-overs of a step) no
-    # buffer is reused inside a step and the waits disappear; 288 GB of HBM pay for it (2 x 32 x 0.54 GB at the benchmark batch).
-    # Falls back to 3 when that would exceed SLOTS_DEEP_MAX_BYTES (very large batches).
+    # buffer is reused inside a step and the waits disappear -- MEASURED (round 5, same-box A/B, scripts/ab_engine_flags.py
+    # deep_slots): 3.094 -> 3.105 ms at 128^2 x 20, 17.996 -> 18.108 ms at 512^2 x 16, 3.282 -> 3.245 ms at 96^2 x 32: the gaps are
+    # not the waits (the event RECORD on the main queue in front of them stays), and 34 GB more footprint costs more than it saves.
+    # Off by default (`deep_slots`); falls back to 3 anyway when it would exceed SLOTS_DEEP_MAX_BYTES.
     SLOTS = 3
     SLOTS_DEEP = 32
     SLOTS_DEEP_MAX_BYTES = 48 << 30
@@ -280,7 +282,7 @@ class UNetEngine(object):
         self._bufs = {}
         # launch tapes (csrc/tape.cpp): the enqueue sequence of each phase of a steady-state train step, recorded once (and
         # verified against a second recording) per key, then replayed from C.  DC_TAPES=0: every launch from Python.
-        self.deep_slots = True            # one backward buffer set per block instead of a rotation of 3 (A/B: False; set before the first step)
+        self.deep_slots = False           # A/B (set before the first step): one backward buffer set per block instead of a rotation of 3
         self.stats_per_wg = True          # BatchNorm partials: one row per (workgroup, consumer set) of the role-split kernel (A/B: False)
         self.use_tapes = os.environ.get('DC_TAPES', '1') != '0'
         self._tapes = {}

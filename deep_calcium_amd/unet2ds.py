@@ -238,56 +238,77 @@ class _ValidationMetricsCB(Callback):
             out[i] = (p, r, f)
         return out
 
+    # Only the validation stripe of every forward is scored (:90-91).  An output pixel of this network depends on the input within
+    # 102 pixels of it (measured with the float64 oracle, worst pooling alignment; 2 + 4 + ... analytically <= 107): forwarding the
+    # stripe plus a HALO of 112 rows / columns (a multiple of 16, so every pooling grid stays where it was) gives the stripe's
+    # probabilities BIT FOR BIT -- every kernel's per-pixel arithmetic is position-independent and inference BatchNorm is a
+    # per-channel affine -- at about half the FLOPs of the 512 x 512 forward (tests/test_fit_device_gpu.py holds the equality).
+    HALO = 112
+
+    def _crop_window(self, c, hw, ww):
+        """(cy0, cy1, cx0, cx1): the part of the (hw, ww) padded image that has to be forwarded for the scored window c."""
+        y0, y1, x0, x1 = (int(v) for v in c)
+        R = self.HALO
+        if R is None or y1 <= y0 or x1 <= x0:
+            return 0, hw, 0, ww
+        cy0, cy1 = max(0, (y0 - R) // 16 * 16), min(hw, -(-(y1 + R) // 16) * 16)
+        cx0, cx1 = max(0, (x0 - R) // 16 * 16), min(ww, -(-(x1 + R) // 16) * 16)
+        if (cy1 - cy0) * (cx1 - cx0) > 0.8 * hw * ww:
+            return 0, hw, 0, ww
+        return cy0, cy1, cx0, cx1
+
     def _score_on_device(self, n):
         """The 6 n validation forwards + scorings of one epoch (:76-91), organised for the hardware:
-          * the 6 n reflect-padded images are uploaded ONCE per fit() and stay in HBM (n = 19: 120 MB);
+          * the reflect-padded images are uploaded ONCE per fit() and stay in HBM -- cropped to the scored stripe + HALO (above);
           * under data parallelism the items are dealt round-robin to the ranks (inference is 'replicas only'),
             the per-item scores are summed over the ranks -- every item is owned by exactly one rank, the others add 0.0 --,
             so every rank writes the SAME logs;
-          * forwards run in batches of 8 (inference BatchNorm is per-image), the probabilities never leave the device: the
-            scored stripe `mp[y0:y1, x0:x1].round()` (:91) comes back as one byte per pixel (dc_round_window_u8);
+          * forwards run in batches of 8 per window shape (inference BatchNorm is per-image), the probabilities never leave the
+            device: the scored stripe `mp[y0:y1, x0:x1].round()` (:91) comes back as one byte per pixel (dc_round_window_u8);
           * a scoring thread takes each batch as its copy lands and runs the native scorer (dc_host_nf_pairs: bit-identical
             to nf_mask_metrics, GIL released) while the device is on the next batch."""
         import threading
         import torch
+        from .net import UNetEngine
         from .nf_metrics import NativeScorer
         eng = self.model_val.engine
         _, hw, ww = self.model_val.input_shape
         world, rank = parallel.world_size(), parallel.rank()
         mine = list(range(rank, n, world))
         st = getattr(self, '_dev', None)
-        if st is None or st['key'] != (hw, ww, n, world, rank):
-            pad = [np.pad(self.S_summ[i], ((0, hw - self.S_summ[i].shape[0]), (0, ww - self.S_summ[i].shape[1])), 'reflect')
-                   for i in mine]
+        if st is None or st['key'] != (hw, ww, n, world, rank, self.HALO):
             truth = [np.ascontiguousarray(np.asarray(self.M_summ[i])[c[0]:c[1], c[2]:c[3]] != 0, dtype=np.uint8)
                      for i, c in ((i, self.val_coords[i]) for i in mine)]
             sizes = [t.size for t in truth]
             offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            groups = {}                              # window shape -> items (positions in `mine`), their crops
+            for k, i in enumerate(mine):
+                win = self._crop_window(self.val_coords[i], hw, ww)
+                s_pad = np.pad(self.S_summ[i], ((0, hw - self.S_summ[i].shape[0]), (0, ww - self.S_summ[i].shape[1])), 'reflect')
+                g = groups.setdefault((win[1] - win[0], win[3] - win[2]), dict(ks=[], wins=[], imgs=[]))
+                g['ks'].append(k)
+                g['wins'].append(win)
+                g['imgs'].append(np.ascontiguousarray(s_pad[win[0]:win[1], win[2]:win[3]], dtype=np.float32))
             with torch.cuda.device(eng.device):
-                x = torch.from_numpy(np.stack(pad).astype(np.float32)).to(eng.device) if mine else None
+                for shape, g in groups.items():
+                    g['x'] = torch.from_numpy(np.stack(g.pop('imgs'))).to(eng.device)
+                    g['eng'] = eng if shape == (hw, ww) else UNetEngine(shape, eng.nfb, eng.drp, device=eng.device, mfma=eng.mfma,
+                                                                      upsampling=eng.upsampling, conv_kernel_init=None)
                 out_dev = torch.empty(max(int(offs[-1]), 1), dtype=torch.uint8, device=eng.device)
                 out_host = torch.empty(max(int(offs[-1]), 1), dtype=torch.uint8).pin_memory()
-            st = self._dev = dict(key=(hw, ww, n, world, rank), x=x, truth=truth, offs=offs, out_dev=out_dev, out_host=out_host,
-                                  scorer=NativeScorer(max(sizes + [1])))
+            st = self._dev = dict(key=(hw, ww, n, world, rank, self.HALO), groups=groups, truth=truth, offs=offs, out_dev=out_dev,
+                                  out_host=out_host, scorer=NativeScorer(max(sizes + [1])))
         scores = np.zeros((n, 3))
         if mine:
-            chunks = [list(range(k, min(k + 8, len(mine)))) for k in range(0, len(mine), 8)]
+            with torch.cuda.device(eng.device):
+                for g in st['groups'].values():          # the cropped-window engines run on the validation model's weights
+                    if g['eng'] is not eng:
+                        g['eng'].pflat.copy_(eng.pflat, non_blocking=True)
+                        g['eng'].sflat.copy_(eng.sflat, non_blocking=True)
+                        g['eng']._packed_dirty = g['eng']._fold_dirty = True
+            chunks = [(g, g['ks'][j:j + 8], g['wins'][j:j + 8], j) for g in st['groups'].values() for j in range(0, len(g['ks']), 8)]
             events, flags = [], []
             done = []
-
-            def score_chunks():
-                try:
-                    host = st['out_host'].numpy()
-                    for ev, chunk in zip(events_iter(), chunks):
-                        ev.synchronize()
-                        for k in chunk:
-                            c = self.val_coords[mine[k]]
-                            mp = host[st['offs'][k]:st['offs'][k + 1]].reshape(c[1] - c[0], c[3] - c[2])
-                            p, r, _, _, f = st['scorer'](st['truth'][k], mp)
-                            scores[mine[k]] = (p, r, f)
-                except BaseException as e:      # surfaced on the caller's thread
-                    done.append(e)
-
             cond = threading.Condition()
 
             def events_iter():
@@ -297,10 +318,23 @@ class _ValidationMetricsCB(Callback):
                             cond.wait()
                     yield events[j]
 
+            def score_chunks():
+                try:
+                    host = st['out_host'].numpy()
+                    for ev, (_, ks, _, _) in zip(events_iter(), chunks):
+                        ev.synchronize()
+                        for k in ks:
+                            c = self.val_coords[mine[k]]
+                            mp = host[st['offs'][k]:st['offs'][k + 1]].reshape(c[1] - c[0], c[3] - c[2])
+                            p, r, _, _, f = st['scorer'](st['truth'][k], mp)
+                            scores[mine[k]] = (p, r, f)
+                except BaseException as e:      # surfaced on the caller's thread
+                    done.append(e)
+
             th = threading.Thread(target=score_chunks, daemon=True)
             th.start()
             try:
-                self._forward_chunks(eng, st, mine, chunks, events, flags, cond, hw, ww)
+                self._forward_chunks(eng, st, mine, chunks, events, flags, cond)
             finally:
                 with cond:                       # never leave the scorer waiting for an event that will not come
                     while len(events) < len(chunks):
@@ -313,31 +347,32 @@ class _ValidationMetricsCB(Callback):
                 raise done[0]
             if any(float(f) != 0.0 for f in torch.stack(flags).cpu().numpy().ravel()):
                 # an activation left fp16's range under the optimistic guard (never on trained weights): measured bounds, again
-                eng.infer_measured = True
+                for g in st['groups'].values():
+                    g['eng'].infer_measured = True
                 return self._score_on_device(n)
         if world > 1:
             scores = parallel.all_reduce_sum_host(scores)
         return scores
 
-    def _forward_chunks(self, eng, st, mine, chunks, events, flags, cond, hw, ww):
+    def _forward_chunks(self, eng, st, mine, chunks, events, flags, cond):
         import torch
         with torch.cuda.device(eng.device):
             stream = torch.cuda.current_stream(eng.device)
-            for chunk in chunks:
-                p = eng.forward_infer(st['x'][chunk[0]:chunk[-1] + 1])
-                if eng.mfma == 'f16x3' and eng.range_guard and not eng.infer_measured:
-                    flags.append(eng._ovf[0:1].clone())
+            for g, ks, wins, j0 in chunks:
+                ge = g['eng']
+                hc, wc = g['x'].shape[1:]
+                p = ge.forward_infer(g['x'][j0:j0 + len(ks)])
+                if ge.mfma == 'f16x3' and ge.range_guard and not ge.infer_measured:
+                    flags.append(ge._ovf[0:1].clone())
                 else:
                     flags.append(torch.zeros(1, device=eng.device))
-                for j, k in enumerate(chunk):
-                    y0, y1, x0, x1 = self.val_coords[mine[k]]
+                for j, (k, win) in enumerate(zip(ks, wins)):
+                    y0, y1, x0, x1 = (int(v) for v in self.val_coords[mine[k]])
                     o0, o1 = int(st['offs'][k]), int(st['offs'][k + 1])
                     if o1 > o0:
-                        eng.L.dc_round_window_u8(p[j].data_ptr(), 1, hw, ww, int(y0), int(y1), int(x0), int(x1),
+                        eng.L.dc_round_window_u8(p[j].data_ptr(), 1, hc, wc, y0 - win[0], y1 - win[0], x0 - win[2], x1 - win[2],
                                                  st['out_dev'].data_ptr() + o0, stream.cuda_stream)
-                o0, o1 = int(st['offs'][chunk[0]]), int(st['offs'][chunk[-1] + 1])
-                if o1 > o0:
-                    st['out_host'][o0:o1].copy_(st['out_dev'][o0:o1], non_blocking=True)
+                        st['out_host'][o0:o1].copy_(st['out_dev'][o0:o1], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(stream)
                 with cond:

@@ -158,6 +158,44 @@ def test_validation_on_device_equals_the_references_sequence(tmp_path):
     assert [f1_dev[n] for n in 'abc'] == [list(ff[6 * i:6 * i + 6]) for i in range(3)]
 
 
+@pytest.mark.parametrize('nfb', [8, 32])
+def test_validation_crop_is_bit_identical_to_the_full_forward(nfb):
+    """The validation callback forwards only the scored stripe + a 112-pixel halo (_ValidationMetricsCB.HALO: the network's output
+    depends on the input within 102 pixels).  At the real validation size (512 x 512 windows, stripes of 128 rows / columns after
+    the 6 augmentations) the bytes that come back -- `mp[y0:y1, x0:x1].round()` of every item -- and the logs must equal those of
+    the full 512 x 512 forwards, on weights with non-trivial BatchNorm statistics."""
+    from deep_calcium_amd import unet_hip
+    from deep_calcium_amd.unet2ds import _ValidationMetricsCB
+    from oracle import unet_numpy as on
+    rs = np.random.RandomState(4)
+    S = [rs.standard_normal((512, 512)).astype(np.float32), rs.standard_normal((500, 470)).astype(np.float32)]
+    M = []
+    for s_ in S:
+        m = np.zeros(s_.shape)
+        for _ in range(80):
+            cy, cx = rs.randint(6, s_.shape[0] - 6), rs.randint(6, s_.shape[1] - 6)
+            m[cy - 3:cy + 4, cx - 3:cx + 4] = 1
+        M.append(m)
+    yc = [(s_.shape[0] - int(s_.shape[0] * 0.25), s_.shape[0]) for s_ in S]
+    model = unet_hip((32, 32), nb_filters_base=nfb)
+    model.set_weights(on.init_weights(nfb, seed=5, randomize_bn=True))
+    model_val = unet_hip((512, 512), nb_filters_base=nfb)
+    cb = _ValidationMetricsCB(model_val, S, M, ['a', 'b'], yc)
+    cb.set_model(model)
+    logs_crop, logs_full = {}, {}
+    cb.on_epoch_end(1, logs_crop)
+    shapes = sorted(cb._dev['groups'])
+    assert (240, 512) in shapes and (512, 240) in shapes, shapes            # 128-row / -column stripes + halo, 16-aligned
+    bytes_crop = cb._dev['out_host'].numpy().copy()
+    cb.HALO = None                                                         # the reference's own extent: the whole padded image
+    cb.on_epoch_end(1, logs_full)
+    assert sorted(cb._dev['groups']) == [(512, 512)]
+    bytes_full = cb._dev['out_host'].numpy().copy()
+    assert bytes_crop.shape == bytes_full.shape and 0.02 < bytes_full.mean() < 0.98
+    assert np.array_equal(bytes_crop, bytes_full)
+    assert logs_crop == logs_full
+
+
 def test_background_checkpoint_is_the_snapshot_not_the_later_weights(tmp_path):
     """ModelCheckpoint(background=True): the file written by the background thread holds the weights / Adam state of the moment
     save() was called, byte for byte what a blocking save() of that moment writes -- although training went on meanwhile."""
