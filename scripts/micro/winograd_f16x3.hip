@@ -29,11 +29,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-constexpr int TT = 8, NT = TT * TT, KB = 64, CKC = 16, RW = 2 * TT + 2, RWP = RW + 1, NPXP = RW * RWP;   // raw rows padded to an ODD slot count
-constexpr int RAW_BYTES = 4 * NPXP * 16;                       // [channel quad][padded px] 16-byte slots: 21 888
-constexpr int V_BYTES = 16 * 2 * 2 * NT * 16;                  // one stage: [xi][hi|lo][cg][tile] x 16 B = 65 536
-constexpr int EX_BYTES = 4 * 2 * NT * KB * 4;                  // 131 072: [i][b][tile][cout] floats
-constexpr int LDS_BYTES = RAW_BYTES + 2 * V_BYTES;             // 152 960 (the epilogue exchange aliases it)
+constexpr int TT = 8, NT = TT * TT, KB = 64, CKC = 16, RW = 2 * TT + 2, RWP = RW + 1;      // raw rows padded to an ODD slot count
+constexpr int NPXP = ((RW * RWP + 15) / 16) * 16 + 1;          // ... and the quad planes to 1 (mod 16) slots: conflict-free transform reads
+constexpr int RAW_BYTES = 4 * NPXP * 16;                       // [channel quad][padded px] 16-byte slots: 22 592
+constexpr int V_BYTES = 16 * 2 * 2 * NT * 16;                  // one stage: [xi][hi|lo][cg][(tile + 8 cg) & 63] x 16 B = 65 536
+constexpr int EX_BYTES = 4 * 2 * 2 * NT * 32 * 4;              // 131 072: [i][j pair][b][tile][32 couts] floats, one column block at a time
+constexpr int LDS_BYTES = RAW_BYTES + 2 * V_BYTES;             // 153 664 (the epilogue exchange aliases it)
 static_assert(EX_BYTES <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // ---- weights: U = G g G^T, scaled by a power of two, split into fp16 hi / lo: Up[xi][c/8][hi|lo][k][8]
@@ -81,12 +82,12 @@ __device__ __forceinline__ void split4(const f32x4 v, float s, u32x2& hi, u32x2&
   lo = u32x2{l01, l23};
 }
 
-// v2 schedule: V is double-buffered and the two waves of every SIMD run the chunk's two phases in OPPOSITE order -- waves 0-3
-// issue the MFMAs of chunk k-1 and then transform their share of chunk k, waves 4-7 transform first and multiply second -- so the
-// matrix pipe of a SIMD works for one wave while the other wave's VALU / LDS transform runs (v1 ran the phases one after the other
-// for everybody: 241 us).  Raw patch as [channel quad][px] slots with an odd padded row: the transform's reads spread over all banks.
+// Schedule: V is double-buffered; SCHED 1 / 2: the two waves of a SIMD run the chunk's two phases in OPPOSITE order (which waves share
+// a SIMD is not documented: SCHED 1 assumes w and w + 4, SCHED 2 assumes 2s and 2s + 1); SCHED 0: the same order for every wave.
+// v5 (this version): consumers register-blocked 2 xi x 2 tile blocks x 2 column blocks (every A fragment feeds two column blocks: half
+// the fragment reads of v1-v3), conflict-free LDS layouts (transform lanes = 8 tiles of a row x 2 quads per 16-lane group over
+// [quad][px] planes of 1 (mod 16) slots; the two 8-channel groups of V rotated by 8 tiles), epilogue per column block with 16-byte IO.
 // ABL (ablation, wrong results on purpose): 1 no transform, 2 no MFMAs, 4 no B-fragment loads, 8 no raw-patch loads, 16 no epilogue
-// SCHED: 0 = both phases in the same order for all waves (v1), 1 = opposite order for the two waves of a SIMD (v2)
 template <int SCHED, int ABL>
 __global__ __launch_bounds__(512, 1) void wino_fwd(const float* __restrict__ x, const _Float16* __restrict__ up, float* __restrict__ y,
                                                    int N, int H, int W, int C, int K, float in_scale, float out_scale) {
@@ -95,9 +96,8 @@ __global__ __launch_bounds__(512, 1) void wino_fwd(const float* __restrict__ x, 
   char* vstage = smem + RAW_BYTES;                                              // 2 x V
   float* exch = reinterpret_cast<float*>(smem);                                 // epilogue (aliases everything)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
-  const int regs_x = W / (2 * TT), regs_y = H / (2 * TT), regs = N * regs_y * regs_x;
-  // output-channel block FASTEST: the K / 64 workgroups of one region run side by side and share its input patch in L2 (block slowest,
-  // v1 / v2: the input came from HBM once per column block -- removing the raw loads saved 85 of 290 us)
+  const int regs_x = W / (2 * TT), regs_y = H / (2 * TT);
+  // output-channel block FASTEST: the K / 64 workgroups of one region run side by side and share its input patch in L2
   const int nkb = K / KB, kb = blockIdx.x % nkb, reg = blockIdx.x / nkb;
   const int rx = reg % regs_x, ry = (reg / regs_x) % regs_y, img = reg / (regs_x * regs_y);
   const int oy0 = ry * 2 * TT, ox0 = rx * 2 * TT, k0 = kb * KB;
@@ -126,11 +126,10 @@ __global__ __launch_bounds__(512, 1) void wino_fwd(const float* __restrict__ x, 
     for (int s = 0; s < 3; ++s)
       if (rdst[s] >= 0) raw[rdst[s]] = rv[s];
   };
-  // ---- transform item of this thread: (tile, channel quad, half of the 4 x 4)
-  // (the half is wave-uniform: waves 0-3 rows 0-1 of the 4 x 4, waves 4-7 rows 2-3 -- no per-lane selects in the row transform)
-  const int tq = tid & 3, thalf = __builtin_amdgcn_readfirstlane(tid >> 8), ttile = (tid >> 2) & 63, tty = ttile / TT, ttx = ttile % TT;
+  // ---- transform item of this thread: (tile, channel quad, half of the 4 x 4); a 16-lane group = the 8 tiles of a tile row x 2 quads
+  const int ttx = tid & 7, tq = (tid >> 3) & 3, tty = (tid >> 5) & 7, thalf = __builtin_amdgcn_readfirstlane(tid >> 8), ttile = tty * TT + ttx;
   const f32x4* rsrc = raw + tq * NPXP + (2 * tty + thalf) * RWP + 2 * ttx;
-  const int vdst = ((tq >> 1) * NT + ttile) * 16 + (tq & 1) * 8;
+  const int vdst = ((tq >> 1) * NT + ((ttile + 8 * (tq >> 1)) & 63)) * 16 + (tq & 1) * 8;
   auto transform = [&](char* vbase) {
     if (ABL & 1) return;
     // rows of B^T d: half 0 -> (d0 - d2, d1 + d2), half 1 -> (d2 - d1, d1 - d3); raw rows needed: half 0: 0,1,2; half 1: 1,2,3
@@ -159,48 +158,64 @@ __global__ __launch_bounds__(512, 1) void wino_fwd(const float* __restrict__ x, 
       }
     }
   };
-  // ---- consumer role of this wave: row i of the 4 x 4, output-channel block nb
-  const int wi = wave & 3, wnb = (wave >> 2) & 1;
-  f32x16 acc[4][2];
+  // ---- consumer role of this wave: row i of the 4 x 4, column pair jp (xi = 4 i + 2 jp + jj), both tile blocks, both column blocks
+  const int wi = wave >> 1, wjp = wave & 1;
+  f32x16 acc[2][2][2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][tb][r] = 0.f;
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jj][tb][nb][r] = 0.f;
   const int C8 = C / 8;
-  f16x8 bf[4][2];
-  const _Float16* bsrc = up + ((long)((wi * 4) * C8 + h) * 2 * K + k0 + wnb * 32 + li) * 8;
+  f16x8 bf[2][2][2];
+  const _Float16* bsrc = up + ((long)((wi * 4 + 2 * wjp) * C8 + h) * 2 * K + k0 + li) * 8;
   auto b_load = [&](int c0) {
     if (ABL & 4) {
       if (c0 == 0)
-        for (int j = 0; j < 4; ++j) for (int hl = 0; hl < 2; ++hl) for (int e = 0; e < 8; ++e) bf[j][hl][e] = (_Float16)(0.001f * (lane + e));
+        for (int jj = 0; jj < 2; ++jj) for (int nb = 0; nb < 2; ++nb) for (int hl = 0; hl < 2; ++hl) for (int e = 0; e < 8; ++e) bf[jj][nb][hl][e] = (_Float16)(0.001f * (lane + e));
       return;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-      for (int hl = 0; hl < 2; ++hl)
-        bf[j][hl] = *reinterpret_cast<const f16x8*>(bsrc + ((long)((j * C8 + c0 / 8) * 2 + hl) * K) * 8);
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+          bf[jj][nb][hl] = *reinterpret_cast<const f16x8*>(bsrc + (((long)(jj * C8 + c0 / 8) * 2 + hl) * K + nb * 32) * 8);
   };
+  const int aoff0 = (h * NT + ((li + 8 * h) & 63)) * 16, aoff1 = (h * NT + ((32 + li + 8 * h) & 63)) * 16;
   auto mfma_phase = [&](const char* vbase) {
     if (ABL & 2) return;
+    __builtin_amdgcn_s_setprio(3);                           // the wave that feeds the matrix pipe goes first
+    // all 8 A fragments first, then the three product terms ACROSS the accumulator blocks: consecutive MFMAs never depend on each
+    // other, so ONE wave can keep its SIMD's matrix pipe busy (the other wave of the SIMD is transforming)
+    f16x8 ah[2][2], al[2][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int xi = wi * 4 + j;
+    for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb) {
-        const f16x8 ah = *reinterpret_cast<const f16x8*>(vbase + ((((xi * 2 + 0) * 2 + h) * NT + tb * 32 + li) * 16));
-        const f16x8 al = *reinterpret_cast<const f16x8*>(vbase + ((((xi * 2 + 1) * 2 + h) * NT + tb * 32 + li) * 16));
-        acc[j][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bf[j][0], acc[j][tb], 0, 0, 0);
-        acc[j][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bf[j][1], acc[j][tb], 0, 0, 0);
-        acc[j][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bf[j][0], acc[j][tb], 0, 0, 0);
+        const char* ap = vbase + (wi * 4 + 2 * wjp + jj) * (2 * 2 * NT * 16) + (tb ? aoff1 : aoff0);
+        ah[jj][tb] = *reinterpret_cast<const f16x8*>(ap);
+        al[jj][tb] = *reinterpret_cast<const f16x8*>(ap + 2 * NT * 16);
       }
-    }
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[jj][tb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? al[jj][tb] : ah[jj][tb], bf[jj][nb][term == 1 ? 1 : 0],
+                                                                     acc[jj][tb][nb], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
   };
 
   const int nch = C / CKC;
-  const bool mfma_first = SCHED == 0 || wave < 4;              // SCHED 1: one wave of each kind per SIMD (waves w and w + 4 share SIMD w % 4)
+  const bool mfma_first = SCHED == 0 || (SCHED == 1 ? wave < 4 : (wave & 1) == 0);
   raw_load(0);
   // iteration k: transform chunk k (k < nch) into stage k & 1; multiply chunk k - 1 (k >= 1) from stage (k - 1) & 1
   for (int k = 0; k <= nch; ++k) {
@@ -219,35 +234,41 @@ __global__ __launch_bounds__(512, 1) void wino_fwd(const float* __restrict__ x, 
     }
     __syncthreads();                                           // V stage k & 1 complete; raw and stage (k - 1) & 1 free
   }
-  // ---- output transform: R[i][b] = sum_j M[i][j] A[j][b] in registers, Y[a][b] = sum_i A^T[a][i] R[i][b] through LDS
+  // ---- output transform.  R[i][b] = sum_j M[i][j] A[j][b]: the wave holding columns (0, 1) contributes (m0 + m1, m1), the one holding
+  // (2, 3) contributes (m2, -m2 - m3); Y[a][b] = sum_i A^T[a][i] R[i][b] across the waves through LDS, one 32-column block at a time.
   if (ABL & 16) {
     float sacc = 0.f;
-    for (int j = 0; j < 4; ++j) for (int tb = 0; tb < 2; ++tb) for (int r = 0; r < 16; ++r) sacc += acc[j][tb][r];
+    for (int jj = 0; jj < 2; ++jj) for (int tb = 0; tb < 2; ++tb) for (int nb = 0; nb < 2; ++nb) for (int r = 0; r < 16; ++r) sacc += acc[jj][tb][nb][r];
     if (sacc == 12345.f) y[tid] = sacc;
     return;
   }
-#pragma unroll
-  for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int tile = tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float r0 = acc[0][tb][r] + acc[1][tb][r] + acc[2][tb][r];
-      const float r1 = acc[1][tb][r] - acc[2][tb][r] - acc[3][tb][r];
-      exch[((wi * 2 + 0) * NT + tile) * KB + wnb * 32 + li] = r0;
-      exch[((wi * 2 + 1) * NT + tile) * KB + wnb * 32 + li] = r1;
-    }
-  __syncthreads();
   float* yimg = y + (long)img * H * W * K;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int idx = tid + 512 * s, c4 = (idx & 15) * 4, b = (idx >> 4) & 1, tile = idx >> 5;
-    const f32x4 q0 = *reinterpret_cast<const f32x4*>(exch + ((0 * 2 + b) * NT + tile) * KB + c4);
-    const f32x4 q1 = *reinterpret_cast<const f32x4*>(exch + ((1 * 2 + b) * NT + tile) * KB + c4);
-    const f32x4 q2 = *reinterpret_cast<const f32x4*>(exch + ((2 * 2 + b) * NT + tile) * KB + c4);
-    const f32x4 q3 = *reinterpret_cast<const f32x4*>(exch + ((3 * 2 + b) * NT + tile) * KB + c4);
-    const int oy = oy0 + 2 * (tile / TT), ox = ox0 + 2 * (tile % TT) + b;
-    *reinterpret_cast<f32x4*>(yimg + ((long)oy * W + ox) * K + k0 + c4) = (q0 + q1 + q2) * out_scale;
-    *reinterpret_cast<f32x4*>(yimg + ((long)(oy + 1) * W + ox) * K + k0 + c4) = (q1 - q2 - q3) * out_scale;
+  for (int nb = 0; nb < 2; ++nb) {
+    if (nb) __syncthreads();                                   // the previous block's readers are done
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tile = tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float m0 = acc[0][tb][nb][r], m1 = acc[1][tb][nb][r];
+        const float p0 = wjp == 0 ? m0 + m1 : m0, p1 = wjp == 0 ? m1 : -m0 - m1;
+        exch[(((wi * 2 + wjp) * 2 + 0) * NT + tile) * 32 + li] = p0;
+        exch[(((wi * 2 + wjp) * 2 + 1) * NT + tile) * 32 + li] = p1;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int idx = tid + 512 * s, c4 = (idx & 7) * 4, b = (idx >> 3) & 1, tile = idx >> 4;
+      f32x4 R[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        R[i] = *reinterpret_cast<const f32x4*>(exch + (((i * 2 + 0) * 2 + b) * NT + tile) * 32 + c4) +
+               *reinterpret_cast<const f32x4*>(exch + (((i * 2 + 1) * 2 + b) * NT + tile) * 32 + c4);
+      const int oy = oy0 + 2 * (tile / TT), ox = ox0 + 2 * (tile % TT) + b;
+      *reinterpret_cast<f32x4*>(yimg + ((long)oy * W + ox) * K + k0 + nb * 32 + c4) = (R[0] + R[1] + R[2]) * out_scale;
+      *reinterpret_cast<f32x4*>(yimg + ((long)(oy + 1) * W + ox) * K + k0 + nb * 32 + c4) = (R[1] - R[2] - R[3]) * out_scale;
+    }
   }
 }
 
@@ -267,7 +288,7 @@ int main(int argc, char** argv) {
   if (!dc_conv) printf("(libdcunet.so not found: no baseline)\n");
   typedef void (*kern_t)(const float*, const _Float16*, float*, int, int, int, int, int, float, float);
   struct Var { const char* name; kern_t fn; };
-  const Var vars[] = {{"v3 (opposite phase order per SIMD, column blocks side by side, uniform halves, 16-byte stores)", wino_fwd<1, 0>}, {"v1 order (same phases for all waves)", wino_fwd<0, 0>},
+  const Var vars[] = {{"v5 SCHED 1", wino_fwd<1, 0>}, {"v5 SCHED 0 (same phase order for all waves)", wino_fwd<0, 0>}, {"v5 SCHED 2 (opposite order for waves 2s / 2s+1)", wino_fwd<2, 0>},
                       {"v2 - transform", wino_fwd<1, 1>}, {"v2 - MFMAs", wino_fwd<1, 2>}, {"v2 - B loads", wino_fwd<1, 4>},
                       {"v2 - raw loads", wino_fwd<1, 8>}, {"v2 - epilogue", wino_fwd<1, 16>}, {"v2 - transform - MFMAs (loads + barriers)", wino_fwd<1, 3>},
                       {"v2 - MFMAs - B - raw (transform alone)", wino_fwd<1, 14>}, {"v2 - transform - B - raw (MFMAs alone)", wino_fwd<1, 13>}};
