@@ -77,22 +77,21 @@ class KernelTimer(object):
     """Proxy around the C-ABI library that brackets every launch of ONE kernel symbol with HIP events
     (recorded on the stream the kernel is launched on) and tallies its algorithmic FLOPs."""
 
-    # Dominant kernel = the conv3x3 implicit GEMM with 256 px x 64 col tiles, launched by dc_conv3x3_fwd* /
-    # dc_conv3x3_dgrad* whenever W > 16 and the output has > 32 columns: the persistent role-split kernel of
-    # csrc/igemm_pp.hip (Cin a multiple of 16, >= 64; the 256-thread igemm_f16x3_kernel<3,3,1,1,32,4,2,2,16> serves the one
-    # Cin = 32 training-forward launch of that shape; the data gradients that also emit BatchNorm-backward sums run its
-    # <2,2,1,*> instantiation through dc_conv3x3_dgrad_bnred_f16x3, the dz-on-load data gradient of d0a its <2,2,0,true>
-    # one through dc_conv3x3_dgrad_dzin_f16x3: other symbols, not counted here), csrc/igemm_conv.hip for mfma='f32'.
-    # Per train step at batch 16 of 512^2: 19 launches (14 forward convolutions + 5 data gradients), 4.6 ms of 18.2.
+    # Dominant kernel = the conv3x3 implicit GEMM with 256 px x 64 col tiles: the persistent role-split kernel of
+    # csrc/igemm_pp.hip.  Round 5: the TRAINING FORWARD convolutions of that shape (BatchNorm partials merged per workgroup,
+    # dc_conv3x3_stats_rows) run its own instantiation igemm_pp_kernel<2,2,3,false> -- 14 launches per train step at batch 16 of
+    # 512^2, the largest single symbol of the step; the 5 plain data gradients of the shape stay on <2,2,0,false> (rounds 2-4 counted
+    # both under that one symbol: 19 launches), the data gradients that emit BatchNorm-backward sums on <2,2,1,*>, d0a's dz-on-load
+    # data gradient on <2,2,0,true>: other symbols, not counted here.  csrc/igemm_conv.hip for mfma='f32'.
     KERNELS = {
-        'f16x3': ('igemm_pp_kernel<2,2,0,false>', PEAK_FP16_MFMA_TFLOPS, 3),
+        'f16x3': ('igemm_pp_kernel<2,2,3,false>', PEAK_FP16_MFMA_TFLOPS, 3),
         'f32': ('igemm_kernel<3,3,1,1,32,4,2,2,16>', PEAK_FP32_MFMA_TFLOPS, 1),
     }
     # entry point -> (GEMM column count is Cout / Cin, is a data gradient, index of the `stats` argument | None); every
     # one ends with N, H, W, Cin, Cout, stream.  A launch is counted only if the library's own routing query says it runs the
-    # named symbol (f16x3: dc_conv3x3_pp_blocks() > 0 and > 32 columns = igemm_pp_kernel<2,2,0,false>).
+    # named symbol (f16x3: a forward launch with per-workgroup BatchNorm partials, dc_conv3x3_pp_blocks() > 0 and > 32 columns).
     SITES = {'dc_conv3x3_fwd': ('cout', 0, 5), 'dc_conv3x3_dgrad': ('cin', 1, None), 'dc_conv3x3_fwd_f16x3': ('cout', 0, 5),
-             'dc_conv3x3_dgrad_f16x3': ('cin', 1, None), 'dc_conv3x3_fwd_bnin_f16x3': ('cout', 0, 8)}
+             'dc_conv3x3_fwd_bnin_f16x3': ('cout', 0, 8)}
 
     def __init__(self, lib):
         self._lib = lib
@@ -113,9 +112,11 @@ class KernelTimer(object):
             ncols = Cout if colkey == 'cout' else Cin
             if not (Ww > 16 and ncols > 32):
                 return fn(*args)
-            if f16 and self._lib.dc_conv3x3_pp_blocks(N, Hh, Ww, Cin, Cout, dgrad,
-                                                      int(stats_at is not None and args[stats_at] is not None)) <= 0:
-                return fn(*args)          # a 256-thread kernel serves this launch (e.g. the 32-input-channel forward layer)
+            if f16:
+                per_wg = (stats_at is not None and args[stats_at] is not None and
+                          args[stats_at + 1] not in (0, self._lib.dc_conv3x3_tiles(N, Hh, Ww, Cout)))
+                if not per_wg or self._lib.dc_conv3x3_pp_blocks(N, Hh, Ww, Cin, Cout, dgrad, 1) <= 0:
+                    return fn(*args)      # another symbol: a 256-thread kernel, an inference launch, per-tile partials
             e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
             self._lib.dc_event_create(ctypes.byref(e0))
             self._lib.dc_event_create(ctypes.byref(e1))
