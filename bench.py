@@ -78,25 +78,28 @@ class KernelTimer(object):
     (recorded on the stream the kernel is launched on) and tallies its algorithmic FLOPs."""
 
     # Dominant kernel = the conv3x3 implicit GEMM with 256 px x 64 col tiles: the persistent role-split kernel of
-    # csrc/igemm_pp.hip.  Round 5: the TRAINING FORWARD convolutions of that shape (BatchNorm partials merged per workgroup,
-    # dc_conv3x3_stats_rows) run its own instantiation igemm_pp_kernel<2,2,3,false> -- 14 launches per train step at batch 16 of
-    # 512^2, the largest single symbol of the step; the 5 plain data gradients of the shape stay on <2,2,0,false> (rounds 2-4 counted
-    # both under that one symbol: 19 launches), the data gradients that emit BatchNorm-backward sums on <2,2,1,*>, d0a's dz-on-load
-    # data gradient on <2,2,0,true>: other symbols, not counted here.  csrc/igemm_conv.hip for mfma='f32'.
+    # csrc/igemm_pp.hip, base instantiation igemm_pp_kernel<2,2,0,false> (igemm_kernel of csrc/igemm_conv.hip for mfma='f32').
+    # Per train step at batch 16 of 512^2 it serves 12 launches: the 7 forward convolutions of that shape at levels 3-4 (BatchNorm
+    # partials per pixel tile) + the 5 plain data gradients.  Round 5 moved the 7 forward convolutions at levels 1-2 to their own
+    # instantiation <2,2,3,false> (BatchNorm partials merged per workgroup, dc_conv3x3_stats_rows: same main loop, other symbol;
+    # rounds 2-4 counted all 19 under the base symbol); the data gradients that emit BatchNorm-backward sums run <2,2,1,*>, d0a's
+    # dz-on-load data gradient <2,2,0,true>.  Launches are tallied per symbol; the line reports the one with the largest total time.
     KERNELS = {
-        'f16x3': ('igemm_pp_kernel<2,2,3,false>', PEAK_FP16_MFMA_TFLOPS, 3),
+        'f16x3': ('igemm_pp_kernel<2,2,0,false>', PEAK_FP16_MFMA_TFLOPS, 3),
         'f32': ('igemm_kernel<3,3,1,1,32,4,2,2,16>', PEAK_FP32_MFMA_TFLOPS, 1),
     }
+    PERWG_F16 = 'igemm_pp_kernel<2,2,3,false>'
     # entry point -> (GEMM column count is Cout / Cin, is a data gradient, index of the `stats` argument | None); every
     # one ends with N, H, W, Cin, Cout, stream.  A launch is counted only if the library's own routing query says it runs the
-    # named symbol (f16x3: a forward launch with per-workgroup BatchNorm partials, dc_conv3x3_pp_blocks() > 0 and > 32 columns).
+    # role-split kernel with > 32 columns (dc_conv3x3_pp_blocks() > 0).
     SITES = {'dc_conv3x3_fwd': ('cout', 0, 5), 'dc_conv3x3_dgrad': ('cin', 1, None), 'dc_conv3x3_fwd_f16x3': ('cout', 0, 5),
-             'dc_conv3x3_fwd_bnin_f16x3': ('cout', 0, 8)}
+             'dc_conv3x3_dgrad_f16x3': ('cin', 1, None), 'dc_conv3x3_fwd_bnin_f16x3': ('cout', 0, 8)}
 
     def __init__(self, lib):
         self._lib = lib
-        self.records = []
+        self.records = {}                  # symbol -> [(e0, e1, flops, bytes)]
         self.enabled = False
+        self.symbol = None
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
@@ -112,11 +115,15 @@ class KernelTimer(object):
             ncols = Cout if colkey == 'cout' else Cin
             if not (Ww > 16 and ncols > 32):
                 return fn(*args)
+            symbol = None
             if f16:
-                per_wg = (stats_at is not None and args[stats_at] is not None and
-                          args[stats_at + 1] not in (0, self._lib.dc_conv3x3_tiles(N, Hh, Ww, Cout)))
-                if not per_wg or self._lib.dc_conv3x3_pp_blocks(N, Hh, Ww, Cin, Cout, dgrad, 1) <= 0:
-                    return fn(*args)      # another symbol: a 256-thread kernel, an inference launch, per-tile partials
+                with_stats = stats_at is not None and args[stats_at] is not None
+                per_wg = with_stats and args[stats_at + 1] not in (0, self._lib.dc_conv3x3_tiles(N, Hh, Ww, Cout))
+                if self._lib.dc_conv3x3_pp_blocks(N, Hh, Ww, Cin, Cout, dgrad, int(with_stats)) <= 0:
+                    return fn(*args)      # a 256-thread kernel serves this launch (e.g. the 32-input-channel forward layer)
+                symbol = self.PERWG_F16 if per_wg else self.KERNELS['f16x3'][0]
+            else:
+                symbol = self.KERNELS['f32'][0]
             e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
             self._lib.dc_event_create(ctypes.byref(e0))
             self._lib.dc_event_create(ctypes.byref(e1))
@@ -125,22 +132,29 @@ class KernelTimer(object):
             rc = fn(*args)
             self._lib.dc_event_record(e1, stream)
             # algorithmic bytes (input + output + weights, fp32, each moved once)
-            self.records.append((e0, e1, 2.0 * 9 * Cin * Cout * N * Hh * Ww, 4.0 * (N * Hh * Ww * (Cin + Cout) + 9 * Cin * Cout)))
+            self.records.setdefault(symbol, []).append((e0, e1, 2.0 * 9 * Cin * Cout * N * Hh * Ww, 4.0 * (N * Hh * Ww * (Cin + Cout) + 9 * Cin * Cout)))
             return rc
         return wrapped
 
-    def summarize(self):
-        tot_ms, tot_flops, tot_bytes = 0.0, 0.0, 0.0
-        for e0, e1, flops, nbytes in self.records:
-            ms = ctypes.c_float()
-            self._lib.dc_event_elapsed_ms(e0, e1, ctypes.byref(ms))
-            tot_ms += ms.value
-            tot_flops += flops
-            tot_bytes += nbytes
-            self._lib.dc_event_destroy(e0)
-            self._lib.dc_event_destroy(e1)
-        n = len(self.records)
-        self.records = []
+    def summarize(self, symbol=None):
+        """(launches, ms, flops) of ONE symbol: `symbol`, or -- the first time -- the one with the largest total time (kept in
+        self.symbol, so that the follow-up measurement reports the same kernel)."""
+        per = {}
+        for sym, recs in self.records.items():
+            tot_ms, tot_flops, tot_bytes = 0.0, 0.0, 0.0
+            for e0, e1, flops, nbytes in recs:
+                ms = ctypes.c_float()
+                self._lib.dc_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+                tot_ms += ms.value
+                tot_flops += flops
+                tot_bytes += nbytes
+                self._lib.dc_event_destroy(e0)
+                self._lib.dc_event_destroy(e1)
+            per[sym] = (len(recs), tot_ms, tot_flops, tot_bytes)
+        self.records = {}
+        symbol = symbol or self.symbol or (max(per, key=lambda k: per[k][1]) if per else None)
+        self.symbol = symbol
+        n, tot_ms, tot_flops, tot_bytes = per.get(symbol, (0, 0.0, 0.0, 0.0))
         self.last_bytes = tot_bytes
         return n, tot_ms, tot_flops
 
@@ -245,7 +259,8 @@ def bench_infer(args, model, xd, rank, world):
     if rank != 0:
         return
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-    kname, peak, mpf = KernelTimer.KERNELS[eng.mfma]
+    _, peak, mpf = KernelTimer.KERNELS[eng.mfma]
+    kname = timer.symbol
     emit_json(json.dumps({
         'metric': '512x512 summary images/sec (forward only)', 'value': round(world * B * args.steps / dt, 2),
         'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -531,7 +546,8 @@ def main():
 
     if rank == 0:
         achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        kname, peak, mfma_per_flop = KernelTimer.KERNELS[eng.mfma]
+        _, peak, mfma_per_flop = KernelTimer.KERNELS[eng.mfma]
+        kname = timer.symbol
         traffic, traffic_note = pmc_traffic(kname)
         if (H, B) != (512, 16):
             traffic, traffic_note = None, 'the committed PMC passes were taken at batch 16 of 512x512'

@@ -41,6 +41,22 @@ def test_abi_version_matches_the_header(dclib):
     assert dclib.dc_convT2x2_dgrad_splitk_ws_floats(20, 8, 8, 512, 256) >= 0
 
 
+def test_tape_trampolines_are_current_and_cover_the_launch_entry_points():
+    """csrc/tape_tramp.inc is generated from include/dcunet.h (deep_calcium_amd/_gen_tape.py, run by the build): the committed copy
+    must be what the generator renders from the committed header, and every launch entry point must be replayable -- except the
+    ones that take host data read at call time or return through an out-parameter."""
+    from deep_calcium_amd import _gen_tape, _lib
+    assert open(_gen_tape.OUT).read() == _gen_tape.render()
+    tapeable = set(n for n, _ in _gen_tape.prototypes())
+    protos = _lib.parse_header()
+    launches = set(n for n, (rt, _, _) in protos.items() if rt is ctypes.c_int and not n.endswith(('_tiles', '_blocks', '_floats', '_rows'))
+                   and n != 'dc_version')
+    assert launches - tapeable == {'dc_crop_augment', 'dc_event_create', 'dc_event_create_sync', 'dc_event_elapsed_ms', 'dc_event_destroy',
+                                   'dc_host_nf_pairs', 'dc_host_label8', 'dc_tape_create', 'dc_tape_destroy', 'dc_tape_append',
+                                   'dc_tape_patch', 'dc_tape_replay', 'dc_tape_len'}, launches - tapeable
+    assert {'dc_conv3x3_fwd_f16x3', 'dc_event_record', 'dc_stream_wait_event', 'dc_adam_step_flat', 'dc_conv3x3_bwd_joint_f16x3'} <= tapeable
+
+
 def test_header_cites_reference_call_sites():
     src = open(os.path.join(os.path.dirname(__file__), '..', 'include', 'dcunet.h')).read()
     assert 'unet_2d_summary.py:123-224' in src and 'unet_2d_summary.py:164-165' in src and ':156-157' in src
