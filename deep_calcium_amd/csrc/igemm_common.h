@@ -63,6 +63,9 @@ struct IgemmParams {
   // dzCoef[DC_DZ_COEF_ROWS][Cin] (dc_bn_bwd_finalize_dzin; row 6 = the bound the fp16 range guard scales by)
   const float* in2;
   const float* dzCoef;
+  // ... and (nullable) where the producers also write the dz they form: dense [N][Hin][Win][Cin] like `in`, every pixel once (the
+  // interior of each tile's halo'd patch, by the workgroup that holds the tile's FIRST column block)
+  float* dzOut;
   // 256-thread f16x3 kernel only, split-K (grid.y = S > 1: the narrow 16^2 / 8^2 layers of a small step put < 256 workgroups
   // on the chip with 16-64 serial chunks each): workgroup (x, s) contracts chunks [nch s / S, nch (s+1) / S) and writes its
   // scaled partial tile to the dense slab splitWs + s * splitSlab ([N][Hout][Wout][Ncols] floats, no bias / statistics);

@@ -1045,7 +1045,7 @@ extern "C" int dc_conv3x3_dgrad_dzin_blocks(int N, int H, int W, int Cin, int Co
   return N * dc_cdiv(W, 32) * dc_cdiv(H, Cin <= 32 ? 16 : 8);
 }
 extern "C" int dc_conv3x3_dgrad_dzin_f16x3(const float* da, const float* z, const float* dz_coef, const void* wp16, float* dx,
-                                           const float* red_z, const float* red_mean, const float* red_invstd,
+                                           float* dz_out, const float* red_z, const float* red_mean, const float* red_invstd,
                                            const float* red_gamma, const float* red_beta, float* bn_partial,
                                            float* amax_partial, int N, int H, int W, int Cin, int Cout,
                                            dc_stream_t stream) {
@@ -1059,7 +1059,8 @@ extern "C" int dc_conv3x3_dgrad_dzin_f16x3(const float* da, const float* z, cons
   DC_REQUIRE(dc_conv3x3_dgrad_dzin_blocks(N, H, W, Cin, Cout) > 0, DC_EUNSUP,
              "dc_conv3x3_dgrad_dzin_f16x3: shape not served (dc_conv3x3_dgrad_dzin_blocks() == 0): use dc_bn_bwd_apply + dc_conv3x3_dgrad_f16x3");
   IgemmParams p = dgrad_bnred_params(da, wp16, dx, nullptr, N, H, W, Cin, Cout);
-  p.in2 = z; p.dzCoef = dz_coef;
+  p.in2 = z; p.dzCoef = dz_coef; p.dzOut = dz_out;
+  DC_REQUIRE(dz_out == nullptr || dc_aligned16(dz_out), DC_EINVAL, "dc_conv3x3_dgrad_dzin_f16x3: dz_out must be 16-byte aligned");
   if (red_z) {
     p.bnZ = red_z; p.bnMean = red_mean; p.bnInvstd = red_invstd; p.bnGamma = red_gamma; p.bnBeta = red_beta;
     p.bnPartial = bn_partial; p.bnAmax = amax_partial;

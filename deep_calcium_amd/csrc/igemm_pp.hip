@@ -211,11 +211,30 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
       for (int it = 0; it < NBV; ++it) b_rel[it] = b_rel_of(it, b_row0);
     }
     unsigned a_voff[NA], b_voff[NBV];
-    __amdgpu_buffer_rsrc_t rsrcA = rsrcB, rsrcZ = rsrcB;
+    __amdgpu_buffer_rsrc_t rsrcA = rsrcB, rsrcZ = rsrcB, rsrcO = rsrcB;
+    // DZIN + dzOut: bit k = staging slot k of this thread is an INTERIOR pixel of the halo'd patch (every image pixel is interior
+    // to exactly one tile); store_dz = the item staged next holds the tile's first column block (wave-uniform)
+    // (64-column instantiations only: the <4,1> ones sit at the 168-VGPR budget of a 768-thread workgroup)
+    constexpr bool DZOUT = DZIN && MB == 2;
+    unsigned int_mask = 0;
+    bool store_dz = false;
+    if constexpr (DZOUT) {
+#pragma unroll
+      for (int k = 0; k < NA; ++k) {
+        const int pix = a_pix0 + k * A_STEP, r = pix / TWI, c = pix - r * TWI;
+        if (pix < NPIXH && r >= 1 && r <= THI - 2 && c >= 1 && c <= TWI - 2) int_mask |= 1u << k;
+      }
+    }
     auto setup_item = [&](int j) __attribute__((always_inline)) {
       const Item it = decode(j);
       rsrcA = dc_make_rsrc(p.in + (long)it.img * p.Hin * p.Win * p.Cin, (unsigned)(p.Hin * p.Win * p.Cin) * 4u);
-      if constexpr (DZIN) rsrcZ = dc_make_rsrc(p.in2 + (long)it.img * p.Hin * p.Win * p.Cin, (unsigned)(p.Hin * p.Win * p.Cin) * 4u);
+      if constexpr (DZIN) {
+        rsrcZ = dc_make_rsrc(p.in2 + (long)it.img * p.Hin * p.Win * p.Cin, (unsigned)(p.Hin * p.Win * p.Cin) * 4u);
+        if constexpr (DZOUT) {
+          store_dz = p.dzOut != nullptr && it.n0 == 0;
+          if (p.dzOut) rsrcO = dc_make_rsrc(p.dzOut + (long)it.img * p.Hin * p.Win * p.Cin, (unsigned)(p.Hin * p.Win * p.Cin) * 4u);
+        }
+      }
       const int iy0 = it.oy0 - 1, ix0 = it.ox0 - 1;
       const int base = (iy0 * p.Win + ix0) * p.Cin * 4;
       const bool inside = iy0 >= 0 && ix0 >= 0 && iy0 + THI <= p.Hin && ix0 + TWI <= p.Win;     // wave-uniform
@@ -290,6 +309,10 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
               const float dzv = __builtin_fmaf(cA[e], dy, __builtin_fmaf(cD[e], zz[e] - cmu[e], cE[e]));
               v[e] = live ? dzv : 0.f;
             }
+            // the weight gradient's copy of dz (a store at an out-of-image offset is dropped by the descriptor)
+            if constexpr (DZOUT)
+              if (store_dz && ((int_mask >> k) & 1u))
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcO, a_voff[k], c0 * 4, 0);
           }
           if (bnin) {
             const bool live = !(a_voff[k] >> 31);              // zero padding stays zero
@@ -751,6 +774,7 @@ int dc_igemm_pp_stats_rows(const IgemmParams& p) {
 int dc_igemm_pp_launch(IgemmParams p, hipStream_t st, const char* name) {
   if (p.dzCoef) {
     DC_REQUIRE(p.in2 && p.Cin <= pp::DZ_CIN && !p.inSc && !p.poolOut, DC_EINVAL, "%s: bad dz-on-load launch", name);
+    DC_REQUIRE(p.dzOut == nullptr || p.Ncols > 32, DC_EUNSUP, "%s: dz_out needs more than 32 GEMM columns (the 64-column instantiation)", name);
     if (p.bnPartial) return p.Ncols <= 32 ? pp_launch<4, 1, 1, true>(p, st, name) : pp_launch<2, 2, 1, true>(p, st, name);
     return p.Ncols <= 32 ? pp_launch<4, 1, 0, true>(p, st, name) : pp_launch<2, 2, 0, true>(p, st, name);
   }

@@ -282,6 +282,7 @@ class UNetEngine(object):
         self._bufs = {}
         # launch tapes (csrc/tape.cpp): the enqueue sequence of each phase of a steady-state train step, recorded once (and
         # verified against a second recording) per key, then replayed from C.  DC_TAPES=0: every launch from Python.
+        self.dz_writeback = _dz == '1'    # levels >= 1: dz formed by the data gradient and written once for a plain weight gradient (A/B: False)
         self.deep_slots = False           # A/B (set before the first step): one backward buffer set per block instead of a rotation of 3
         self.stats_per_wg = True          # BatchNorm partials: one row per (workgroup, consumer set) of the role-split kernel (A/B: False)
         self.use_tapes = os.environ.get('DC_TAPES', '1') != '0'
@@ -1148,17 +1149,25 @@ class UNetEngine(object):
         return [(o_dec, self.n_train), (o_ba, o_dec), (0, o_ba)]
 
     def _dzin_ok(self, l, N):
-        """Does block l run without the BatchNorm-backward apply pass (dz formed on load by its gradient kernels)?"""
-        if not self.dzin or l.kind != 'conv' or l.drop > 0.0 or l.lvl not in self.dzin_lvls:
-            return False
+        """Does block l run without the BatchNorm-backward apply pass?  0: no (finalize -> apply -> gradients);
+        1: dz formed on load by BOTH gradient kernels (level 0: joint / dz-on-load kernels; DC_DZIN=all: everywhere eligible);
+        2 (round 5, levels >= 1): the data gradient forms dz on load AND writes it once, the weight gradient is the plain kernel --
+           the dz-on-load weight gradient is the slower of the two (its producers are its longest role), the data gradient's
+           producers have the values in registers anyway: 1 tensor write replaces the apply pass' 2 reads + 1 write."""
+        if not self.dzin or l.kind != 'conv' or l.drop > 0.0:
+            return 0
         h, w = self._hw(l.lvl)
         if not self.dzin_all and N * h * w <= (1 << 20):
             # small steps (the reference's own 96^2 / 128^2 training windows) are launch-latency bound, not HBM-bound: the
             # apply pass costs ~15 us there while the persistent dz-on-load kernels pay their set-up (same-box 3.29 vs 3.92 ms)
-            return False
-        if l.cin == 1:
-            return True
-        return self.L.dc_conv3x3_dgrad_dzin_blocks(N, h, w, l.cin, l.cout) > 0
+            return 0
+        if l.lvl in self.dzin_lvls:
+            if l.cin == 1:
+                return 1
+            return 1 if self.L.dc_conv3x3_dgrad_dzin_blocks(N, h, w, l.cin, l.cout) > 0 else 0
+        if self.dz_writeback and l.cin > 32 and self.L.dc_conv3x3_dgrad_dzin_blocks(N, h, w, l.cin, l.cout) > 0:
+            return 2          # (the write-back lives in the 64-column instantiation: layers with more than 32 input channels)
+        return 0
 
     @_on_device
     def backward(self, bucket_cb=None, defer_tail=False):
@@ -1276,7 +1285,10 @@ class UNetEngine(object):
             gamma, beta = self.pview(self.pflat, l, 'gamma'), self.pview(self.pflat, l, 'beta')
             dgamma, dbeta = self.pview(self.gflat, l, 'gamma'), self.pview(self.gflat, l, 'beta')
             dk, ws = self.pview(self.gflat, l, 'k'), _ptr(T['wgrad_ws'])
-            dzin = da_ld == l.cout and self._dzin_ok(l, N)
+            dz_mode = self._dzin_ok(l, N) if da_ld == l.cout else 0
+            if dz_mode == 2 and dx_ptr is None:
+                dz_mode = 0
+            dzin = dz_mode > 0
             k = state['slot']
             state['slot'] = (k + 1) % S
             if fused is None:
@@ -1333,13 +1345,23 @@ class UNetEngine(object):
                                  self.pview(self.pflat, red, 'gamma'), self.pview(self.pflat, red, 'beta'),
                                  _ptr(T['part_ws']), _ptr(T['amax_ws']))
                         fused_next = (_ptr(T['part_ws']), _ptr(T['amax_ws']), rows)
-                    L.dc_conv3x3_dgrad_dzin_f16x3(da_ptr, _ptr(z), coef, _ptr(self.wp_dgrad[l.name]), dx_ptr, *rargs,
-                                                  N, h, w, l.cin, l.cout, st)
+                    L.dc_conv3x3_dgrad_dzin_f16x3(da_ptr, _ptr(z), coef, _ptr(self.wp_dgrad[l.name]), dx_ptr,
+                                                  _ptr(T['dz'][k]) if dz_mode == 2 else None, *rargs, N, h, w, l.cin, l.cout, st)
                 if two:
                     self._wait_stream(sh_, mh)
                 sw = sh_
-                L.dc_conv3x3_wgrad_dzin_f16x3(xa[0], xa[1], xa[2], self._ab_in(l), da_ptr, _ptr(z), coef, dk, ws,
-                                              N, h, w, l.cin, l.cout, sw)
+                if dz_mode == 2:
+                    # the data gradient has written dz: plain weight gradient, its power-of-two scale from the table's bound row
+                    dzp, scale = _ptr(T['dz'][k]), _ptr(T['dz_scale'], 4 * k)
+                    L.dc_pow2_scale_from_absmax(coef + 4 * 6 * l.cout, l.cout, 1024.0, scale, sw)
+                    if bsrc is not None:
+                        L.dc_conv3x3_wgrad_bnin_f16x3(bsrc[0], bsrc[1][0], bsrc[1][1], self._ab_in(l), dzp, dk, ws, scale, N, h, w,
+                                                      l.cin, l.cout, sw)
+                    else:
+                        L.dc_conv3x3_wgrad_f16x3(x_in, dzp, dk, ws, scale, self._ab_in(l), N, h, w, l.cin, l.cout, sw)
+                else:
+                    L.dc_conv3x3_wgrad_dzin_f16x3(xa[0], xa[1], xa[2], self._ab_in(l), da_ptr, _ptr(z), coef, dk, ws,
+                                                  N, h, w, l.cin, l.cout, sw)
                 if two:
                     ev = self._record(sh_)
                     slot_free[k] = ev

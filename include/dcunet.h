@@ -36,7 +36,7 @@ typedef void* dc_stream_t;
 
 /* ABI revision: dc_version() of the loaded library must EQUAL the DC_ABI_VERSION of the header the caller was built /
  * bound against (argument lists change between revisions; the Python binding refuses a mismatch). */
-#define DC_ABI_VERSION 104
+#define DC_ABI_VERSION 105
 int dc_version(void);
 const char* dc_last_error(void);
 
@@ -299,6 +299,10 @@ int dc_maxpool2x2_bwd_bnred(const float* dy, const uint8_t* idx, const float* sk
  *     kernel only: dc_conv3x3_dgrad_dzin_blocks() == 0 -> shape not served, use dc_bn_bwd_apply + dc_conv3x3_dgrad_f16x3.
  *     red_z != NULL: dx IS the `da` of the BatchNorm layer in front (as dc_conv3x3_dgrad_bnred_f16x3): also emits
  *     bn_partial[rows][Cin][2] and amax_partial[rows][Cin], rows = the returned block count.
+ *     dz_out != NULL (round 5): the dz the producers form is also WRITTEN, once per pixel (dense [N,H,W,Cout], fp32, unscaled),
+ *     for a plain weight gradient (dc_conv3x3_wgrad_f16x3 / _bnin, dz_scale = dc_pow2_scale_from_absmax over row 6 of dz_coef):
+ *     the BatchNorm-backward apply pass of the block disappears (1 tensor write instead of 2 reads + 1 write) and only the data
+ *     gradient pays for forming dz -- the dz-on-load weight gradient is the slower of the two dz-on-load kernels.
  *   dc_conv3x3_wgrad_dzin_f16x3: dW = sum_p x[p+tap] (x) dz[p]; x as dc_conv3x3_wgrad_f16x3 (in_scale / in_shift NULL)
  *     or the producer's pre-BN tensor with BN + ReLU on load (as dc_conv3x3_wgrad_bnin_f16x3).  Cin == 1 (first layer):
  *     x is the (N,H,W) image.
@@ -309,7 +313,7 @@ int dc_bn_bwd_finalize_dzin(const float* partial, const float* amax_partial, int
                             const float* invstd, const float* gamma, const float* beta, double count,
                             float* dgamma, float* dbeta, float* dz_coef, float* dbias, dc_stream_t stream);
 int dc_conv3x3_dgrad_dzin_blocks(int N, int H, int W, int Cin, int Cout);
-int dc_conv3x3_dgrad_dzin_f16x3(const float* da, const float* z, const float* dz_coef, const void* wp16, float* dx,
+int dc_conv3x3_dgrad_dzin_f16x3(const float* da, const float* z, const float* dz_coef, const void* wp16, float* dx, float* dz_out,
                                 const float* red_z, const float* red_mean, const float* red_invstd,
                                 const float* red_gamma, const float* red_beta, float* bn_partial, float* amax_partial,
                                 int N, int H, int W, int Cin, int Cout, dc_stream_t stream);

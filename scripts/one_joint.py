@@ -32,7 +32,7 @@ def joint(r):
     L.dc_conv3x3_bwd_joint_f16x3(x.data_ptr(), xsc.data_ptr(), xsh.data_ptr(), None, da.data_ptr(), z.data_ptr(), coef.data_ptr(), wpd.data_ptr(),
                                  dx.data_ptr(), *(red if r else (None,) * 7), dw.data_ptr(), ws.data_ptr(), N, H, W, C, C, None)
 def sep(r):
-    L.dc_conv3x3_dgrad_dzin_f16x3(da.data_ptr(), z.data_ptr(), coef.data_ptr(), wpd.data_ptr(), dx.data_ptr(), *(red if r else (None,) * 7), N, H, W, C, C, None)
+    L.dc_conv3x3_dgrad_dzin_f16x3(da.data_ptr(), z.data_ptr(), coef.data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, *(red if r else (None,) * 7), N, H, W, C, C, None)
     L.dc_conv3x3_wgrad_dzin_f16x3(x.data_ptr(), xsc.data_ptr(), xsh.data_ptr(), None, da.data_ptr(), z.data_ptr(), coef.data_ptr(), dw.data_ptr(), ws.data_ptr(), N, H, W, C, C, None)
 for name, fn in (('joint + sums', lambda: joint(True)), ('joint', lambda: joint(False)), ('separate + sums', lambda: sep(True))):
     for _ in range(3): fn()

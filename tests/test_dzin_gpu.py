@@ -155,7 +155,7 @@ def test_conv3x3_dgrad_dzin(dclib, N, H, W, Cin, Cout, with_sums):
         part = torch.full((rows * Cin * 2,), float('nan'), device='cuda')
         amx = torch.full((rows * Cin,), float('nan'), device='cuda')
         red = (rz.data_ptr(), rmu.data_ptr(), ris.data_ptr(), rga.data_ptr(), rbe.data_ptr(), part.data_ptr(), amx.data_ptr())
-    L.dc_conv3x3_dgrad_dzin_f16x3(dad.data_ptr(), zd.data_ptr(), coef.data_ptr(), wpd.data_ptr(), dx.data_ptr(), *red,
+    L.dc_conv3x3_dgrad_dzin_f16x3(dad.data_ptr(), zd.data_ptr(), coef.data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, *red,
                                   N, H, W, Cin, Cout, None)
     torch.cuda.synchronize()
     got = dx.cpu().numpy()
@@ -163,7 +163,7 @@ def test_conv3x3_dgrad_dzin(dclib, N, H, W, Cin, Cout, with_sums):
     assert np.abs(got - dx_ref).max() < 2e-5 * np.abs(dx_ref).max()
     # run to run: bit-reproducible
     dx2 = torch.full_like(dx, float('nan'))
-    L.dc_conv3x3_dgrad_dzin_f16x3(dad.data_ptr(), zd.data_ptr(), coef.data_ptr(), wpd.data_ptr(), dx2.data_ptr(), *red,
+    L.dc_conv3x3_dgrad_dzin_f16x3(dad.data_ptr(), zd.data_ptr(), coef.data_ptr(), wpd.data_ptr(), dx2.data_ptr(), None, *red,
                                   N, H, W, Cin, Cout, None)
     torch.cuda.synchronize()
     assert torch.equal(dx, dx2)
@@ -181,6 +181,54 @@ def test_conv3x3_dgrad_dzin(dclib, N, H, W, Cin, Cout, with_sums):
         tol = 2e-5 * max(np.abs(ref_dg).max(), np.abs(ref_db).max())
         assert np.abs(dg.cpu().numpy() - ref_dg).max() < tol and np.abs(db.cpu().numpy() - ref_db).max() < tol
         assert np.array_equal(amx.cpu().numpy().reshape(rows, Cin).max(0), np.abs(dy).max(0).astype(np.float32))
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 64, 64, 64, 64), (1, 40, 72, 48, 80), (1, 32, 32, 128, 256), (3, 33, 50, 64, 96),
+                                            (2, 32, 64, 256, 128)])
+def test_dgrad_dzin_writes_dz_for_a_plain_weight_gradient(dclib, N, H, W, Cin, Cout):
+    """dz_out (round 5): the dz-on-load data gradient also WRITES the dz its producers form -- every pixel exactly once (interior
+    and ragged tiles, 2-5 column blocks of which only the first stores) -- so that the block's weight gradient is the plain kernel
+    and no BatchNorm-backward apply pass runs.  dx is bit-identical with and without the write-back; dz_out is the float64 dz to
+    fp32 rounding; dc_conv3x3_wgrad_f16x3 on it (scale from the table's bound row) meets the oracle's dK at the usual 2e-5."""
+    L = dclib
+    assert L.dc_conv3x3_dgrad_dzin_blocks(N, H, W, Cin, Cout) > 0
+    rs = np.random.RandomState(Cin + Cout + W)
+    x, z, mean, invstd, gamma, beta, da = _block_case(rs, N, H, W, Cin, Cout)
+    K = (rs.standard_normal((3, 3, Cin, Cout)) * 0.05).astype(np.float32)
+    dz_ref, _, _, _ = _dz_ref(z, mean, invstd, gamma, beta, da)
+    _, dK_ref, _ = on.conv3x3_bwd(x.astype(np.float64), K.astype(np.float64), dz_ref)
+    zd, dad, coef, _, _, _ = _finalize(L, z, mean, invstd, gamma, beta, da)
+    Kd, xd = dev(K), dev(x)
+    wpd = torch.empty(L.dc_pack_weights_f16x3_floats(9, Cout, Cin), device='cuda')
+    L.dc_pack_weights_f16x3(Kd.data_ptr(), wpd.data_ptr(), 9, Cout, Cin, Cin * Cout, 1, Cout, 1, None)
+    dx0 = torch.full((N, H, W, Cin), float('nan'), device='cuda'); dx1 = torch.full_like(dx0, float('nan'))
+    dzo = torch.full((N, H, W, Cout), float('nan'), device='cuda')
+    L.dc_conv3x3_dgrad_dzin_f16x3(dad.data_ptr(), zd.data_ptr(), coef.data_ptr(), wpd.data_ptr(), dx0.data_ptr(), None, *((None,) * 7),
+                                  N, H, W, Cin, Cout, None)
+    L.dc_conv3x3_dgrad_dzin_f16x3(dad.data_ptr(), zd.data_ptr(), coef.data_ptr(), wpd.data_ptr(), dx1.data_ptr(), dzo.data_ptr(),
+                                  *((None,) * 7), N, H, W, Cin, Cout, None)
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1)
+    got = dzo.cpu().numpy()
+    assert np.isfinite(got).all(), 'pixels the write-back missed: %d' % int((~np.isfinite(got)).sum())
+    assert np.abs(got - dz_ref).max() < 2e-6 * np.abs(dz_ref).max()
+    scale = torch.full((4,), float('nan'), device='cuda')
+    L.dc_pow2_scale_from_absmax(coef.data_ptr() + 4 * 6 * Cout, Cout, 1024.0, scale.data_ptr(), None)
+    ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, H, W, Cin, Cout), device='cuda')
+    dw = torch.full((3, 3, Cin, Cout), float('nan'), device='cuda')
+    L.dc_conv3x3_wgrad_f16x3(xd.data_ptr(), dzo.data_ptr(), dw.data_ptr(), ws.data_ptr(), scale.data_ptr(), None, N, H, W, Cin, Cout, None)
+    torch.cuda.synchronize()
+    sc = float(scale[0].item())
+    assert sc > 0 and np.log2(sc) == np.floor(np.log2(sc)) and sc * np.abs(got).max() <= 1024.0
+    assert np.abs(dw.cpu().numpy() - dK_ref).max() < 2e-5 * np.abs(dK_ref).max()
+    if Cin <= 32:
+        return
+    from deep_calcium_amd._lib import DcunetError
+    with pytest.raises(DcunetError, match='dz_out needs more than 32'):
+        small = torch.empty((N, H, W, 32), device='cuda')
+        wps = torch.empty(L.dc_pack_weights_f16x3_floats(9, Cout, 32), device='cuda')
+        L.dc_conv3x3_dgrad_dzin_f16x3(dad.data_ptr(), zd.data_ptr(), coef.data_ptr(), wps.data_ptr(), small.data_ptr(), dzo.data_ptr(),
+                                      *((None,) * 7), N, H, W, 32, Cout, None)
 
 
 # every weight-gradient tile configuration (wgrad_f16x3.hip CONV_H_DISPATCH) incl. the narrow ones the data gradient
@@ -259,7 +307,7 @@ def test_dzin_fp16_range(dclib, case):
     wpd = torch.empty(L.dc_pack_weights_f16x3_floats(9, Cout, Cin), device='cuda')
     L.dc_pack_weights_f16x3(Kd.data_ptr(), wpd.data_ptr(), 9, Cout, Cin, Cin * Cout, 1, Cout, 1, None)
     dx = torch.full((N, H, W, Cin), float('nan'), device='cuda')
-    L.dc_conv3x3_dgrad_dzin_f16x3(dad.data_ptr(), zd.data_ptr(), coef.data_ptr(), wpd.data_ptr(), dx.data_ptr(), *((None,) * 7),
+    L.dc_conv3x3_dgrad_dzin_f16x3(dad.data_ptr(), zd.data_ptr(), coef.data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, *((None,) * 7),
                                   N, H, W, Cin, Cout, None)
     ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, H, W, Cin, Cout), device='cuda')
     dw = torch.full((3, 3, Cin, Cout), float('nan'), device='cuda')
@@ -306,7 +354,7 @@ def test_dzin_bound_when_dy_follows_xhat(dclib, noise):
     wpd = torch.empty(L.dc_pack_weights_f16x3_floats(9, Cout, Cin), device='cuda')
     L.dc_pack_weights_f16x3(Kd.data_ptr(), wpd.data_ptr(), 9, Cout, Cin, Cin * Cout, 1, Cout, 1, None)
     dx = torch.full((N, H, W, Cin), float('nan'), device='cuda')
-    L.dc_conv3x3_dgrad_dzin_f16x3(dad.data_ptr(), zd.data_ptr(), coef.data_ptr(), wpd.data_ptr(), dx.data_ptr(), *((None,) * 7),
+    L.dc_conv3x3_dgrad_dzin_f16x3(dad.data_ptr(), zd.data_ptr(), coef.data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, *((None,) * 7),
                                   N, H, W, Cin, Cout, None)
     ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, H, W, Cin, Cout), device='cuda')
     dw = torch.full((3, 3, Cin, Cout), float('nan'), device='cuda')
