@@ -1157,7 +1157,7 @@ class UNetEngine(object):
         if not self.dzin or l.kind != 'conv' or l.drop > 0.0:
             return 0
         h, w = self._hw(l.lvl)
-        if not self.dzin_all and N * h * w <= (1 << 20):
+        if not self.dzin_all and N * self.H * self.W <= (1 << 20):
             # small steps (the reference's own 96^2 / 128^2 training windows) are launch-latency bound, not HBM-bound: the
             # apply pass costs ~15 us there while the persistent dz-on-load kernels pay their set-up (same-box 3.29 vs 3.92 ms)
             return 0
