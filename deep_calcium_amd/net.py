@@ -282,7 +282,9 @@ class UNetEngine(object):
         self._bufs = {}
         # launch tapes (csrc/tape.cpp): the enqueue sequence of each phase of a steady-state train step, recorded once (and
         # verified against a second recording) per key, then replayed from C.  DC_TAPES=0: every launch from Python.
-        self.dz_writeback = _dz == '1'    # levels >= 1: dz formed by the data gradient and written once for a plain weight gradient (A/B: False)
+        # levels >= 1: dz formed by the data gradient AND written once for a plain weight gradient (no apply pass): built, parity-green,
+        # measured SLOWER same box (17.651 -> 18.103 ms: the role-split kernel's producers become its longest role, as for DC_DZIN=all)
+        self.dz_writeback = False
         self.deep_slots = False           # A/B (set before the first step): one backward buffer set per block instead of a rotation of 3
         self.stats_per_wg = True          # BatchNorm partials: one row per (workgroup, consumer set) of the role-split kernel (A/B: False)
         self.use_tapes = os.environ.get('DC_TAPES', '1') != '0'
