@@ -579,6 +579,7 @@ class Model(object):
         box = []
 
         def feed():
+            raw = None
             try:
                 snap['event'].synchronize()
                 proc = self._writer_process()
@@ -599,6 +600,11 @@ class Model(object):
                     raise IOError(reply or 'the checkpoint writer process died')
             except BaseException as e:       # surfaced by wait_for_saves()
                 box.append(e)
+                if raw is not None and os.path.exists(raw):      # (the writer process removes it when it got that far)
+                    try:
+                        os.remove(raw)
+                    except OSError:
+                        pass
         th = threading.Thread(target=feed, daemon=False)
         self._saving = (th, box, filepath)
         th.start()
