@@ -170,6 +170,13 @@ class _Lib(object):
             raise DcunetError('libdcunet.so not found at %s -- run `python -m deep_calcium_amd._build` '
                               '(there is no CPU fallback)' % path)
         self.path = path
+        # torch FIRST: the PyTorch-ROCm wheel carries its own libamdhip64; once it is loaded, libdcunet.so's dependency on that
+        # soname resolves to the same runtime.  Loaded the other way round (this library before torch: /opt/rocm's copy, then
+        # torch's) the process holds two HIP runtimes and every launch from here fails with "no ROCm-capable device is detected".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         self.cdll = ctypes.CDLL(path)
         self.protos = parse_header()
         # the header's argument lists are only valid for a library of the same ABI revision (DC_LIB_PATH A/B builds!)
