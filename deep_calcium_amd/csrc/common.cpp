@@ -35,9 +35,12 @@ extern "C" int dc_event_create(void** ev) {
 extern "C" int dc_event_create_sync(void** ev) {
   DC_REQUIRE(ev, DC_EINVAL, "dc_event_create_sync: null");
   hipEvent_t e;
-  // (hipEventReleaseToDevice instead of the default system-scope release was measured to change nothing: 18.13-18.21 ms either
-  // way at 512^2 x 16, 3.07-3.13 at 128^2 x 20 -- the ~12 us the main queue loses at every hand-off are not the fence)
-  hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  // Same-device stream ordering only: the producing kernel's own agent-scope release publishes its stores to the consumer's queue, the
+  // marker's system-scope fence (for HOST visibility: nobody synchronises the host on these events) is skipped.  Measured
+  // (scripts/micro/handoff_flags.hip, profiles/r05_ab.txt item 11): 5.7 -> 3.4 us lost by the recording queue per hand-off, no stale
+  // element in 200 x 256 MB cross-queue hand-overs; hipEventReleaseToDevice alone changes nothing.  DC_EVENT_SYSTEM_FENCE=1 keeps the fence.
+  static const bool fence = [] { const char* v = getenv("DC_EVENT_SYSTEM_FENCE"); return v && v[0] == '1'; }();
+  hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming | (fence ? 0u : (unsigned)hipEventDisableSystemFence));
   DC_REQUIRE(rc == hipSuccess, DC_EHIP, "hipEventCreateWithFlags: %s", hipGetErrorString(rc));
   *ev = (void*)e;
   return DC_OK;

@@ -286,6 +286,7 @@ class UNetEngine(object):
         # measured SLOWER same box (17.651 -> 18.103 ms: the role-split kernel's producers become its longest role, as for DC_DZIN=all)
         self.dz_writeback = False
         self.deep_slots = False           # A/B (set before the first step): one backward buffer set per block instead of a rotation of 3
+        self.tail_main = os.environ.get('DC_TAIL_MAIN', '1') == '1'      # the step's last weight gradient on the main stream (A/B: 0)
         self.stats_per_wg = True          # BatchNorm partials: one row per (workgroup, consumer set) of the role-split kernel (A/B: False)
         self.use_tapes = os.environ.get('DC_TAPES', '1') != '0'
         self._tapes = {}
@@ -902,6 +903,10 @@ class UNetEngine(object):
         T['dz_coef'] = [torch.zeros(7 * cmax, dtype=torch.float32, device=dev) for _ in range(S)]   # dz-on-load tables
         T['red_tmp'] = torch.empty(32 * 1024, dtype=torch.float32, device=dev)
         T['wgrad_ws'] = torch.empty(ws_floats, dtype=torch.float32, device=dev)
+        # the first layer's weight gradient may run on the MAIN stream beside the side stream's last one (tail_on_main): its own slabs
+        l0 = self.layers[0]
+        T['wgrad_ws_main'] = torch.empty(max(L.dc_conv3x3_wgrad_ws_floats(N, self.H, self.W, l0.cin, l0.cout), 4), dtype=torch.float32,
+                                         device=dev)
         # the joint data- + weight-gradient kernel of the 32 -> 32 blocks runs on the MAIN stream: its own slab workspace
         # (the side stream's weight gradients share wgrad_ws)
         jws = max([L.dc_conv3x3_bwd_joint_ws_floats(N, *self._hw(l.lvl), l.cin, l.cout) for l in self.layers if l.kind == 'conv'] + [4])
@@ -1246,7 +1251,7 @@ class UNetEngine(object):
 
         main = torch.cuda.current_stream(self.device)
         side = self._side_stream if self.streams == 2 else main
-        two = side is not main
+        two = two_streams = side is not main
         mh, sh_ = main.cuda_stream, side.cuda_stream          # raw handles: the hand-offs below go through the C ABI (tape-able)
         if two:
             self._wait_stream(sh_, mh)    # everything queued so far (forward, head) precedes the first wgrad
@@ -1272,12 +1277,14 @@ class UNetEngine(object):
         def red_of(la):          # pass-1 sums out of the data gradient's epilogue: dense da of a dropout-free layer only
             return la if la.drop <= 0.0 else None
 
-        def block_bwd(l, x_in, da_ptr, da_ld, dx_ptr, prod=None, fused=None, red=None, da_g=None):
+        def block_bwd(l, x_in, da_ptr, da_ld, dx_ptr, prod=None, fused=None, red=None, da_g=None, on_main=False):
             """da (da_ld-strided) -> gradients of block l; dx (dense [.., cin]) written to dx_ptr unless None.  prod: the
             layer that produced x_in (its activation may be non-materialised: BN + ReLU on load).  fused: (partial, amax,
             rows) when the producer of da emitted the pass-1 sums.  red: the layer whose `da` dx is -- when the data
             gradient runs on the role-split kernel it emits that layer's sums; returned for that layer's `fused`.
-            da_g: index of the g buffer da lives in (None: a dcat buffer, written once per step)."""
+            da_g: index of the g buffer da lives in (None: a dcat buffer, written once per step).  on_main: the weight gradient
+            stays on the main stream (the step's last block: nothing is left to run beside it)."""
+            two = two_streams and not on_main
             bsrc = self._bnin_src(prod, T)
             h, w = self._hw(l.lvl)
             pixels = N * h * w
@@ -1286,7 +1293,7 @@ class UNetEngine(object):
             mean, invstd = self.stat_ptr(l, 0), self.stat_ptr(l, 1)
             gamma, beta = self.pview(self.pflat, l, 'gamma'), self.pview(self.pflat, l, 'beta')
             dgamma, dbeta = self.pview(self.gflat, l, 'gamma'), self.pview(self.gflat, l, 'beta')
-            dk, ws = self.pview(self.gflat, l, 'k'), _ptr(T['wgrad_ws'])
+            dk, ws = self.pview(self.gflat, l, 'k'), _ptr(T['wgrad_ws_main' if on_main else 'wgrad_ws'])
             dz_mode = self._dzin_ok(l, N) if da_ld == l.cout else 0
             if dz_mode == 2 and dx_ptr is None:
                 dz_mode = 0
@@ -1351,7 +1358,7 @@ class UNetEngine(object):
                                                   _ptr(T['dz'][k]) if dz_mode == 2 else None, *rargs, N, h, w, l.cin, l.cout, st)
                 if two:
                     self._wait_stream(sh_, mh)
-                sw = sh_
+                sw = st if on_main else sh_
                 if dz_mode == 2:
                     # the data gradient has written dz: plain weight gradient, its power-of-two scale from the table's bound row
                     dzp, scale = _ptr(T['dz'][k]), _ptr(T['dz_scale'], 4 * k)
@@ -1432,7 +1439,7 @@ class UNetEngine(object):
                 fused_next = dgrad()
             if two:
                 self._wait_stream(sh_, mh)
-            sw = sh_
+            sw = st if on_main else sh_
             if side_fin:
                 finalize(sw)
             if bsrc is not None and l.kind == 'conv':
@@ -1518,9 +1525,14 @@ class UNetEngine(object):
                            fused=fused_pool, red=red_of(la), da_g=ki)
             state['g'] = ko
             if lvl == 0:
-                if two and defer_tail and bucket_cb is None:
+                # the step's last block: its weight gradient stays on the main stream (which has nothing else left), beside the previous
+                # block's on the side stream -- one join, one Adam launch (same box: 3.019 -> 2.997 ms at 128^2 x 20, 3.197 -> 3.170 at
+                # 96^2 x 32, 17.62 -> 17.58 at 512^2 x 16).  DC_TAIL_MAIN=0: both on the side stream in sequence, Adam + re-pack of
+                # everything but the first layer underneath the last one (defer_tail).
+                tail_main = two and self.tail_main and bucket_cb is None
+                if two and defer_tail and bucket_cb is None and not tail_main:
                     self._tail = self._record(sh_)        # everything the side stream has been given so far
-                block_bwd(la, xp, _ptr(gb[ko]), c, None, fused=fa, da_g=ko)
+                block_bwd(la, xp, _ptr(gb[ko]), c, None, fused=fa, da_g=ko, on_main=tail_main)
             else:
                 kn = g_next()
                 block_bwd(la, _ptr(A['pool%d' % (lvl - 1)]), _ptr(gb[ko]), c, _ptr(gb[kn]), fused=fa, da_g=ko)

@@ -464,7 +464,8 @@ int dc_scale_flat(float* p, long n, float s, dc_stream_t stream);
  * these wrap hipEventCreate/Record/Synchronize/ElapsedTime on the given stream (so bench.py measures on the
  * stream the kernels are launched on). */
 int dc_event_create(void** ev);
-/* an event for stream ordering only (hipEventDisableTiming): what the engine's two-stream backward hands between its streams */
+/* an event for stream ordering on ONE device only (hipEventDisableTiming | hipEventDisableSystemFence): what the engine's two-stream
+ * backward hands between its streams.  Not for host synchronisation (no system-scope fence at the marker). */
 int dc_event_create_sync(void** ev);
 /* hipStreamWaitEvent(stream, ev): work queued on `stream` after this call waits for the work `ev` was last recorded behind */
 int dc_stream_wait_event(dc_stream_t stream, void* ev);
