@@ -706,14 +706,24 @@ static int convT_dgrad_h_launch(IgemmParams p, hipStream_t st, long* query = nul
 // kernels of 1e-4 would lose bits; the contraction kernels undo the scale exactly in their epilogue.
 // One job = DC_PACK_JOB_LONGS longs { src pointer, dst pointer, taps, K, Ncols, s_tap, s_k, s_n, flip, first block };
 // a trailing sentinel entry carries the grid size in its last field.  Three launches: zero the trailers' max slots,
-// max|src| per job (order-independent atomic max on the float bits), scale + split.
+// max|src| per job (order-independent atomic max on the float bits; consecutive jobs over one source share the sweep), scale + split.
 #define DC_PACK_JOB_LONGS 10
 struct PackJob {
   const float* src; _Float16* dst; int taps, K, Ncols, flip, b0, nb; long s_tap, s_k, s_n, total; float* trailer;
+  const long* next;   // batch: the job entries behind this one; `ndup` of them pack the SAME source (forward + data-gradient image of
+  int ndup, dup;      // one layer): their max slots are written here; dup: this job's source is the previous job's (max taken there)
 };
+__device__ __forceinline__ float* pack_trailer_of(const long* jb) {
+  return reinterpret_cast<float*>(reinterpret_cast<_Float16*>(jb[1]) + 2 * (jb[2] * ((jb[3] + 7) >> 3) * 8 * jb[4]));
+}
 __device__ __forceinline__ PackJob pack_job(const long* __restrict__ jobs, int njobs) {
-  int j = 0;
-  while (j + 1 < njobs && jobs[(j + 1) * DC_PACK_JOB_LONGS + 9] <= (long)blockIdx.x) ++j;
+  // which job is this block's: one table entry per thread (a serial walk over the 44 entries of the U-Net's table costs every block
+  // ~44 dependent loads: measured, the walk -- not the sweep -- was what these launches took)
+  __shared__ int sj;
+  for (int t = threadIdx.x; t < njobs; t += blockDim.x)
+    if (jobs[t * DC_PACK_JOB_LONGS + 9] <= (long)blockIdx.x && (long)blockIdx.x < jobs[(t + 1) * DC_PACK_JOB_LONGS + 9]) sj = t;
+  __syncthreads();
+  const int j = sj;
   const long* jb = jobs + (long)j * DC_PACK_JOB_LONGS;
   PackJob q;
   q.src = reinterpret_cast<const float*>(jb[0]);
@@ -723,19 +733,27 @@ __device__ __forceinline__ PackJob pack_job(const long* __restrict__ jobs, int n
   q.b0 = (int)jb[9]; q.nb = (int)jb[DC_PACK_JOB_LONGS + 9] - q.b0;
   q.total = (long)q.taps * ((q.K + 7) >> 3) * 8 * q.Ncols;
   q.trailer = reinterpret_cast<float*>(q.dst + 2 * q.total);
+  q.dup = j > 0 && jb[-DC_PACK_JOB_LONGS] == jb[0];
+  q.next = jb + DC_PACK_JOB_LONGS;
+  q.ndup = 0;
+  while (j + 1 + q.ndup < njobs && q.next[(long)q.ndup * DC_PACK_JOB_LONGS] == jb[0]) ++q.ndup;
   return q;
 }
-__device__ __forceinline__ float pack_src(const PackJob& q, long i, int& e, long& slot) {
-  const int K8 = (q.K + 7) >> 3;
-  e = (int)(i & 7);
-  long r = i >> 3;
-  const int n = (int)(r % q.Ncols); r /= q.Ncols;
-  const int k8 = (int)(r % K8);
-  const int tap = (int)(r / K8);
-  const int k = k8 * 8 + e;
-  const int ts = q.flip ? (q.taps - 1 - tap) : tap;
-  slot = ((long)(tap * K8 + k8) * 2) * q.Ncols + n;
-  return (k < q.K) ? q.src[ts * q.s_tap + k * q.s_k + n * q.s_n] : 0.f;
+// One 16-byte slot = 8 consecutive k of one (tap, n): one hi and one lo store.  32-bit index arithmetic (a job has at most
+// taps * K/8 * Ncols = 9 * 128 * 1024 slots).  A thread takes DC_PACK_UNROLL slots per round, all loads first: these launches are
+// short (15 M weights), what they cost is the dependent-load latency per block, not bandwidth.
+#define DC_PACK_UNROLL 4
+struct PackSlot { const float* base; _Float16* d; int kleft; };
+__device__ __forceinline__ PackSlot pack_slot_of(const PackJob& q, unsigned sidx) {
+  const unsigned K8 = (unsigned)(q.K + 7) >> 3, nc = (unsigned)q.Ncols;
+  const unsigned n = sidx % nc, r = sidx / nc;
+  const unsigned k8 = r % K8, tap = r / K8;
+  const unsigned ts = q.flip ? ((unsigned)q.taps - 1u - tap) : tap;
+  PackSlot s;
+  s.base = q.src + (long)ts * q.s_tap + (long)(k8 * 8u) * q.s_k + (long)n * q.s_n;
+  s.d = q.dst + ((long)(tap * K8 + k8) * 2 * nc + n) * 8;
+  s.kleft = q.K - (int)(k8 * 8u);
+  return s;
 }
 __global__ void pack_zero_kernel(const long* __restrict__ jobs, int njobs) {
   for (int j = threadIdx.x; j < njobs; j += blockDim.x) {
@@ -745,17 +763,29 @@ __global__ void pack_zero_kernel(const long* __restrict__ jobs, int njobs) {
   }
 }
 __device__ __forceinline__ void pack_absmax_body(const PackJob& q) {
-  // the source tensor is contiguous (taps * K * Ncols floats, K a multiple of 4): a linear float4 sweep
+  // the source tensor is contiguous (taps * K * Ncols floats, K a multiple of 4): a linear float4 sweep, one atomic per block
+  __shared__ float wmax[4];
   const long n4 = (long)q.taps * q.K * q.Ncols / 4;
   const f32x4* s4 = reinterpret_cast<const f32x4*>(q.src);
+  const long stride = (long)q.nb * blockDim.x;
   float m = 0.f;
-  for (long i = (blockIdx.x - q.b0) * (long)blockDim.x + threadIdx.x; i < n4; i += (long)q.nb * blockDim.x) {
-    const f32x4 v = s4[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  for (long i = (blockIdx.x - q.b0) * (long)blockDim.x + threadIdx.x; i < n4; i += DC_PACK_UNROLL * stride) {
+    f32x4 v[DC_PACK_UNROLL];
+#pragma unroll
+    for (int u = 0; u < DC_PACK_UNROLL; ++u) v[u] = (i + u * stride < n4) ? s4[i + u * stride] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < DC_PACK_UNROLL; ++u)
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u][0]), fabsf(v[u][1]))), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) dc_atomic_absmax(q.trailer + 1, m);
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    dc_atomic_absmax(q.trailer + 1, m);
+    for (int d = 0; d < q.ndup; ++d) dc_atomic_absmax(pack_trailer_of(q.next + (long)d * DC_PACK_JOB_LONGS) + 1, m);
+  }
 }
 __device__ __forceinline__ void pack_split_body(const PackJob& q) {
   const float amax = q.trailer[1];
@@ -763,17 +793,37 @@ __device__ __forceinline__ void pack_split_body(const PackJob& q) {
   // 2^(10 - floor(log2 amax)); all-zero / denormal / non-finite kernels stay unscaled
   const float ws = (amax > 0.f && ex >= 14u && ex != 0xffu) ? __builtin_bit_cast(float, (264u - ex) << 23) : 1.f;
   if (blockIdx.x == (unsigned)q.b0 && threadIdx.x == 0) q.trailer[0] = ws;
-  for (long i = (blockIdx.x - q.b0) * (long)blockDim.x + threadIdx.x; i < q.total; i += (long)q.nb * blockDim.x) {
-    int e; long slot;
-    const float x = pack_src(q, i, e, slot) * ws;
-    const _Float16 hi = (_Float16)x;
-    const _Float16 lo = (_Float16)(x - (float)hi);
-    q.dst[slot * 8 + e] = hi;
-    q.dst[(slot + q.Ncols) * 8 + e] = lo;
+  const unsigned slots = (unsigned)(q.total >> 3), stride = (unsigned)q.nb * blockDim.x;
+  for (unsigned i = (blockIdx.x - q.b0) * blockDim.x + threadIdx.x; i < slots; i += DC_PACK_UNROLL * stride) {
+    PackSlot sl[DC_PACK_UNROLL];
+    float x[DC_PACK_UNROLL][8];
+#pragma unroll
+    for (int u = 0; u < DC_PACK_UNROLL; ++u) {
+      const bool on = i + u * stride < slots;
+      sl[u] = pack_slot_of(q, on ? i + u * stride : i);
+      if (!on) sl[u].kleft = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[u][e] = (e < sl[u].kleft) ? sl[u].base[e * q.s_k] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < DC_PACK_UNROLL; ++u) {
+      if (i + u * stride >= slots) break;
+      f16x8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xs = x[u][e] * ws;
+        const _Float16 h = (_Float16)xs;
+        hi[e] = h;
+        lo[e] = (_Float16)(xs - (float)h);
+      }
+      *reinterpret_cast<f16x8*>(sl[u].d) = hi;
+      *reinterpret_cast<f16x8*>(sl[u].d + (long)q.Ncols * 8) = lo;
+    }
   }
 }
 __global__ __launch_bounds__(256) void pack_absmax_kernel(const long* __restrict__ jobs, int njobs) {
-  pack_absmax_body(pack_job(jobs, njobs));
+  const PackJob q = pack_job(jobs, njobs);
+  if (!q.dup) pack_absmax_body(q);
 }
 __global__ __launch_bounds__(256) void pack_weights_f16x3_batch_kernel(const long* __restrict__ jobs, int njobs) {
   pack_split_body(pack_job(jobs, njobs));
@@ -790,6 +840,7 @@ extern "C" int dc_pack_weights_f16x3(const float* src, void* dst, int taps, int 
   q.s_tap = s_tap; q.s_k = s_k; q.s_n = s_n;
   q.total = (long)taps * ((K + 7) / 8) * 8 * Ncols;
   q.trailer = reinterpret_cast<float*>(q.dst + 2 * q.total);
+  q.next = nullptr; q.ndup = 0; q.dup = 0;
   q.b0 = 0;
   q.nb = (int)((q.total + 255) / 256 > 4096 ? 4096 : (q.total + 255) / 256);
   hipStream_t st = (hipStream_t)stream;

@@ -516,7 +516,7 @@ class UNetEngine(object):
                 for j in jobs:
                     total = j[2] * ((j[3] + 7) // 8) * 8 * j[4]
                     rows.append(list(j) + [b])
-                    b += max(1, min((total + 255) // 256, 128))
+                    b += max(1, min((total // 8 + 1023) // 1024, 2048))   # a thread packs 4 of the image's 16-byte slots
                 rows.append([0] * 9 + [b])
                 self._pack_jobs = (torch.tensor(rows, dtype=torch.int64, device=self.device), len(jobs), b)
             tab, n, blocks = self._pack_jobs

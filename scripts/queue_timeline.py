@@ -39,3 +39,16 @@ for r in step:
     print('%s %9.1f  dur %7.1f  gap %7.1f  %s' % ('M' if q == main_q else '  s', (r['s'] - t0) / 1e3, (r['e'] - r['s']) / 1e3, gap, r['k'][:70]))
 for q, d in tot.items():
     print('queue %s%s: %d launches, busy %.1f us, gaps %.1f us' % (q, ' (main)' if q == main_q else '', d[0], d[1], d[2]))
+
+if len(sys.argv) > 3 and sys.argv[3] == 'all':
+    # every step of the trace: span, main-queue idle time, largest main-queue gap
+    print('\nstep  span us  main idle us  largest main gap')
+    for kk in range(1, len(heads) - 1):
+        try:
+            pa = max(i for i in range(heads[kk - 1], heads[kk]) if rows[i]['k'].startswith('adam_kernel'))
+            la = max(i for i in range(heads[kk], heads[kk + 1]) if rows[i]['k'].startswith('adam_kernel'))
+        except ValueError:
+            continue
+        st = [r for r in rows[pa + 1:la + 1] if r['Queue_Id'] == main_q]
+        gaps = [(st[i + 1]['s'] - st[i]['e']) / 1e3 for i in range(len(st) - 1)]
+        print('%4d  %7.1f  %7.1f  %7.1f' % (kk, (rows[la]['e'] - rows[pa]['e']) / 1e3, sum(g for g in gaps if g > 0), max(gaps)))

@@ -1093,3 +1093,66 @@ def test_convT_dgrad_with_fused_bn_backward_sums(dclib, N, H, W, Ci, Co):
     tol = 2e-5 * max(np.abs(ref_dg).max(), np.abs(ref_db).max())
     assert np.abs(dg.cpu().numpy() - ref_dg).max() < tol and np.abs(db.cpu().numpy() - ref_db).max() < tol
     assert np.array_equal(amx.cpu().numpy().reshape(rows, Ci).max(0), np.abs(dy).max(0).astype(np.float32))
+
+
+def _pack_ref(src, taps, K, Ncols, s_tap, s_k, s_n, flip):
+    """numpy restatement of the split-fp16 weight image (csrc/igemm_f16x3.hip): [tap][K/8][hi|lo][n][8 halfs] of
+    w_scale * src[(flip ? taps-1-tap : tap)*s_tap + k*s_k + n*s_n], w_scale = 2^(10 - floor(log2 max|src|)); trailer {w_scale, max|src|}."""
+    flat = np.asarray(src, np.float32).ravel()
+    amax = np.float32(np.abs(flat).max())
+    ws = np.float32(2.0 ** (10 - int(np.floor(np.log2(amax))))) if amax > 0 else np.float32(1.0)
+    K8 = (K + 7) // 8
+    img = np.zeros((taps, K8, 2, Ncols, 8), np.float16)
+    for tap in range(taps):
+        ts = taps - 1 - tap if flip else tap
+        for k in range(K):
+            x = flat[ts * s_tap + k * s_k + np.arange(Ncols) * s_n] * ws
+            hi = x.astype(np.float16)
+            img[tap, k // 8, 0, :, k % 8] = hi
+            img[tap, k // 8, 1, :, k % 8] = (x - hi.astype(np.float32)).astype(np.float16)
+    return img.ravel(), ws, amax
+
+
+def test_pack_weights_f16x3_image_single_and_batched(dclib):
+    """The split-fp16 weight image bit for bit against its numpy restatement -- the single-job entry point and the batched one (whose
+    consecutive jobs over ONE source share the max|src| sweep): forward + data-gradient (flipped, transposed) images of a 3x3 layer, K
+    not a multiple of 8, a conv-transpose pair, and a lone job behind them."""
+    L = dclib
+    rs = np.random.RandomState(5)
+    jobs, srcs = [], []
+
+    def layer(kh, ci, co, scale):
+        w = dev((rs.standard_normal((kh * kh, ci, co)) * scale).astype(np.float32))
+        srcs.append(w)
+        return w
+
+    w1 = layer(3, 12, 40, 0.02)                    # K = 12: half-filled last slot in the forward image
+    jobs.append((w1, 9, 12, 40, 12 * 40, 40, 1, 0))
+    jobs.append((w1, 9, 40, 12, 12 * 40, 1, 40, 1))
+    w2 = layer(2, 16, 8, 3e-4)                     # conv-transpose (2,2,Cout,Cin) = [tap][co=16][ci=8] here: forward [1][ci][4 co], dgrad [4][co][ci]
+    jobs.append((w2, 1, 8, 4 * 16, 0, 1, 8, 0))
+    jobs.append((w2, 4, 16, 8, 16 * 8, 8, 1, 0))
+    w3 = layer(3, 32, 32, 5.0)
+    jobs.append((w3, 9, 32, 32, 32 * 32, 32, 1, 0))
+    single, batched, rows, b = [], [], [], 0
+    for (w, taps, K, nc, st, sk, sn, flip) in jobs:
+        n = L.dc_pack_weights_f16x3_floats(taps, K, nc)
+        d1 = torch.zeros(n, dtype=torch.float32, device='cuda')
+        d2 = torch.zeros(n, dtype=torch.float32, device='cuda')
+        L.dc_pack_weights_f16x3(w.data_ptr(), d1.data_ptr(), taps, K, nc, st, sk, sn, flip, None)
+        single.append(d1)
+        batched.append(d2)
+        total = taps * ((K + 7) // 8) * 8 * nc
+        rows.append([w.data_ptr(), d2.data_ptr(), taps, K, nc, st, sk, sn, flip, b])
+        b += max(1, min((total // 8 + 1023) // 1024, 2048))
+    rows.append([0] * 9 + [b])
+    tab = torch.tensor(rows, dtype=torch.int64, device='cuda')
+    L.dc_pack_weights_f16x3_batch(tab.data_ptr(), len(jobs), b, None)
+    torch.cuda.synchronize()
+    for (w, taps, K, nc, st, sk, sn, flip), d1, d2 in zip(jobs, single, batched):
+        ref, ws, amax = _pack_ref(w.cpu().numpy(), taps, K, nc, st, sk, sn, flip)
+        for d in (d1, d2):
+            raw = d.cpu().numpy()
+            img = raw[:-4].view(np.float16)
+            assert np.array_equal(img.view(np.uint16), ref.view(np.uint16))
+            assert raw[-4] == ws and raw[-3] == amax
