@@ -113,6 +113,38 @@ extern "C" int dc_bn_stats_finalize_affine(const double* partial, int parts, int
   return DC_OK;
 }
 
+// ---- partial rows folded parts -> chunks, in a fixed order.  The finalize launches above read one 16-byte piece per (row, channel),
+// 16 * groups * C bytes apart: with the 16 384 tile rows of a 512^2 up-convolution that is 77 us of quarter-used sectors on the
+// step's critical path.  Here a block reads WHOLE rows (coalesced) of its chunk of rows; the finalize then reads `chunks` rows.
+__global__ __launch_bounds__(256) void bn_stats_rows_fold_kernel(const double* __restrict__ partial, int parts, int width,
+                                                                int chunks, double* __restrict__ out) {
+  const int b = blockIdx.x, col = blockIdx.y * 256 + threadIdx.x;
+  if (col >= width) return;
+  const int r0 = (int)((long)parts * b / chunks), r1 = (int)((long)parts * (b + 1) / chunks);
+  const double* src = partial + (long)r0 * width + col;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int r = r0;
+  for (; r + 4 <= r1; r += 4, src += 4L * width) {
+    s0 += src[0];
+    s1 += src[width];
+    s2 += src[2L * width];
+    s3 += src[3L * width];
+  }
+  for (; r < r1; ++r, src += width) s0 += src[0];
+  out[(long)b * width + col] = (s0 + s1) + (s2 + s3);
+}
+extern "C" int dc_bn_stats_rows_fold(const double* partial, int parts, int groups, int C, int chunks, double* out,
+                                     dc_stream_t stream) {
+  DC_REQUIRE(partial && out && partial != out, DC_EINVAL, "dc_bn_stats_rows_fold: null or aliased pointer");
+  DC_REQUIRE(parts > 0 && groups > 0 && C > 0 && chunks > 0 && chunks <= parts, DC_EINVAL,
+             "dc_bn_stats_rows_fold: bad sizes (parts %d, groups %d, C %d, chunks %d)", parts, groups, C, chunks);
+  const int width = groups * C * 2;
+  hipLaunchKernelGGL(bn_stats_rows_fold_kernel, dim3(chunks, dc_cdiv(width, 256)), dim3(256), 0, (hipStream_t)stream, partial,
+                     parts, width, chunks, out);
+  DC_CHECK_LAUNCH("dc_bn_stats_rows_fold");
+  return DC_OK;
+}
+
 // ---- synchronised BatchNorm (data-parallel 'sync' mode): the per-channel sums leave the device-local finalize so that
 // they can be all-reduced over the ranks: reduce (partials -> double sums) | all-reduce | finalize from sums.
 __global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const double* __restrict__ partial, int parts, int groups,

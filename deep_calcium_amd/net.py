@@ -161,6 +161,12 @@ class UNetEngine(object):
     # not the waits (the event RECORD on the main queue in front of them stays), and 34 GB more footprint costs more than it saves.
     # Off by default (`deep_slots`); falls back to 3 anyway when it would exceed SLOTS_DEEP_MAX_BYTES.
     SLOTS = 3
+    # BatchNorm partial rows: launches that leave >= FOLD_MIN rows (one per pixel tile: the 512^2-class layers outside the role-split
+    # kernel, the up-convolutions) fold them to FOLD_ROWS with coalesced whole-row reads first; the finalize's own reads are 16-byte
+    # pieces one row apart (77 us for the 16 384 x 4 rows of u0 at 512^2 x 16, on the critical path).  Same box: 17.77 -> 17.67 ms at
+    # 512^2 x 16 (0 = never: A/B); the 128^2 / 96^2 steps stay below the threshold (an extra launch costs them 0.2 %).
+    FOLD_MIN = int(os.environ.get('DC_STATS_FOLD_MIN', '8192'))
+    FOLD_ROWS = 128
     SLOTS_DEEP = 32
     SLOTS_DEEP_MAX_BYTES = 48 << 30
 
@@ -883,6 +889,8 @@ class UNetEngine(object):
                 sk = max(sk, L.dc_convT2x2_dgrad_splitk_ws_floats(N, h // 2, w // 2, l.cin, l.cout))
         T['splitk_ws'] = torch.empty(sk, dtype=torch.float32, device=dev)
         T['stats_ws'] = torch.empty(stats_floats, dtype=torch.float64, device=dev)      # (sum, sum of squares) partials
+        # partial rows folded to FOLD_ROWS before the finalize where a launch leaves thousands of them (dc_bn_stats_rows_fold)
+        T['stats_fold'] = torch.empty(self.FOLD_ROWS * 4 * max(l.cout for l in self.layers) * 2, dtype=torch.float64, device=dev)
         T['part_ws'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         T['part_ws2'] = torch.empty(part_floats, dtype=torch.float32, device=dev)
         # per-(row, channel) max |dy| next to the pass-1 sums of the same producer (dc_bn_bwd_finalize_dzin)
@@ -1081,6 +1089,10 @@ class UNetEngine(object):
                 self._convT_fwd(xin, l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h // 2, w // 2, st, bnin=bn)
             pixels = N * h * w
             mom = l.mom if update_moving else -1.0
+            if self.FOLD_MIN > 0 and tiles * groups >= self.FOLD_MIN and tiles > self.FOLD_ROWS:
+                fold = T['stats_fold'].data_ptr()
+                L.dc_bn_stats_rows_fold(stats, tiles, groups, l.cout, self.FOLD_ROWS, fold, st)
+                stats, tiles = fold, self.FOLD_ROWS
             if sync:
                 # 'sync' BatchNorm: per-channel (sum, sum of squares) -> all-reduce over the ranks -> statistics
                 bs = T['bn_sums'][:2 * l.cout]

@@ -36,7 +36,7 @@ typedef void* dc_stream_t;
 
 /* ABI revision: dc_version() of the loaded library must EQUAL the DC_ABI_VERSION of the header the caller was built /
  * bound against (argument lists change between revisions; the Python binding refuses a mismatch). */
-#define DC_ABI_VERSION 105
+#define DC_ABI_VERSION 106
 int dc_version(void);
 const char* dc_last_error(void);
 
@@ -345,6 +345,10 @@ int dc_conv3x3_bwd_joint_f16x3(const float* x, const float* in_scale, const floa
  *   backward: dc_bn_bwd_finalize | all-reduce(sum) of (dgamma, dbeta) | dc_bn_bwd_apply_count with the same count.
  * With one rank (or count == pixels) the results equal the local entry points'. */
 int dc_bn_stats_reduce(const double* partial, int parts, int groups, int C, double* sums, dc_stream_t stream);
+/* partial rows folded parts -> chunks (fixed order, whole rows read coalesced): out = double[chunks][groups * C][2], same layout
+ * as `partial`; dc_bn_stats_finalize* / dc_bn_stats_reduce then take (out, chunks, groups).  For launches with thousands of tile
+ * rows (the 512^2-class layers), where the finalize's strided 16-byte reads cost more than this extra launch. */
+int dc_bn_stats_rows_fold(const double* partial, int parts, int groups, int C, int chunks, double* out, dc_stream_t stream);
 int dc_bn_stats_finalize_sums(const double* sums, int C, double count, float eps, float momentum, float* mean,
                               float* invstd, float* moving_mean, float* moving_var, const float* gamma,
                               const float* beta, float* scale, float* shift, float* abound, dc_stream_t stream);

@@ -1156,3 +1156,32 @@ def test_pack_weights_f16x3_image_single_and_batched(dclib):
             img = raw[:-4].view(np.float16)
             assert np.array_equal(img.view(np.uint16), ref.view(np.uint16))
             assert raw[-4] == ws and raw[-3] == amax
+
+
+@pytest.mark.parametrize('parts,groups,C,chunks', [(1000, 1, 32, 128), (4097, 4, 32, 128), (130, 4, 512, 128), (16384, 4, 32, 128)])
+def test_bn_stats_rows_fold(dclib, parts, groups, C, chunks):
+    """dc_bn_stats_rows_fold: chunk b holds the sum of rows [parts*b/chunks, parts*(b+1)/chunks) (float64, to rounding), and the
+    finalize over the folded rows gives the statistics of the finalize over all of them."""
+    L = dclib
+    rs = np.random.RandomState(parts + C)
+    part = rs.standard_normal((parts, groups * C, 2))
+    part[..., 1] = np.abs(part[..., 1]) * 3 + 2.0           # sums of squares: keep the variance positive
+    p_d = dev(part)
+    out = torch.zeros(chunks * groups * C * 2, dtype=torch.float64, device='cuda')
+    L.dc_bn_stats_rows_fold(p_d.data_ptr(), parts, groups, C, chunks, out.data_ptr(), None)
+    got = out.cpu().numpy().reshape(chunks, groups * C, 2)
+    for b in (0, 1, chunks // 2, chunks - 1):
+        r0, r1 = parts * b // chunks, parts * (b + 1) // chunks
+        ref = part[r0:r1].sum(axis=0)
+        assert np.allclose(got[b], ref, rtol=1e-12, atol=1e-11)
+    assert np.allclose(got.sum(axis=0), part.sum(axis=0), rtol=1e-12, atol=1e-10)
+    count = float(parts * groups * 7)
+    res = []
+    for src, n in ((p_d, parts), (out, chunks)):
+        mean = torch.zeros(C, device='cuda')
+        inv = torch.zeros(C, device='cuda')
+        L.dc_bn_stats_finalize(src.data_ptr(), n, groups, C, count, 1e-3, -1.0, mean.data_ptr(), inv.data_ptr(), None, None, None)
+        res.append((mean.cpu().numpy(), inv.cpu().numpy()))
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-6, atol=1e-9) and np.allclose(res[0][1], res[1][1], rtol=1e-6)
+    with pytest.raises(Exception):
+        L.dc_bn_stats_rows_fold(p_d.data_ptr(), parts, groups, C, parts + 1, out.data_ptr(), None)

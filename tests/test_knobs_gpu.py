@@ -14,7 +14,7 @@ torch = pytest.importorskip('torch')
 HERE = os.path.dirname(os.path.abspath(__file__))
 SWITCHES = [('DC_MFMA', 'f32'), ('DC_STREAMS', '1'), ('DC_IGEMM_PP', '0'), ('DC_IGEMM_PP', '2'), ('DC_BNIN', '0'), ('DC_DZIN', '0'),
             ('DC_DZIN', 'all'), ('DC_BN_MODE', 'sync'), ('DC_INFER_GUARD', '1'), ('DC_AR_BUCKETS', '1'), ('DC_TAPES', '0'), ('DC_EVENT_SYSTEM_FENCE', '1'),
-            ('DC_TAIL_MAIN', '0')]
+            ('DC_TAIL_MAIN', '0'), ('DC_STATS_FOLD_MIN', '0'), ('DC_STATS_FOLD_MIN', '4')]
 
 
 @pytest.mark.parametrize('name,value', SWITCHES, ids=['%s=%s' % s for s in SWITCHES])
