@@ -1089,10 +1089,10 @@ class UNetEngine(object):
                 self._convT_fwd(xin, l, bias, _ptr(z), l.cout, stats, None, None, 0, N, h // 2, w // 2, st, bnin=bn)
             pixels = N * h * w
             mom = l.mom if update_moving else -1.0
-            if self.FOLD_MIN > 0 and tiles * groups >= self.FOLD_MIN and tiles > self.FOLD_ROWS:
-                fold = T['stats_fold'].data_ptr()
-                L.dc_bn_stats_rows_fold(stats, tiles, groups, l.cout, self.FOLD_ROWS, fold, st)
-                stats, tiles = fold, self.FOLD_ROWS
+            if self.FOLD_MIN > 0 and tiles * groups >= self.FOLD_MIN and tiles >= 2:
+                fold, chunks = T['stats_fold'].data_ptr(), min(self.FOLD_ROWS, tiles // 2)
+                L.dc_bn_stats_rows_fold(stats, tiles, groups, l.cout, chunks, fold, st)
+                stats, tiles = fold, chunks
             if sync:
                 # 'sync' BatchNorm: per-channel (sum, sum of squares) -> all-reduce over the ranks -> statistics
                 bs = T['bn_sums'][:2 * l.cout]
