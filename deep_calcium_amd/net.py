@@ -1316,7 +1316,7 @@ class UNetEngine(object):
                 L.dc_bn_bwd_reduce(da_ptr, da_ld, _ptr(z), mean, invstd, gamma, beta, mptr, keep, seed,
                                    _ptr(T['part_ws']), _ptr(T['amax_ws']) if dzin else None, pixels, l.cout, st)
                 fused = (_ptr(T['part_ws']), _ptr(T['amax_ws']), L.dc_bn_bwd_blocks(pixels, l.cout))
-            if two and slot_free[k] is not None:
+            if two_streams and slot_free[k] is not None:   # (also when THIS block's weight gradient stays on the main stream)
                 self._wait(mh, slot_free[k])        # the weight gradient that last read this slot has finished
                 slot_free[k] = None
             count = float((world if sync else 1) * pixels)
