@@ -65,6 +65,34 @@ def test_taped_training_is_bit_identical_to_launch_by_launch(hw, nfb, B):
             assert np.array_equal(u, v), name
 
 
+@pytest.mark.parametrize('hw,nfb,B', [(32, 8, 6), (128, 32, 20)])
+def test_last_weight_gradient_on_the_main_stream_is_the_same_step(hw, nfb, B):
+    """DC_TAIL_MAIN (the first layer's weight gradient on the main stream beside the previous block's on the side stream, own slab
+    workspace, one Adam launch) against the side-stream tail with the deferred Adam: 12 seeded steps with RNG dropout, parameters and
+    Adam state bit for bit after every step, with the weight-gradient stream of one run held back by unrelated work.  (The block on the
+    main stream still has to wait for the weight gradient that last read its dz slot: that race, when it existed, needed two ranks
+    contending for one GPU to show -- tests/test_dp_gpu.py's bitwise bucket comparison caught it, this single-process run did not.)"""
+    a, b = _pair(hw, nfb)
+    b.engine.use_tapes = True
+    a.engine.tail_main, b.engine.tail_main = True, False
+    data = _batches(2, B, hw, 11)
+    junk = torch.randn(2048, 2048, device='cuda') * 0.01
+    for step in range(12):
+        x, y = data[step % 2]
+        if step >= 3:
+            # the weight-gradient stream of `a` is held back by a few ms of unrelated work: the main stream runs through the whole
+            # backward ahead of it, every buffer hand-back (slot_free / g_free events) is now load-bearing
+            with torch.cuda.stream(a.engine._side_stream):
+                t = junk
+                for _ in range(6):
+                    t = (t @ junk) * 0.01
+        va, vb = a.train_on_device_batch(x, y), b.train_on_device_batch(x, y)
+        assert va == vb, step
+        assert torch.equal(a.engine.gflat, b.engine.gflat), step
+    torch.cuda.synchronize()
+    assert torch.equal(a.engine.pflat, b.engine.pflat) and torch.equal(a.engine.mflat, b.engine.mflat) and torch.equal(a.engine.vflat, b.engine.vflat)
+
+
 def test_tape_failure_names_the_operation(dclib):
     """A replayed operation goes through its entry point's own checks: the failing one is named, its message kept."""
     from deep_calcium_amd._lib import Tape, DcunetError
