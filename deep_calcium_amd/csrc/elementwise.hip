@@ -975,13 +975,21 @@ extern "C" int dc_upsample2x_drop_bwd(const float* dout, long dout_ld, const uin
 #define DC_HEAD_SUMS 12   // bce, tp, sum round(p), fn, sum y, sum y*p, sum p^2, sum y^2, sum p, weighted-bce, 2 spare
 __device__ __forceinline__ float round_half_even(float x) { return rintf(x); }  // default RN mode = half to even
 
+
+// One pixel's contribution of a lane's 4 channels to a logit: an EXPLICIT fma chain, so that every head kernel (inference forward,
+// training forward, fused forward + backward in both instantiations) rounds it identically whatever the compiler would contract.
+__device__ __forceinline__ float head_dot4(const f32x4& v, const float (&k)[4]) {
+  return __builtin_fmaf(v[3], k[3], __builtin_fmaf(v[2], k[2], __builtin_fmaf(v[1], k[1], v[0] * k[0])));
+}
+// C4T = 8 (C == 32): the 8 loads of a lane's pixel group are issued together (see head_fwd_bwd_kernel); 0 = generic.
+template <int C4T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ a, const float* __restrict__ kh,
                                                       const float* __restrict__ bh, const uint8_t* __restrict__ y,
                                                       float* __restrict__ p, float* __restrict__ partial, long pixels,
                                                       int C, const float* __restrict__ in_sc,
                                                       const float* __restrict__ in_sh) {
   __shared__ float sm[256][DC_HEAD_SUMS];
-  const int C4 = C >> 2, PPB = 256 / C4;
+  const int C4 = C4T ? C4T : (C >> 2), PPB = 256 / C4;
   const int tid = threadIdx.x, q = tid % C4, pl = tid / C4;
   float k0[4], k1[4];
 #pragma unroll
@@ -1001,19 +1009,40 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   for (long it0 = 0; it0 < iters; it0 += C4) {  // uniform trip counts: the shuffles below need every lane
     float kz0 = 0.f, kz1 = 0.f;
     long kpix = pixels;                           // "no pixel"
-    for (int j = 0; j < C4; ++j) {
-      const long pix = ((it0 + j) * gridDim.x + blockIdx.x) * PPB + pl;
-      const bool ok = pix < pixels;
-      f32x4 v = ok ? ld4(a + pix * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    auto one = [&](int j, long pix, bool ok, f32x4 v) {
       if (bnin) {
         v = fma4(v, isc, ish);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ok ? fmaxf(v[e], 0.f) : 0.f;
       }
-      float z0 = v[0] * k0[0] + v[1] * k0[1] + v[2] * k0[2] + v[3] * k0[3];
-      float z1 = v[0] * k1[0] + v[1] * k1[1] + v[2] * k1[2] + v[3] * k1[3];
-      for (int s = 1; s < C4; s <<= 1) { z0 += __shfl_xor(z0, s); z1 += __shfl_xor(z1, s); }
+      float z0 = head_dot4(v, k0);
+      float z1 = head_dot4(v, k1);
+      if constexpr (C4T != 0) {
+#pragma unroll
+        for (int s = 1; s < C4T; s <<= 1) { z0 += __shfl_xor(z0, s); z1 += __shfl_xor(z1, s); }
+      } else {
+        for (int s = 1; s < C4; s <<= 1) { z0 += __shfl_xor(z0, s); z1 += __shfl_xor(z1, s); }
+      }
       if (j == q) { kz0 = z0; kz1 = z1; kpix = pix; }
+    };
+    if constexpr (C4T != 0) {
+      f32x4 held[C4T];
+#pragma unroll
+      for (int j = 0; j < C4T; ++j) {
+        const long pix = ((it0 + j) * gridDim.x + blockIdx.x) * PPB + pl;
+        held[j] = pix < pixels ? ld4(a + pix * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < C4T; ++j) {
+        const long pix = ((it0 + j) * gridDim.x + blockIdx.x) * PPB + pl;
+        one(j, pix, pix < pixels, held[j]);
+      }
+    } else {
+      for (int j = 0; j < C4; ++j) {
+        const long pix = ((it0 + j) * gridDim.x + blockIdx.x) * PPB + pl;
+        const bool ok = pix < pixels;
+        one(j, pix, ok, ok ? ld4(a + pix * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f});
+      }
     }
     if (kpix < pixels) {
       const long pix = kpix;
@@ -1172,6 +1201,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 // weight-gradient partials and (bn_partial) the producing BatchNorm layer's backward sums, as head_bwd_kernel does.
 // One read of the 512^2 x nfb tensor instead of two, no read of p.  Per-block summation order differs from
 // head_bwd_kernel's (same terms).
+// C4T = 8 (C == 32, the network's nfb): the 8 loads of a lane's pixel group are issued TOGETHER and held in registers for the backward
+// half.  The generic loop issues one load per iteration and waits for it (the shuffle reductions in between keep the compiler from
+// hoisting the next one): 16 groups x 8 dependent loads per lane made the kernel latency-bound at 285-300 us for a 200-us sweep.
+template <int C4T>
 __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restrict__ a, const float* __restrict__ kh,
                                                           const float* __restrict__ bh, const uint8_t* __restrict__ y,
                                                           float* __restrict__ p, float* __restrict__ partial,
@@ -1183,7 +1216,7 @@ __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restri
   __shared__ float sm[256][DC_HEAD_SUMS];
   __shared__ f32x4 sm4[256], sm4b[256];
   __shared__ float sms[256];
-  const int C4 = C >> 2, PPB = 256 / C4;
+  const int C4 = C4T ? C4T : (C >> 2), PPB = 256 / C4;
   const int tid = threadIdx.x, q = tid % C4, pl = tid / C4, lane = tid & 63;
   float k0[4], k1[4];
   f32x4 kd;
@@ -1205,19 +1238,40 @@ __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restri
   for (long it0 = 0; it0 < iters; it0 += C4) {
     float kz0 = 0.f, kz1 = 0.f;
     long kpix = pixels;
-    for (int j = 0; j < C4; ++j) {
-      const long pix = ((it0 + j) * gridDim.x + blockIdx.x) * PPB + pl;
-      const bool ok = pix < pixels;
-      f32x4 v = ok ? ld4(a + pix * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 held[C4T ? C4T : 1];
+    auto fwd_one = [&](int j, long pix, bool ok, f32x4 v) {
       if (bnin) {
         v = fma4(v, isc, ish);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ok ? fmaxf(v[e], 0.f) : 0.f;
       }
-      float z0 = v[0] * k0[0] + v[1] * k0[1] + v[2] * k0[2] + v[3] * k0[3];
-      float z1 = v[0] * k1[0] + v[1] * k1[1] + v[2] * k1[2] + v[3] * k1[3];
-      for (int s = 1; s < C4; s <<= 1) { z0 += __shfl_xor(z0, s); z1 += __shfl_xor(z1, s); }
+      float z0 = head_dot4(v, k0);
+      float z1 = head_dot4(v, k1);
+      if constexpr (C4T != 0) {
+#pragma unroll
+        for (int s = 1; s < C4T; s <<= 1) { z0 += __shfl_xor(z0, s); z1 += __shfl_xor(z1, s); }
+      } else {
+        for (int s = 1; s < C4; s <<= 1) { z0 += __shfl_xor(z0, s); z1 += __shfl_xor(z1, s); }
+      }
       if (j == q) { kz0 = z0; kz1 = z1; kpix = pix; }
+    };
+    if constexpr (C4T != 0) {
+#pragma unroll
+      for (int j = 0; j < C4T; ++j) {
+        const long pix = ((it0 + j) * gridDim.x + blockIdx.x) * PPB + pl;
+        held[j] = pix < pixels ? ld4(a + pix * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < C4T; ++j) {
+        const long pix = ((it0 + j) * gridDim.x + blockIdx.x) * PPB + pl;
+        fwd_one(j, pix, pix < pixels, held[j]);
+      }
+    } else {
+      for (int j = 0; j < C4; ++j) {
+        const long pix = ((it0 + j) * gridDim.x + blockIdx.x) * PPB + pl;
+        const bool ok = pix < pixels;
+        fwd_one(j, pix, ok, ok ? ld4(a + pix * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f});
+      }
     }
     float sown = 0.f;                              // dL/dlogit1 of this lane's pixel
     if (kpix < pixels) {
@@ -1250,12 +1304,10 @@ __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restri
       }
       smax = fmaxf(smax, fabsf(sown));
     }
-    // backward of the C4 pixels of this group (their values are re-read: they were loaded a moment ago)
-    for (int j = 0; j < C4; ++j) {
+    // backward of the C4 pixels of this group
+    auto bwd_one = [&](int j, f32x4 v, long pix) {
       const float s = __shfl(sown, lane - q + j);
-      const long pix = ((it0 + j) * gridDim.x + blockIdx.x) * PPB + pl;
       if (pix < pixels) {
-        f32x4 v = ld4(a + pix * C + 4 * q);
         if (bnin) {
           const f32x4 zraw = v;
           v = fma4(v, isc, ish);
@@ -1274,6 +1326,16 @@ __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restri
         st4(da + pix * C + 4 * q, kd * s);
         sa += v * s;
         if (q == 0) ss += s;
+      }
+    };
+    if constexpr (C4T != 0) {
+#pragma unroll
+      for (int j = 0; j < C4T; ++j) bwd_one(j, held[j], ((it0 + j) * gridDim.x + blockIdx.x) * PPB + pl);
+    } else {
+      // (the values are re-read: they were loaded a moment ago)
+      for (int j = 0; j < C4; ++j) {
+        const long pix = ((it0 + j) * gridDim.x + blockIdx.x) * PPB + pl;
+        bwd_one(j, pix < pixels ? ld4(a + pix * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f}, pix);
       }
     }
   }
@@ -1368,7 +1430,7 @@ static int head_fwd_impl(const float* a, const float* in_sc, const float* in_sh,
   int rc = chan_check("dc_head_fwd", C);
   if (rc) return rc;
   DC_REQUIRE(C <= 256, DC_EUNSUP, "dc_head_fwd: C=%d > 256 (the C/4 lanes of a pixel must fit one wave)", C);
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(head_blocks(pixels)), dim3(256), 0, (hipStream_t)stream, a, kh, bh, y, p,
+  hipLaunchKernelGGL(C == 32 ? head_fwd_kernel<8> : head_fwd_kernel<0>, dim3(head_blocks(pixels)), dim3(256), 0, (hipStream_t)stream, a, kh, bh, y, p,
                      y ? partial : nullptr, pixels, C, in_sc, in_sh);
   DC_CHECK_LAUNCH("dc_head_fwd");
   return DC_OK;
@@ -1420,7 +1482,7 @@ extern "C" int dc_head_fwd_bwd(const float* a, const float* in_scale, const floa
   int rc = chan_check("dc_head_fwd_bwd", C);
   if (rc) return rc;
   DC_REQUIRE(C <= 64, DC_EUNSUP, "dc_head_fwd_bwd: C=%d > 64 (the C/4 lanes of a pixel group must divide a wave)", C);
-  hipLaunchKernelGGL(head_fwd_bwd_kernel, dim3(head_blocks(pixels)), dim3(256), 0, (hipStream_t)stream, a, kh, bh, y, p,
+  hipLaunchKernelGGL(C == 32 ? head_fwd_bwd_kernel<8> : head_fwd_bwd_kernel<0>, dim3(head_blocks(pixels)), dim3(256), 0, (hipStream_t)stream, a, kh, bh, y, p,
                      partial, da, grad_partial, pixels, C, loss_kind, in_scale, in_shift, bn_mean, bn_invstd, bn_partial,
                      amax_partial);
   DC_CHECK_LAUNCH("dc_head_fwd_bwd");
