@@ -20,6 +20,7 @@
 //   * activations are split while being written to LDS (v_cvt_pk_f16_f32 x2 + 2 sub per pair);
 //   * weights arrive PRE-split from dc_pack_weights_f16x3 ([tap][K/8][hi|lo][col][8]) and are copied verbatim.
 #include "igemm_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 // Phase timestamps of sampled workgroups (scripts/igemm_phases.py builds the library with -DDC_IGEMM_TRACE and reads
@@ -665,11 +666,15 @@ static int convT_fwd_h_launch(IgemmParams p, hipStream_t st) {
     // With ONE tap a staged input tile feeds only 24 MFMAs per wave and chunk: wider column blocks (all four waves side by side on
     // 2 x 32 pixels x 256 columns, or 2 x 2 on 4 x 32 x 128) split a quarter / half of the input elements per MFMA -- the staging
     // VALU, not the matrix pipe, bounds these launches.  Measured (scripts/one_convT.py, u0..u3): 200 / 143 / 97 / 82 -> 179 / 123 /
-    // 82 / 72 us.  dc_convT2x2_f16x3_tiles() reports the resulting BatchNorm-partial row count.
-    if (p.Ncols % 256 == 0) return igemm_h_launch<1, 1, 1, 0, 32, 1, 2, 2, 32>(p, st, "convT2x2_fwd_f16x3");
-    if (p.Ncols % 128 == 0) return igemm_h_launch<1, 1, 1, 0, 32, 2, 2, 2, 32>(p, st, "convT2x2_fwd_f16x3");
+    // 82 / 72 us (round 3).  dc_convT2x2_f16x3_tiles() reports the resulting BatchNorm-partial row count.
+    // Round 5: 16-channel chunks instead of 32 (half the LDS per workgroup: these one-tap launches are occupancy / latency-bound -- matrix
+    // pipe 21 % busy, HBM 45 % --, not staging-bound alone), and the 2 x 2 wave layout for 256 columns as well.  scripts/one_convT.py,
+    // u0..u3 at batch 16: 173 / 128 / 89 / 71 -> 158 / 112 / 73 / 74 us (64-channel chunks: 202 / 190 / 136 / 104).
+    if (p.Ncols % 512 == 0) return igemm_h_launch<1, 1, 1, 0, 32, 1, 2, 2, 16>(p, st, "convT2x2_fwd_f16x3");
+    if (p.Ncols % 128 == 0) return igemm_h_launch<1, 1, 1, 0, 32, 2, 2, 2, 16>(p, st, "convT2x2_fwd_f16x3");
     return igemm_h_launch<1, 1, 1, 0, 32, 4, 2, 2, 32>(p, st, "convT2x2_fwd_f16x3");
   }
+  // (16-channel chunks change nothing for the 16^2 / 8^2 inputs of the 128^2 windows: 20-21 us either way)
   if (p.Wout > 8) return igemm_h_launch<1, 1, 1, 0, 16, 4, 2, 2, 32>(p, st, "convT2x2_fwd_f16x3");
   return igemm_h_launch<1, 1, 1, 0, 8, 2, 1, 2, 32>(p, st, "convT2x2_fwd_f16x3");
 }
@@ -677,7 +682,7 @@ extern "C" int dc_convT2x2_f16x3_tiles(int N, int H, int W, int Cout) {
   if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
   const int Ncols = 4 * Cout;
   int tw, th;                                       // the tile shapes of convT_fwd_h_launch above
-  if (W > 16) { tw = 32; th = Ncols <= 32 ? 16 : (Ncols % 256 == 0 ? 2 : (Ncols % 128 == 0 ? 4 : 8)); }
+  if (W > 16) { tw = 32; th = Ncols <= 32 ? 16 : (Ncols % 512 == 0 ? 2 : (Ncols % 128 == 0 ? 4 : 8)); }
   else if (W > 8) { tw = 16; th = 16; }
   else { tw = 8; th = 8; }
   return N * dc_cdiv(W, tw) * dc_cdiv(H, th);

@@ -1,10 +1,14 @@
-"""Micro-benchmark of the conv-transpose kernels (split-fp16 path) on the four UNet2DS up-layer shapes."""
+"""Micro-benchmark of the conv-transpose kernels (split-fp16 path) on the four UNet2DS up-layer shapes (batch 16 of 512^2;
+`python scripts/one_convT.py small`: batch 20 of the reference's 128^2 training windows)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deep_calcium_amd._lib import lib
 L = lib()
 N = 16
-def timeit(fn, iters=10):
+SHAPES = [(256, 64, 32), (128, 128, 64), (64, 256, 128), (32, 512, 256)]
+if len(sys.argv) > 1 and sys.argv[1] == 'small':
+    N, SHAPES = 20, [(64, 64, 32), (32, 128, 64), (16, 256, 128), (8, 512, 256)]
+def timeit(fn, iters=30):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -13,7 +17,7 @@ def timeit(fn, iters=10):
     return e0.elapsed_time(e1) / iters
 tot = [0, 0, 0]
 one = torch.ones(1, device='cuda')
-for HW, Ci, Co in [(256, 64, 32), (128, 128, 64), (64, 256, 128), (32, 512, 256)]:
+for HW, Ci, Co in SHAPES:
     x = torch.randn(N, HW, HW, Ci, device='cuda'); dz = torch.randn(N, 2 * HW, 2 * HW, Co, device='cuda')
     K = torch.randn(2, 2, Co, Ci, device='cuda') * 0.05
     wf = torch.empty(L.dc_pack_weights_f16x3_floats(1, Ci, 4 * Co), device='cuda')
