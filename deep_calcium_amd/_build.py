@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdcunet.so')
-SOURCES = ['common.cpp', 'nf_score.cpp', 'tape.cpp', 'igemm_conv.hip', 'igemm_f16x3.hip', 'igemm_pp.hip', 'wgrad.hip', 'wgrad_f16x3.hip', 'bwd_joint.hip', 'conv_c1.hip', 'elementwise.hip']
+SOURCES = ['common.cpp', 'comm.cpp', 'nf_score.cpp', 'tape.cpp', 'igemm_conv.hip', 'igemm_f16x3.hip', 'igemm_pp.hip', 'wgrad.hip', 'wgrad_f16x3.hip', 'bwd_joint.hip', 'conv_c1.hip', 'elementwise.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 HOST_ONLY = {'nf_score.cpp': ['-ffp-contract=off']}      # host arithmetic that must round like numpy's: no fused multiply-add
 

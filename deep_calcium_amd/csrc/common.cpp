@@ -45,6 +45,16 @@ extern "C" int dc_event_create_sync(void** ev) {
   *ev = (void*)e;
   return DC_OK;
 }
+extern "C" int dc_event_create_fenced(void** ev) {
+  DC_REQUIRE(ev, DC_EINVAL, "dc_event_create_fenced: null");
+  hipEvent_t e;
+  // Ordering in front of / behind a COLLECTIVE: the buffer's next reader (or last writer) is a peer GPU over xGMI, so the marker keeps its
+  // system-scope release; ~2.3 us per record, three or four of them per data-parallel step.
+  hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  DC_REQUIRE(rc == hipSuccess, DC_EHIP, "hipEventCreateWithFlags: %s", hipGetErrorString(rc));
+  *ev = (void*)e;
+  return DC_OK;
+}
 extern "C" int dc_stream_wait_event(dc_stream_t stream, void* ev) {
   DC_REQUIRE(ev, DC_EINVAL, "dc_stream_wait_event: null event");
   hipError_t rc = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0);

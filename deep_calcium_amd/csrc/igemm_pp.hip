@@ -29,6 +29,16 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #ifndef DC_PP_ABL
 #define DC_PP_ABL 0
 #endif
+#ifdef DC_PP_TIMELINE
+// per workgroup: s_memrealtime (the chip-wide 100 MHz counter) at kernel entry, barrier 0 passed, last MFMA step done, exit
+__device__ unsigned long long g_pp_timeline[1024 * 4];
+extern "C" int dc_debug_pp_timeline(unsigned long long* out4096) {
+  return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_pp_timeline), sizeof(g_pp_timeline)) == hipSuccess ? 0 : -2;
+}
+#define PP_TL(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_pp_timeline[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PP_TL(i) do {} while (0)
+#endif
 #ifdef DC_IGEMM_TRACE
 __device__ unsigned long long* g_pp_trace = nullptr;
 extern "C" int dc_debug_set_pp_trace(unsigned long long* p) {
@@ -125,6 +135,7 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..11
   const int role = wave >> 2, wr = wave & 3;                      // 0, 1: consumer sets; 2: producers
   PP_TRACE_INIT();
+  PP_TL(0);
 
   // ---- this workgroup's items: each XCD walks a contiguous range of (tile, column block) pairs, its workgroups
   // striding through it (ids b and b+8 share an L2: the workgroups that read one input patch for different columns, and
@@ -673,8 +684,10 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
   PP_TRACE();
   __syncthreads();                                              // barrier 0
   PP_TRACE();
+  PP_TL(1);
   int j = 0, c = 0;
   for (int k = 0; k < K + 5; ++k) {                             // + 5: the last tile's 4 epilogue slices and its merge
+    if (k == K) PP_TL(2);
     if (merge_pending) epi_merge();                             // partials written one step ago (a barrier in between)
     if (k < K && (j & 1) == role) {
       if (c == 0) {
@@ -704,6 +717,10 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
     if (role < 2)
       for (int n = tid & 255; n < p.Ncols; n += 256)
         dc_moments_store(p.stats + ((long)(2 * blockIdx.x + role) * p.Ncols + n) * 2, PP_RUN_M[role * EP_COLS + n]);
+#ifdef DC_PP_TIMELINE
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+  PP_TL(3);
+#endif
 #undef PP_RUN_M
 }
 

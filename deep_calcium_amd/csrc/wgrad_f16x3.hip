@@ -26,6 +26,38 @@
 #include "wgrad_common.h"
 #include <stdlib.h>
 
+// Experiment switches (scripts/wgrad_variants.py builds copies of the library with them; the shipped build uses the defaults).
+// DC_WG_ABL (ablation builds only, results are garbage): bit 0 producers stage only the first two tiles (no split / LDS
+// writes in the loop), bit 1 producers request only the first two tiles (no global loads in the loop), bit 2 consumers
+// issue no fragment reads / MFMAs (producers alone), bit 3 no slab store.  DC_WG_CLOCK: wave 0 of workgroup 0 stamps
+// s_memtime / s_memrealtime around its loop (dc_debug_wgrad_stamps): the clock the chip holds in this kernel.
+#ifndef DC_WG_ABL
+#define DC_WG_ABL 0
+#endif
+#ifndef DC_WG_RW
+#define DC_WG_RW 4          // pixel rows per 16-wide tile of the Cin, Cout > 32 instantiation
+#endif
+#ifndef DC_WG_PRIO
+#define DC_WG_PRIO 0        // s_setprio of the consumer waves
+#endif
+#ifndef DC_WG_DEPTH
+#define DC_WG_DEPTH 1       // (k-step, tap) groups the A fragments are requested ahead of their MFMAs
+#endif
+#ifdef DC_WG_CLOCK
+__device__ unsigned long long g_wg_stamps[4];
+// per workgroup: s_memrealtime (the chip-wide 100 MHz counter) at kernel entry, first tile ready, tile loop done, slab stored
+__device__ unsigned long long g_wg_timeline[1024 * 4];
+extern "C" int dc_debug_wgrad_stamps(unsigned long long* out4) {
+  return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_wg_stamps), sizeof(g_wg_stamps)) == hipSuccess ? 0 : -2;
+}
+extern "C" int dc_debug_wgrad_timeline(unsigned long long* out4096) {
+  return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_wg_timeline), sizeof(g_wg_timeline)) == hipSuccess ? 0 : -2;
+}
+#define WG_TL(i) do { if (tid == 0 && blockIdx.x < 1024) g_wg_timeline[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WG_TL(i) do {} while (0)
+#endif
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((__vector_size__(4 * sizeof(short)))) short tr_v4i16;
@@ -115,6 +147,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // 0..7, provably wave-uniform
+  WG_TL(0);
   // operand scales (powers of two, undone in the epilogue): the gradient operand's device scalar, the activation
   // operand's range guard -- every wave needs them (producers to split, consumers to un-scale)
   const float x_scale = dc_block_guard_scale(hp.xAbound, hp.xChannels, reinterpret_cast<float*>(smem));
@@ -295,12 +328,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
       stage(ra0, rb0, rz0, ma0, mb0, smem);
       __syncthreads();
       for (int i = 0; i < nt; i += 2) {
-        if (i + 2 < nt) request(tile_beg + i + 2, ra0, rb0, rz0, ma0, mb0);
-        if (i + 1 < nt) stage(ra1, rb1r, rz1r, ma1, mb1, smem + SET);
+        if (i + 2 < nt && !(DC_WG_ABL & 2)) request(tile_beg + i + 2, ra0, rb0, rz0, ma0, mb0);
+        if (i + 1 < nt && !((DC_WG_ABL & 1) && i > 0)) stage(ra1, rb1r, rz1r, ma1, mb1, smem + SET);
         __syncthreads();
         if (i + 1 < nt) {
-          if (i + 3 < nt) request(tile_beg + i + 3, ra1, rb1r, rz1r, ma1, mb1);
-          if (i + 2 < nt) stage(ra0, rb0, rz0, ma0, mb0, smem);
+          if (i + 3 < nt && !(DC_WG_ABL & 2)) request(tile_beg + i + 3, ra1, rb1r, rz1r, ma1, mb1);
+          if (i + 2 < nt && !(DC_WG_ABL & 1)) stage(ra0, rb0, rz0, ma0, mb0, smem);
           __syncthreads();
         }
       }
@@ -346,11 +379,24 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
   };
 
   __syncthreads();   // image set 0 is ready
+  WG_TL(1);
+  if (DC_WG_PRIO) __builtin_amdgcn_s_setprio(DC_WG_PRIO);
+#ifdef DC_WG_CLOCK
+  unsigned long long t0c = 0, t0r = 0;
+  if (blockIdx.x == 0 && tid == 0) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
+#endif
+  constexpr int DEPTH = DC_WG_DEPTH, RING = DEPTH + 1;
   for (int i = 0; i < nt; ++i) {
     char* cur = smem + (i & 1) * SET;
-    f16x8 ah[2], al[2], bh[2][NBW], bl[2][NBW];
-    ah[0] = tr_frag(cur, offA[0] + a_off(0), offA[1] + a_off(0));
-    al[0] = tr_frag(cur + A_IMG, offA[0] + a_off(0), offA[1] + a_off(0));
+    if (!(DC_WG_ABL & 4)) {
+    f16x8 ah[RING], al[RING], bh[2][NBW], bl[2][NBW];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      if (d < GROUPS) {
+        ah[d] = tr_frag(cur, offA[0] + a_off(d), offA[1] + a_off(d));
+        al[d] = tr_frag(cur + A_IMG, offA[0] + a_off(d), offA[1] + a_off(d));
+      }
+    }
 #pragma unroll
     for (int w = 0; w < NBW; ++w) {
       bh[0][w] = tr_frag(cur, offB[0] + b_off(0, w), offB[1] + b_off(0, w));
@@ -358,16 +404,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
     }
 #pragma unroll
     for (int g = 0; g < GROUPS; ++g) {
-      const int ca = g & 1, ks = g / TAPS, tap = g % TAPS, cbuf = ks & 1;
-      if (g + 1 < GROUPS) {      // fragments of group g+1 are requested before the MFMAs of group g issue
-        ah[ca ^ 1] = tr_frag(cur, offA[0] + a_off(g + 1), offA[1] + a_off(g + 1));
-        al[ca ^ 1] = tr_frag(cur + A_IMG, offA[0] + a_off(g + 1), offA[1] + a_off(g + 1));
-        if ((g + 1) % TAPS == 0) {
+      const int ca = g % RING, ks = g / TAPS, tap = g % TAPS, cbuf = ks & 1;
+      if (g + DEPTH < GROUPS) {  // fragments of group g + DEPTH are requested before the MFMAs of group g issue
+        ah[(g + DEPTH) % RING] = tr_frag(cur, offA[0] + a_off(g + DEPTH), offA[1] + a_off(g + DEPTH));
+        al[(g + DEPTH) % RING] = tr_frag(cur + A_IMG, offA[0] + a_off(g + DEPTH), offA[1] + a_off(g + DEPTH));
+      }
+      // the B fragments of the next k-step: one group ahead (DEPTH 1) or at the head of this k-step (the other buffer is free)
+      if ((DEPTH == 1 ? (g + 1) % TAPS == 0 : tap == 0) && (ks + 1) * TAPS < GROUPS) {
 #pragma unroll
-          for (int w = 0; w < NBW; ++w) {
-            bh[cbuf ^ 1][w] = tr_frag(cur, offB[0] + b_off(ks + 1, w), offB[1] + b_off(ks + 1, w));
-            bl[cbuf ^ 1][w] = tr_frag(cur + B_IMG, offB[0] + b_off(ks + 1, w), offB[1] + b_off(ks + 1, w));
-          }
+        for (int w = 0; w < NBW; ++w) {
+          bh[cbuf ^ 1][w] = tr_frag(cur, offB[0] + b_off(ks + 1, w), offB[1] + b_off(ks + 1, w));
+          bl[cbuf ^ 1][w] = tr_frag(cur + B_IMG, offB[0] + b_off(ks + 1, w), offB[1] + b_off(ks + 1, w));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -379,14 +426,29 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
     __syncthreads();   // this set may be overwritten, the other one is complete
   }
+  if (DC_WG_PRIO) __builtin_amdgcn_s_setprio(0);
+  WG_TL(2);
+#ifdef DC_WG_CLOCK
+  if (blockIdx.x == 0 && tid == 0) {
+    g_wg_stamps[0] = __builtin_amdgcn_s_memtime() - t0c;
+    g_wg_stamps[1] = __builtin_amdgcn_s_memrealtime() - t0r;
+    g_wg_stamps[2] = (unsigned long long)nt;
+    g_wg_stamps[3] = (unsigned long long)GROUPS;
+  }
+#endif
 
   const float out_scale = 1.f / (a_scale * b_scale);
 #pragma unroll
   for (int w = 0; w < NBW; ++w)   // one 32x32 block at a time through the shared cross-wave reduction + store
-    wgrad_store<TAPS, WM, WNW, WK>(p, acc[w], smem, split, m0, n0 + 32 * (wnw * NBW + w) - 32 * wnw, wm, wnw, wk, lane,
+    if (WK > 1 || !(DC_WG_ABL & 8) || p.tilesTotal < 0) wgrad_store<TAPS, WM, WNW, WK>(p, acc[w], smem, split, m0, n0 + 32 * (wnw * NBW + w) - 32 * wnw, wm, wnw, wk, lane,
                                    out_scale);
+#ifdef DC_WG_CLOCK
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the slab stores have left
+  WG_TL(3);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -453,7 +515,8 @@ static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, 
 // outputs (1.69x) instead of 4x34 (2.13x) with 32x2 tiles: less L2->LDS traffic, +3.5..5 % measured.
 #define CONV_H_DISPATCH(FN, ...)                                                       \
   if (W <= 8) return FN<3, 3, 1, 1, 8, 8, 2, 2, 1 __VA_ARGS__;                         \
-  if (W <= 16 || (Cin > 32 && Cout > 32)) return FN<3, 3, 1, 1, 16, 4, 2, 2, 1 __VA_ARGS__; \
+  if (W <= 16) return FN<3, 3, 1, 1, 16, 4, 2, 2, 1 __VA_ARGS__;                       \
+  if (Cin > 32 && Cout > 32) return FN<3, 3, 1, 1, 16, DC_WG_RW, 2, 2, 1 __VA_ARGS__;  \
   if (Cin > 32) return FN<3, 3, 1, 1, 32, 2, 2, 1, 1 __VA_ARGS__;                      \
   if (Cout > 32) return FN<3, 3, 1, 1, 32, 2, 1, 2, 1 __VA_ARGS__;                     \
   return FN<3, 3, 1, 1, 32, 2, 1, 1, 1 __VA_ARGS__;

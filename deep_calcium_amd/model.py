@@ -411,6 +411,14 @@ class Model(object):
         only the encoder's 15 % is exposed.  DC_AR_BUCKETS=1: one blocking all-reduce after the backward."""
         import torch.distributed as dist
         eng = self.engine
+        comm = parallel.native_comm(eng.device)
+        if comm is not None:
+            # RCCL through the C ABI (dc_comm_all_reduce_sum on the engine's collective stream): the exchange is part of the
+            # backward's launch sequence -- one tape, no return to Python between the ranges (DC_COMM=torch: the path below)
+            t0 = self._ar_mark()
+            eng.backward(comm=comm)
+            self._ar_mark(t0)
+            return
         if os.environ.get('DC_AR_BUCKETS', '3') == '1':
             eng.backward()
             t0 = self._ar_mark()

@@ -295,9 +295,12 @@ class UNetEngine(object):
         self.tail_main = os.environ.get('DC_TAIL_MAIN', '1') == '1'      # the step's last weight gradient on the main stream (A/B: 0)
         self.stats_per_wg = True          # BatchNorm partials: one row per (workgroup, consumer set) of the role-split kernel (A/B: False)
         self.use_tapes = os.environ.get('DC_TAPES', '1') != '0'
+        self.ar_buckets = 1 if os.environ.get('DC_AR_BUCKETS', '3') == '1' else 3      # gradient exchange: one all-reduce or three ranges
         self._tapes = {}
+        self._tape_epoch = 0
         self.tape_replays = 0
         self._evpool, self._ev_i = [], 0
+        self._evpool_f, self._evf_i = [], 0       # events with the system-scope fence: collective boundaries
         self._tail = None
         self._packed_dirty = True
         self._fold_dirty = True
@@ -432,17 +435,31 @@ class UNetEngine(object):
             self._evpool.append(h.value)
         return self._evpool[i]
 
-    def _record(self, stream_h):
-        ev = self._ev()
+    def _ev_fenced(self):
+        """The same for the hand-offs in front of / behind a COLLECTIVE: events that keep the marker's system-scope fence
+        (dc_event_create_fenced) -- the buffer's next reader, or last writer, is a peer GPU over xGMI."""
+        i = self._evf_i
+        self._evf_i = i + 1
+        if i == len(self._evpool_f):
+            import ctypes
+            h = ctypes.c_void_p()
+            rc = self.L.cdll.dc_event_create_fenced(ctypes.byref(h))
+            if rc != 0:
+                raise DcunetError('dc_event_create_fenced failed (%d): %s' % (rc, self.L.cdll.dc_last_error().decode()))
+            self._evpool_f.append(h.value)
+        return self._evpool_f[i]
+
+    def _record(self, stream_h, fenced=False):
+        ev = self._ev_fenced() if fenced else self._ev()
         self.L.dc_event_record(ev, stream_h)
         return ev
 
     def _wait(self, stream_h, ev):
         self.L.dc_stream_wait_event(stream_h, ev)
 
-    def _wait_stream(self, dst_h, src_h):
+    def _wait_stream(self, dst_h, src_h, fenced=False):
         """work queued on dst from here on runs after everything queued on src so far"""
-        self._wait(dst_h, self._record(src_h))
+        self._wait(dst_h, self._record(src_h, fenced))
 
     def _sync_bn(self):
         """'sync' BatchNorm is live when there is more than one rank -- or under DC_DIST_FORCE=1 (a one-rank process group: the
@@ -460,6 +477,26 @@ class UNetEngine(object):
         e1.record()
         rec.append((e0, e1))
         return t
+
+    # Engine state a recorded body branches on WITHOUT it being part of the tape keys: assigning a different value to any of
+    # these drops every tape (they bake in the control flow AND raw device pointers), and so does any allocation path that
+    # can move a buffer a tape points into (buf() regrow, set_crop_sources, a new side stream).
+    _TAPE_STATE = frozenset(('range_guard', 'bnin', 'dzin', 'dzin_lvls', 'dzin_all', 'joint', 'stats_per_wg', 'tail_main',
+                             'dz_writeback', 'deep_slots', 'FOLD_MIN', 'bn_mode', 'streams', 'mfma', 'upsampling', 'up_drop',
+                             'infer_measured', 'SLOTS', 'SLOTS_DEEP', 'SLOTS_DEEP_MAX_BYTES', '_side_stream', '_comm_stream', 'nm', 'use_tapes',
+                             'ar_buckets'))
+
+    def __setattr__(self, name, value):
+        if name in UNetEngine._TAPE_STATE and '_tapes' in self.__dict__:
+            old = self.__dict__.get(name, getattr(type(self), name, None))
+            if old is not value and old != value:
+                self.invalidate_tapes()
+        object.__setattr__(self, name, value)
+
+    def invalidate_tapes(self):
+        """Forget every recorded launch tape: the next two steps re-record (and re-verify) them."""
+        self._tapes.clear()
+        self._tape_epoch = self.__dict__.get('_tape_epoch', 0) + 1
 
     def _v(self, key, value):
         """A per-step launch argument: wrapped for the tape while one is being recorded."""
@@ -494,6 +531,8 @@ class UNetEngine(object):
     def buf(self, name, numel, dtype=torch.float32):
         t = self._bufs.get(name)
         if t is None or t.numel() < numel or t.dtype != dtype:
+            if t is not None:
+                self.invalidate_tapes()          # a regrown buffer moves: recorded pointers into the old one are dead
             t = torch.empty(int(numel), dtype=dtype, device=self.device)
             self._bufs[name] = t
         return t
@@ -1189,7 +1228,7 @@ class UNetEngine(object):
         return 0
 
     @_on_device
-    def backward(self, bucket_cb=None, defer_tail=False):
+    def backward(self, bucket_cb=None, defer_tail=False, comm=None):
         """Backward of the last forward_train: fills gflat (same layout as pflat).  defer_tail (single-GPU training step
         only): return WITHOUT joining the weight-gradient stream -- the only thing still running there is the first layer's
         weight (and bias) gradient, and adam_step() updates everything else and re-packs the weights underneath it before
@@ -1214,8 +1253,14 @@ class UNetEngine(object):
         world = parallel.world_size()
         sync = self._sync_bn()
 
+        if comm is not None:
+            if bucket_cb is not None:
+                raise ValueError('backward: pass bucket_cb (the caller issues the collectives) OR comm (dc_comm_* from here), not both')
+            if getattr(self, '_comm_stream', None) is None:
+                self._comm_stream = torch.cuda.Stream(device=self.device)
+
         def body():
-            return self._backward_body(bucket_cb, defer_tail)
+            return self._backward_body(bucket_cb, defer_tail, comm)
 
         def on_mark(i):                      # replay: the same hand-over of a finished gradient range to the collective
             with torch.cuda.stream(side):
@@ -1223,15 +1268,16 @@ class UNetEngine(object):
         if masks is not None or sync:
             return body()
         key = ('bwd', N, self.loss_kind, self._stream(), side.cuda_stream, self._head_bwd_done, bool(defer_tail),
-               bucket_cb is not None, world, parallel.rank())
+               bucket_cb is not None, world, parallel.rank(), comm, self.ar_buckets)
         return self._taped(key, body, lambda: self._step_values(x_dev, y_dev, step_seed),
-                           post_attrs=('_tail', '_head_bwd_done', '_ev_i'), on_mark=on_mark)
+                           post_attrs=('_tail', '_head_bwd_done', '_ev_i', '_evf_i'), on_mark=on_mark)
 
-    def _backward_body(self, bucket_cb, defer_tail):
+    def _backward_body(self, bucket_cb, defer_tail, comm=None):
         N, masks, step_seed, x_dev, y_dev = self._last
         L, st = self.L, self._stream()
         A, T = self._acts(N), self._train_bufs(N)
         self._ev_i = 0
+        self._evf_i = 0
         self._tail = None
         xp, yp = self._v('x', _ptr(x_dev)), self._v('y', y_dev.data_ptr())
         nfb = self.nfb
@@ -1499,11 +1545,24 @@ class UNetEngine(object):
                                      red=red_of(l_up))
             state['g'] = kn
 
+        ch = self._comm_stream.cuda_stream if comm is not None else None
+
         def bucket_done(i):
+            if comm is not None:
+                # the collective through the C ABI, on its own stream, recorded like any launch (no cut in the tape): the range is
+                # final once BOTH queues have reached this point -- weight gradients on the side stream, dbias / dgamma / dbeta /
+                # head gradients on the main one; the events carry the system-scope fence (a peer reads gflat over xGMI)
+                if self.ar_buckets > 1:
+                    self._wait_stream(ch, mh, fenced=True)
+                    if two:
+                        self._wait_stream(ch, sh_, fenced=True)
+                    lo, hi = self.grad_buckets()[i]
+                    L.dc_comm_all_reduce_sum(comm, _ptr(self.gflat, lo), hi - lo, ch)
+                return
             if bucket_cb is None:
                 return
             if two:
-                self._wait_stream(sh_, mh)  # dbias / dgamma / dbeta / head gradients are written on the main stream
+                self._wait_stream(sh_, mh, fenced=True)  # dbias / dgamma / dbeta / head gradients are written on the main stream
             L.mark(i)                       # (a tape is cut here: the collective is issued from Python between two segments)
             with torch.cuda.stream(side):
                 bucket_cb(*self.grad_buckets()[i])
@@ -1550,7 +1609,13 @@ class UNetEngine(object):
                 block_bwd(la, _ptr(A['pool%d' % (lvl - 1)]), _ptr(gb[ko]), c, _ptr(gb[kn]), fused=fa, da_g=ko)
                 state['g'] = kn
         if two and self._tail is None:
-            self._wait_stream(mh, sh_)    # gflat is complete once both streams have drained
+            self._wait_stream(mh, sh_, fenced=bucket_cb is not None)    # gflat is complete once both streams have drained
+        if comm is not None:
+            # the last range (the encoder's: 15 % of the bytes, the only exposed part) -- or, with one bucket, everything
+            self._wait_stream(ch, mh, fenced=True)
+            lo, hi = self.grad_buckets()[-1] if self.ar_buckets > 1 else (0, self.n_train)
+            L.dc_comm_all_reduce_sum(comm, _ptr(self.gflat, lo), hi - lo, ch)
+            self._wait_stream(mh, ch, fenced=True)      # Adam (main stream) reads the reduced gradient
 
     def _join_side(self):
         side = getattr(self, '_side_stream', None)
@@ -1571,7 +1636,9 @@ class UNetEngine(object):
         t = self.iterations + 1
         lr_t = float(lr * np.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t))
         side = getattr(self, '_side_stream', None)
-        key = ('adam', self._stream(), side.cuda_stream if side is not None else 0, self._tail is not None, float(beta_1),
+        # (the tail EVENT, not just its presence: the body bakes `self._wait(st, tail)` in, and which pool event the backward
+        # left as its tail depends on the backward variant that ran)
+        key = ('adam', self._stream(), side.cuda_stream if side is not None else 0, self._tail, float(beta_1),
                float(beta_2), float(epsilon), float(grad_scale), self._packed_dirty)
         self._taped(key, lambda: self._adam_body(lr_t, beta_1, beta_2, epsilon, grad_scale), lambda: {'lr_t': lr_t},
                     post_attrs=('_packed_dirty', '_tail', '_ev_i'))

@@ -13,6 +13,11 @@ import torch
 import torch.distributed as dist
 
 
+def ctypes_void(h):
+    import ctypes
+    return ctypes.c_void_p(h)
+
+
 def is_dist():
     return dist.is_available() and dist.is_initialized()
 
@@ -73,11 +78,57 @@ def shutdown():
     """Tear the process group down (idempotent; registered at exit by init_from_env): without it the backend's worker
     threads are destroyed while still joinable when the interpreter exits -- 'terminate called without an active exception',
     SIGABRT after a run that had finished fine."""
+    if _NATIVE:
+        try:
+            from ._lib import lib
+            for h in _NATIVE.values():
+                lib().cdll.dc_comm_destroy(ctypes_void(h))
+        except Exception:
+            pass
+        _NATIVE.clear()
     if is_dist():
         try:
             dist.destroy_process_group()
         except Exception:
             pass
+
+
+_NATIVE = {}          # device index -> dc_comm_* handle (RCCL through the C ABI) of this process
+
+
+def native_comm(device):
+    """The gradient exchange's RCCL communicator behind the C ABI (include/dcunet.h dc_comm_*, csrc/comm.cpp), made on first use:
+    rank 0 draws the unique id, the others receive it through the process group that rendezvoused the ranks.  None -- the
+    exchange then goes through torch.distributed -- when no exchange is active, when the group's backend is not RCCL (gloo:
+    the CPU tests and the ranks-share-one-GPU functional mode, where RCCL refuses two ranks on one device) or under DC_COMM=torch."""
+    if not exchange_active() or dist.get_backend() != 'nccl' or os.environ.get('DC_COMM', 'rccl') == 'torch':
+        return None
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    h = _NATIVE.get(idx)
+    if h is None:
+        import ctypes
+        from ._lib import lib, DcunetError
+        L = lib()
+        nbytes = 128                      # DC_COMM_ID_BYTES
+        buf = ctypes.create_string_buffer(nbytes)
+        if rank() == 0:
+            L.dc_comm_unique_id(buf)
+        box = [buf.raw]
+        if world_size() > 1:
+            dist.broadcast_object_list(box, 0)
+        ident = ctypes.create_string_buffer(box[0], nbytes)
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(idx):
+            rc = L.cdll.dc_comm_init_rank(ctypes.byref(comm), ident, world_size(), rank())
+        if rc != 0:
+            raise DcunetError('dc_comm_init_rank failed (%d): %s' % (rc, L.cdll.dc_last_error().decode()))
+        h = _NATIVE[idx] = comm.value
+    return h
+
+
+def native_comm_active(device):
+    return native_comm(device) is not None
 
 
 def shard_slice(global_batch, r=None, ws=None):

@@ -36,7 +36,7 @@ typedef void* dc_stream_t;
 
 /* ABI revision: dc_version() of the loaded library must EQUAL the DC_ABI_VERSION of the header the caller was built /
  * bound against (argument lists change between revisions; the Python binding refuses a mismatch). */
-#define DC_ABI_VERSION 106
+#define DC_ABI_VERSION 107
 int dc_version(void);
 const char* dc_last_error(void);
 
@@ -471,11 +471,35 @@ int dc_event_create(void** ev);
 /* an event for stream ordering on ONE device only (hipEventDisableTiming | hipEventDisableSystemFence): what the engine's two-stream
  * backward hands between its streams.  Not for host synchronisation (no system-scope fence at the marker). */
 int dc_event_create_sync(void** ev);
+/* the same WITH the marker's system-scope fence (hipEventDisableTiming only): for the hand-offs whose consumer is not a queue of
+ * this device -- the events in front of and behind a collective (a peer GPU reads / writes the buffer over xGMI). */
+int dc_event_create_fenced(void** ev);
 /* hipStreamWaitEvent(stream, ev): work queued on `stream` after this call waits for the work `ev` was last recorded behind */
 int dc_stream_wait_event(dc_stream_t stream, void* ev);
 int dc_event_record(void* ev, dc_stream_t stream);
 int dc_event_elapsed_ms(void* start, void* stop, float* ms);
 int dc_event_destroy(void* ev);
+
+/* ---- collectives: the data-parallel gradient exchange (SURVEY 8b "call librccl.so ... directly via ctypes or a 3-function
+ * dc_comm_* wrapper", 8e: one ncclAllReduce(sum, fp32) over the flat gradient buffer, optionally in buckets) ---------------
+ * RCCL (librccl.so.1) is resolved with dlopen at the first dc_comm_* call -- the copy the process already holds (PyTorch-ROCm's)
+ * when there is one; every other entry point works without it (DC_EUNSUP + message from these when it cannot be loaded).
+ *   dc_comm_unique_id: HOST buffer of DC_COMM_ID_BYTES, filled by ONE rank and handed to the others out of band (the binding
+ *     sends it through the torch.distributed store that rendezvoused the ranks);
+ *   dc_comm_init_rank: collective over the nranks callers (one per GPU; binds the caller's current device), returns the handle;
+ *   dc_comm_all_reduce_sum (fp32: the flat gradient) / _f64 (the step's loss / metric sums): buf[0..n) <- sum over ranks, in place,
+ *     asynchronous on `stream` (a launch like any other: it can be recorded on a tape -- the backward of a data-parallel step
+ *     replays as ONE tape, collectives included);
+ *   dc_comm_group_start / _end: ncclGroupStart / ncclGroupEnd around several of them.
+ * The caller orders the buffer's producers in front of the call with events made by dc_event_create_fenced. */
+#define DC_COMM_ID_BYTES 128
+int dc_comm_unique_id(void* id_host);
+int dc_comm_init_rank(void** comm, const void* id_host, int nranks, int rank);
+int dc_comm_all_reduce_sum(void* comm, float* buf, long n, dc_stream_t stream);
+int dc_comm_all_reduce_sum_f64(void* comm, double* buf, long n, dc_stream_t stream);
+int dc_comm_group_start(void);
+int dc_comm_group_end(void);
+int dc_comm_destroy(void* comm);
 
 /* ---- launch tape: a step's enqueue sequence, recorded once, replayed from C --------------------------------------------
  * The reference's train loop calls train_on_batch once per step (model.fit_generator, unet_2d_summary.py:429-430); here a

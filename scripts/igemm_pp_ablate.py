@@ -1,7 +1,10 @@
 """What stretches a step of the role-split conv kernel beyond its 108 x 32 = 3 456 cycles of MFMA issue?  Builds
 igemm_pp.hip with -DDC_IGEMM_TRACE -DDC_PP_ABL=<mask> (bit 0 no epilogue, 1 no split / LDS writes, 2 fragments read once
 per step, 3 no global loads; results are garbage) and reports the kernel time and the consumers' MFMA-step cycles.
-    python scripts/igemm_pp_ablate.py HW Cin Cout [masks...]"""
+    python scripts/igemm_pp_ablate.py build [masks...]                 # HERE: the .so files travel to the GPU box
+    python scripts/igemm_pp_ablate.py HW Cin Cout variant [masks...]   # variant 0: forward, no BatchNorm partials (<2,2,0>);
+                                                                       # 3: forward + per-workgroup partials (<2,2,3>);
+                                                                       # 1: data gradient + BatchNorm-backward sums (<2,2,1>)"""
 import ctypes, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,41 +14,65 @@ from deep_calcium_amd._build import SOURCES            # noqa: E402
 
 
 def build(mask):
-    lib = os.path.join(ROOT, 'deep_calcium_amd', 'lib', 'libdcunet_abl%d.so' % mask)
+    lib = os.path.join(ROOT, 'deep_calcium_amd', 'lib', 'libdcunet_ppabl%d.so' % mask)
     if not os.path.exists(lib) or any(os.path.getmtime(os.path.join(CSRC, f)) > os.path.getmtime(lib) for f in os.listdir(CSRC)):
-        cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DDC_IGEMM_TRACE',
-               '-DDC_PP_ABL=%d' % mask, '-o', lib]
-        for f in SOURCES:
-            cmd += ['-x', 'hip', os.path.join(CSRC, f)]
-        subprocess.run(cmd, check=True)
+        from scripts.build_variant import build_variant
+        build_variant('ppabl%d' % mask, ['igemm_pp.hip'], ['-DDC_IGEMM_TRACE', '-DDC_PP_ABL=%d' % mask])
     return lib
 
 
-def worker(lib_path, HW, Ci, Co, mask=0):
-    os.environ['DC_LIB_PATH'] = lib_path
+def make_run(L, variant, HW, Ci, Co, N=16):
+    """One conv3x3 launch of the role-split kernel as a closure: variant 0 forward without BatchNorm partials (<*,*,0>), 3 forward
+    with per-workgroup partial rows (<*,*,3>), 1 data gradient that also emits BatchNorm-backward sums (<*,*,1>).  Returns
+    (run, keep-alive tensors)."""
     import torch
-    from deep_calcium_amd._lib import lib
-    L = lib()
-    N = 16
     x = torch.randn(N, HW, HW, Ci, device='cuda')
     K = torch.randn(3, 3, Ci, Co, device='cuda') * 0.05
     wp16 = torch.empty(L.dc_pack_weights_f16x3_floats(9, Ci, Co), device='cuda')
     L.dc_pack_weights_f16x3(K.data_ptr(), wp16.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
     z = torch.empty(N, HW, HW, Co, device='cuda')
-    stats = torch.zeros(L.dc_conv3x3_tiles(N, HW, HW, Co) * Co * 2, dtype=torch.float64, device='cuda')
+    keep = [x, K, wp16, z]
+    if variant == 3:
+        rows = L.dc_conv3x3_stats_rows(N, HW, HW, Ci, Co)
+        stats = torch.zeros(rows * Co * 2, dtype=torch.float64, device='cuda')
+        keep.append(stats)
+        run = lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp16.data_ptr(), None, z.data_ptr(), Co, stats.data_ptr(), rows, None, None, 0,
+                                             None, 0, None, 0, None, N, HW, HW, Ci, Co, None)
+    elif variant == 0:
+        run = lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp16.data_ptr(), None, z.data_ptr(), Co, None, 0, None, None, 0,
+                                             None, 0, None, 0, None, N, HW, HW, Ci, Co, None)
+    else:           # the data gradient of a Cout -> Cin layer that also emits the sums of the BatchNorm layer it writes `da` of
+        assert Ci == Co, 'variant 1 is timed on square layers (the forward packing stands in for the flipped one)'
+        rows = L.dc_conv3x3_dgrad_bnred_blocks(N, HW, HW, Ci, Co)
+        assert rows > 0
+        zin = torch.randn(N, HW, HW, Ci, device='cuda')
+        mean, invstd, gamma, beta = (torch.rand(Ci, device='cuda') + 0.5 for _ in range(4))
+        part = torch.zeros(rows * Ci * 2, device='cuda'); amax = torch.zeros(rows * Ci, device='cuda')
+        keep += [zin, mean, invstd, gamma, beta, part, amax]
+        run = lambda: L.dc_conv3x3_dgrad_bnred_f16x3(x.data_ptr(), wp16.data_ptr(), z.data_ptr(), None, None, 0, zin.data_ptr(),
+                                                     mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                     part.data_ptr(), amax.data_ptr(), N, HW, HW, Ci, Co, None)
+    return run, keep
+
+
+def worker(lib_path, HW, Ci, Co, mask=0, variant=3):
+    os.environ['DC_LIB_PATH'] = lib_path
+    import torch
+    from deep_calcium_amd._lib import lib
+    L = lib()
+    N = 16
+    run, keep = make_run(L, variant, HW, Ci, Co, N)
     trace = torch.zeros(8 * 3 * 512, dtype=torch.int64, device='cuda')
     fn = L.cdll.dc_debug_set_pp_trace
     fn.argtypes = [ctypes.c_void_p]
-    run = lambda: L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp16.data_ptr(), None, z.data_ptr(), Co, stats.data_ptr(), 0, None, None, 0,
-                                         None, 0, None, 0, None, N, HW, HW, Ci, Co, None)
     fn(None)
-    for _ in range(3): run()
+    for _ in range(10): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5): run()
+    for _ in range(20): run()
     e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / 5
+    us = e0.elapsed_time(e1) * 1e3 / 20
     fn(trace.data_ptr()); run(); torch.cuda.synchronize()
     t = trace.cpu().numpy().reshape(-1, 3, 512)
     nch = Ci // 16
@@ -87,15 +114,19 @@ def worker(lib_path, HW, Ci, Co, mask=0):
 
 if __name__ == '__main__':
     if sys.argv[1] == '--worker':
-        worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
+        worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]))
         sys.exit(0)
-    HW, Ci, Co = sys.argv[1:4]
-    masks = [int(m) for m in sys.argv[4:]] or [0, 1, 2, 4, 8, 3, 7, 15]
+    if sys.argv[1] == 'build':
+        for m in [int(v) for v in sys.argv[2:]] or [0, 2, 4, 8, 10, 14, 16]:
+            print(build(m), flush=True)
+        sys.exit(0)
+    HW, Ci, Co, variant = sys.argv[1:5]
+    masks = [int(m) for m in sys.argv[5:]] or [0, 2, 4, 8, 10, 14, 16]
     names = {0: 'full kernel', 1: 'no epilogue', 2: 'no split / LDS writes', 4: 'fragments read once per step', 8: 'no global loads',
              16: 'detail stamps'}
     for m in masks:
         lib = build(m)
         label = ' + '.join(names[b] for b in (1, 2, 4, 8, 16) if m & b) or names[0]
         print('%-60s' % label, end=' ', flush=True)
-        subprocess.run([sys.executable, os.path.abspath(__file__), '--worker', lib, HW, Ci, Co, str(m)], check=True,
+        subprocess.run([sys.executable, os.path.abspath(__file__), '--worker', lib, HW, Ci, Co, str(m), variant], check=True,
                        env=dict(os.environ, DC_LIB_PATH=lib))      # read when the package is imported

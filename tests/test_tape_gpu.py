@@ -124,3 +124,36 @@ def test_fit_through_tapes_and_device_batches_reaches_the_same_history(tmp_path,
     h0, r0 = run('plain')
     assert r1 >= 3 * 12 and r0 == 0
     assert h1 == h0
+
+
+def test_engine_state_change_drops_the_tapes_and_the_run_stays_the_untaped_one():
+    """A tape bakes in the control flow a body took and raw device pointers.  Engine state the bodies branch on that is not in
+    the tape keys (per-workgroup BatchNorm partial rows, the tail placement, the fold threshold, ...) and any buffer regrow
+    must therefore drop the tapes (UNetEngine._TAPE_STATE / invalidate_tapes): a switch flipped MID-RUN gives the run a
+    launch-by-launch engine with the same flips gives, bit for bit, and the tapes are re-recorded afterwards."""
+    a, b = _pair(64, 32)
+    data = _batches(2, 3, 64, 21)
+    flips = {4: ('stats_per_wg', False), 8: ('tail_main', False), 12: ('stats_per_wg', True)}
+    for step in range(16):
+        if step in flips:
+            name, val = flips[step]
+            before = a.engine._tape_epoch if hasattr(a.engine, '_tape_epoch') else 0
+            for m in (a, b):
+                setattr(m.engine, name, val)
+            assert a.engine._tape_epoch == before + 1 and not a.engine._tapes       # dropped, not replayed into the old sequence
+        x, y = data[step % 2]
+        for m in (a, b):
+            m.train_on_device_batch(x, y)
+    torch.cuda.synchronize()
+    assert a.engine.tape_replays >= 3 * 4 and b.engine.tape_replays == 0
+    assert torch.equal(a.engine.pflat, b.engine.pflat) and torch.equal(a.engine.sflat, b.engine.sflat)
+    assert torch.equal(a.engine.mflat, b.engine.mflat) and torch.equal(a.engine.vflat, b.engine.vflat)
+    # assigning the value a switch already has keeps the tapes; a regrown scratch buffer drops them
+    n = len(a.engine._tapes)
+    assert n > 0
+    a.engine.stats_per_wg = True
+    assert len(a.engine._tapes) == n
+    a.engine.buf('tape_test_scratch', 16)
+    assert len(a.engine._tapes) == n             # a NEW buffer moves nothing
+    a.engine.buf('tape_test_scratch', 1 << 20)
+    assert not a.engine._tapes
