@@ -800,10 +800,14 @@ extern "C" int dc_conv3x3_bwd_joint_f16x3(const float* x, const float* in_sc, co
   p.redZ = red_z; p.redMean = red_mean; p.redInvstd = red_invstd; p.redGamma = red_gamma; p.redBeta = red_beta;
   p.bnPartial = bn_partial; p.bnAmax = amax_partial; p.slabs = ws;
   p.N = N; p.H = H; p.W = W; p.tilesX = dc_cdiv(W, bj::TW); p.tilesY = dc_cdiv(H, bj::TH);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  const bool bracket = dc_take_bracket(&ev0, &ev1);          // dc_bracket_next_launch: the matrix kernel without the slab reduction
+  if (bracket && ev0) (void)hipEventRecord(ev0, (hipStream_t)stream);
   if (Cin == bj::C)
     hipLaunchKernelGGL(bwd_joint32_kernel, dim3((unsigned)grid), dim3(bj::THREADS), bj::LDS_BYTES, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL(bwd_joint64_kernel, dim3((unsigned)grid), dim3(bj::THREADS), bj64::LDS64, (hipStream_t)stream, p);
+  if (bracket && ev1) (void)hipEventRecord(ev1, (hipStream_t)stream);
   DC_CHECK_LAUNCH("dc_conv3x3_bwd_joint_f16x3");
   const long L = 9L * Cin * Cout;
   return dc_reduce_partials(ws, grid, L, 1.0f, dw, ws + (long)grid * L, stream);

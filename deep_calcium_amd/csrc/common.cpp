@@ -32,6 +32,18 @@ extern "C" int dc_event_create(void** ev) {
   *ev = (void*)e;
   return DC_OK;
 }
+static thread_local hipEvent_t g_bracket[2] = {nullptr, nullptr};
+extern "C" int dc_bracket_next_launch(void* ev_before, void* ev_after) {
+  g_bracket[0] = (hipEvent_t)ev_before;
+  g_bracket[1] = (hipEvent_t)ev_after;
+  return DC_OK;
+}
+bool dc_take_bracket(hipEvent_t* before, hipEvent_t* after) {
+  if (!g_bracket[0] && !g_bracket[1]) return false;
+  *before = g_bracket[0]; *after = g_bracket[1];
+  g_bracket[0] = g_bracket[1] = nullptr;
+  return true;
+}
 extern "C" int dc_event_create_sync(void** ev) {
   DC_REQUIRE(ev, DC_EINVAL, "dc_event_create_sync: null");
   hipEvent_t e;

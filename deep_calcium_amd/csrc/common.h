@@ -58,6 +58,9 @@ static inline int dc_func_max_lds(DcLdsAttr& st, const void* kern, int bytes, co
   return DC_OK;
 }
 
+// dc_bracket_next_launch (dcunet.h): the pending event pair of this host thread, taken by the next entry point that honours it
+bool dc_take_bracket(hipEvent_t* before, hipEvent_t* after);
+
 static inline int dc_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool dc_is_pow2(long v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline bool dc_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -385,8 +385,12 @@ int dc_conv3x3_c1_wgrad(const float* x, const float* dz, float* dw, float* ws, i
   const int blocks = c1_blocks(pixels, Cout);
   const bool fast = (W % 4 == 0) && dc_aligned16(x) && pixels < (1L << 31);
   const float* none = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  const bool bracket = dc_take_bracket(&ev0, &ev1);          // dc_bracket_next_launch
+  if (bracket && ev0) (void)hipEventRecord(ev0, st);
   hipLaunchKernelGGL(fast ? conv_c1_wgrad4_kernel<false> : conv_c1_wgrad_kernel<false>, dim3(blocks), dim3(256), 0, st, x, dz,
                      ws, N, H, W, Cout, pixels, none, none);
+  if (bracket && ev1) (void)hipEventRecord(ev1, st);
   DC_CHECK_LAUNCH("dc_conv3x3_wgrad(Cin=1)");
   const long L = 9L * Cout;
   return dc_reduce_partials(ws, blocks, L, 1.0f, dw, ws + (long)blocks * L, (dc_stream_t)st);
@@ -400,8 +404,12 @@ int dc_conv3x3_c1_wgrad_dzin(const float* x, const float* da, const float* z, co
   const long pixels = (long)N * H * W;
   const int blocks = c1_blocks(pixels, Cout);
   const bool fast = (W % 4 == 0) && dc_aligned16(x) && pixels < (1L << 31);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  const bool bracket = dc_take_bracket(&ev0, &ev1);          // dc_bracket_next_launch
+  if (bracket && ev0) (void)hipEventRecord(ev0, st);
   hipLaunchKernelGGL(fast ? conv_c1_wgrad4_kernel<true> : conv_c1_wgrad_kernel<true>, dim3(blocks), dim3(256), 0, st, x, da,
                      ws, N, H, W, Cout, pixels, z, dz_coef);
+  if (bracket && ev1) (void)hipEventRecord(ev1, st);
   DC_CHECK_LAUNCH("dc_conv3x3_wgrad_dzin(Cin=1)");
   const long L = 9L * Cout;
   return dc_reduce_partials(ws, blocks, L, 1.0f, dw, ws + (long)blocks * L, (dc_stream_t)st);

@@ -24,8 +24,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // first wave stores s_memtime when its work of a step is done and again when the step's barrier has released it.
 // DC_PP_ABL (debug builds only, scripts/igemm_pp_ablate.py): bit 0 no epilogue work (the compiler then drops the MFMAs
 // too: unusable), bit 1 producers do not split / write LDS, bit 2 consumers read their fragments once per step, bit 3
-// producers do not load, bit 4 two more stamps per consumer step (tile setup done, first fragments landed).  Results are
-// garbage for bits 0-3.
+// producers do not load, bit 4 two more stamps per consumer step (tile setup done, first fragments landed), bit 5 the producers
+// write the raw fp32 bits instead of the fp16 split (the LDS traffic of a PRE-SPLIT operand, none of its VALU).  Results are
+// garbage for bits 0-3 and 5.
 #ifndef DC_PP_ABL
 #define DC_PP_ABL 0
 #endif
@@ -334,7 +335,12 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
             }
           }
           u32x2 hi, lo;
-          split(v, in_scale, hi, lo);
+          if (DC_PP_ABL & 32) {      // ablation: what an operand stored PRE-SPLIT in HBM would leave -- the same LDS writes, no split VALU
+            hi = u32x2{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1])};
+            lo = u32x2{__builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
+          } else {
+            split(v, in_scale, hi, lo);
+          }
           char* base = st + ((a_g >> 1) * PS + pix) * 16 + (a_g & 1) * 8;
           *reinterpret_cast<u32x2*>(base) = hi;
           *reinterpret_cast<u32x2*>(base + G8 * PS * 16) = lo;

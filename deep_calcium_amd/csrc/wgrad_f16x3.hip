@@ -29,7 +29,8 @@
 // Experiment switches (scripts/wgrad_variants.py builds copies of the library with them; the shipped build uses the defaults).
 // DC_WG_ABL (ablation builds only, results are garbage): bit 0 producers stage only the first two tiles (no split / LDS
 // writes in the loop), bit 1 producers request only the first two tiles (no global loads in the loop), bit 2 consumers
-// issue no fragment reads / MFMAs (producers alone), bit 3 no slab store.  DC_WG_CLOCK: wave 0 of workgroup 0 stamps
+// issue no fragment reads / MFMAs (producers alone), bit 3 no slab store, bit 4 the producers write the raw fp32 bits instead of
+// the fp16 split (what a PRE-SPLIT operand would cost: the LDS writes without the VALU).  DC_WG_CLOCK: wave 0 of workgroup 0 stamps
 // s_memtime / s_memrealtime around its loop (dc_debug_wgrad_stamps): the clock the chip holds in this kernel.
 #ifndef DC_WG_ABL
 #define DC_WG_ABL 0
@@ -112,6 +113,11 @@ __device__ __forceinline__ f16x8 tr_frag(const char* base, int off1, int off2) {
 // hi = fp16(x*s), lo = fp16(x*s - hi): two v_fma_mix per element (see split_f16 in igemm_f16x3.hip)
 template <bool SCALED>
 __device__ __forceinline__ void split4_f16(const f32x4 v, float s, u32x2& hi, u32x2& lo) {
+  if (DC_WG_ABL & 16) {      // ablation: an operand stored PRE-SPLIT in HBM -- the same LDS writes, none of the split VALU
+    hi = u32x2{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1])};
+    lo = u32x2{__builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
+    return;
+  }
   unsigned h01, h23, l01, l23;
   asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
       "v_fma_mixlo_f16 %1, %6, %8, 0\n\t"
@@ -504,7 +510,11 @@ static int wgrad_h_launch(const float* A, const float* B, float* dw, float* ws, 
   hp.xAbound = xAbound; hp.xChannels = A_SCALED ? Cn : Cm;
   hp.bZ = bZ; hp.dzCoef = dzCoef;
   dim3 grid((unsigned)(pl.splits * dc_cdiv(Cm, Cfg::CM) * dc_cdiv(Cn, Cfg::CN)));
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  const bool bracket = dc_take_bracket(&ev0, &ev1);
+  if (bracket && ev0) (void)hipEventRecord(ev0, st);
   hipLaunchKernelGGL(kern, grid, dim3(512), Cfg::LDS_BYTES, st, hp);
+  if (bracket && ev1) (void)hipEventRecord(ev1, st);
   DC_CHECK_LAUNCH(name);
   const long L = (long)KH * KW * Cm * Cn;
   return dc_reduce_partials(ws, pl.splits, L, 1.0f, dw, ws + (long)pl.splits * L, (dc_stream_t)st);
@@ -536,6 +546,20 @@ long dc_convT2x2_wgrad_f16x3_ws(int N, int H, int W, int Cin, int Cout) {
 
 int dc_conv3x3_c1_wgrad(const float* x, const float* dz, float* dw, float* ws, int N, int H, int W, int Cout,
                         hipStream_t st);
+
+// the symbol of the instantiation CONV_H_DISPATCH picks, spelled as rocprofv3 prints it
+template <int KH, int KW, int S, int PAD, int TW, int RW, int WM, int WNW, int NBW>
+static const char* wgrad_h_name(int dzin) {
+  static thread_local char buf[2][96];
+  snprintf(buf[dzin ? 1 : 0], sizeof(buf[0]), "wgrad_f16x3_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d,false,%s>", KH, KW, S, PAD, TW, RW, WM, WNW, NBW,
+           dzin ? "true" : "false");
+  return buf[dzin ? 1 : 0];
+}
+extern "C" const char* dc_conv3x3_wgrad_kernel_name(int N, int H, int W, int Cin, int Cout, int dzin) {
+  (void)N; (void)H;
+  if (Cin == 1) return dzin ? "conv_c1_wgrad4_kernel<true>" : "conv_c1_wgrad4_kernel<false>";
+  CONV_H_DISPATCH(wgrad_h_name, >(dzin))
+}
 
 static int check_h(const char* fn, const void* a, const void* b, const void* c, const void* d, int N, int H, int W,
                    int Cin, int Cout) {

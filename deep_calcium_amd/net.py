@@ -298,7 +298,15 @@ class UNetEngine(object):
         self.ar_buckets = 1 if os.environ.get('DC_AR_BUCKETS', '3') == '1' else 3      # gradient exchange: one all-reduce or three ranges
         self._tapes = {}
         self._tape_epoch = 0
+        self.ar_probe = None
         self.tape_replays = 0
+        # The weight-gradient stream exists (and has been used once) from construction: HIP multiplexes its streams onto
+        # GPU_MAX_HW_QUEUES hardware queues in first-use order, and a side stream first used after the collective library has made its
+        # own streams can land on the MAIN stream's queue -- the two then serialise (measured: +0.7...1.0 ms per step; scripts/queue_timeline.py
+        # shows every launch on one queue).  deep_calcium_amd/__init__.py also raises GPU_MAX_HW_QUEUES to 8 when the process has not set it.
+        self._side_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.device(self.device):
+            torch.cuda.Event().record(self._side_stream)
         self._evpool, self._ev_i = [], 0
         self._evpool_f, self._evf_i = [], 0       # events with the system-scope fence: collective boundaries
         self._tail = None
@@ -483,7 +491,7 @@ class UNetEngine(object):
     # can move a buffer a tape points into (buf() regrow, set_crop_sources, a new side stream).
     _TAPE_STATE = frozenset(('range_guard', 'bnin', 'dzin', 'dzin_lvls', 'dzin_all', 'joint', 'stats_per_wg', 'tail_main',
                              'dz_writeback', 'deep_slots', 'FOLD_MIN', 'bn_mode', 'streams', 'mfma', 'upsampling', 'up_drop',
-                             'infer_measured', 'SLOTS', 'SLOTS_DEEP', 'SLOTS_DEEP_MAX_BYTES', '_side_stream', '_comm_stream', 'nm', 'use_tapes',
+                             'infer_measured', 'SLOTS', 'SLOTS_DEEP', 'SLOTS_DEEP_MAX_BYTES', '_side_stream', 'nm', 'use_tapes',
                              'ar_buckets'))
 
     def __setattr__(self, name, value):
@@ -725,6 +733,14 @@ class UNetEngine(object):
             else:
                 A['bb'] = new(N, h, w, c)
         A['p'] = new(N, self.H, self.W)
+        # split-K slabs of the narrow (16^2 / 8^2) conv layers of a small-window forward -- inference, validation stripes, predict():
+        # these run on the caller's stream like the training forward, which has its own copy in _train_bufs
+        sk = 0
+        if self.mfma == 'f16x3':
+            for l in self.layers:
+                if l.kind == 'conv' and l.cin > 1:
+                    sk = max(sk, self.L.dc_conv3x3_splitk_ws_floats(N, *self._hw(l.lvl), l.cin, l.cout, 0))
+        A['splitk_ws'] = new(sk) if sk > 0 else None
         self._bufs[key] = A
         return A
 
@@ -774,19 +790,27 @@ class UNetEngine(object):
 
     @_on_device
     def forward_infer(self, x_dev):
-        """x_dev: float32 cuda tensor (N,H,W) -> p: (N,H,W) probabilities (BN folded into the conv epilogue)."""
+        """x_dev: float32 cuda tensor (N,H,W) -> p: (N,H,W) probabilities (BN folded into the conv epilogue).  A steady-state
+        forward is a fixed launch sequence: recorded once per (batch, mode, stream) and replayed from C like a train step (_taped)."""
         N = x_dev.shape[0]
         self._check_input('x', x_dev, torch.float32)
+        A = self._acts(N)
+        key = ('infer', N, self._stream(), bool(self.infer_measured), self._packed_dirty, self._fold_dirty)
+        return self._taped(key, lambda: self._forward_infer_body(x_dev, N, A), lambda: {'x': _ptr(x_dev)},
+                           post_attrs=('_packed_dirty', '_fold_dirty'))
+
+    def _forward_infer_body(self, x_dev, N, A):
         L, st = self.L, self._stream()
+        xp = self._v('x', _ptr(x_dev))
         self.repack()
         self.refold()
-        A = self._acts(N)
         if self.mfma == 'f16x3' and self.range_guard:
             if self.infer_measured:
-                self.abound.zero_()       # the conv epilogues fold the measured max |a| per channel into it
+                L.dc_fill(self.abound.data_ptr(), self.abound.numel(), 0.0, st)   # the conv epilogues fold the measured max |a| per channel into it
             else:
-                self._ovf.zero_()         # optimistic: they only raise this flag (forward_infer_checked looks at it)
+                L.dc_fill(self._ovf.data_ptr(), self._ovf.numel(), 0.0, st)       # optimistic: they only raise this flag (forward_infer_checked looks at it)
         plan = self._plan(A)
+        sk = _ptr(A['splitk_ws']) if A.get('splitk_ws') is not None else None
         pooled_by_conv = False
         for si, step in enumerate(plan):
             if step[0] == 'pool':
@@ -805,7 +829,7 @@ class UNetEngine(object):
             _, l, src, dst, coff, ld, h, w, _prod = step
             sc, sh = self.stat_ptr(l, 2), self.stat_ptr(l, 3)
             if l.kind == 'conv' and l.cin == 1:
-                L.dc_conv3x3_c1_fwd(_ptr(x_dev), self.pview(self.pflat, l, 'k'), None, _ptr(dst, coff), ld, None,
+                L.dc_conv3x3_c1_fwd(xp, self.pview(self.pflat, l, 'k'), None, _ptr(dst, coff), ld, None,
                                     sc, sh, 1, *self._ab_infer(l)[2:], N, h, w, l.cout, st)
             elif l.kind == 'conv':
                 nxt = plan[si + 1] if si + 1 < len(plan) else None
@@ -818,7 +842,7 @@ class UNetEngine(object):
                                                 _ptr(A['pool%d' % nxt[1]]), N, h, w, l.cin, l.cout, st)
                     pooled_by_conv = True
                     continue
-                self._conv_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h, w, st, measured=True)
+                self._conv_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h, w, st, measured=True, splitk=sk)
             else:
                 self._convT_fwd(_ptr(src), l, None, _ptr(dst, coff), ld, None, sc, sh, 1, N, h // 2, w // 2, st, measured=True)
         lo = self.by_name['out']
@@ -1256,8 +1280,6 @@ class UNetEngine(object):
         if comm is not None:
             if bucket_cb is not None:
                 raise ValueError('backward: pass bucket_cb (the caller issues the collectives) OR comm (dc_comm_* from here), not both')
-            if getattr(self, '_comm_stream', None) is None:
-                self._comm_stream = torch.cuda.Stream(device=self.device)
 
         def body():
             return self._backward_body(bucket_cb, defer_tail, comm)
@@ -1545,19 +1567,18 @@ class UNetEngine(object):
                                      red=red_of(l_up))
             state['g'] = kn
 
-        ch = self._comm_stream.cuda_stream if comm is not None else None
-
         def bucket_done(i):
             if comm is not None:
-                # the collective through the C ABI, on its own stream, recorded like any launch (no cut in the tape): the range is
-                # final once BOTH queues have reached this point -- weight gradients on the side stream, dbias / dgamma / dbeta /
-                # head gradients on the main one; the events carry the system-scope fence (a peer reads gflat over xGMI)
+                # the collective through the C ABI, recorded like any launch (no cut in the tape), on the WEIGHT-GRADIENT stream: that
+                # queue idles ~4 ms of a step, and a stream of its own would be one more HIP stream competing for the 4 hardware queues
+                # (measured: with a third stream the side stream landed on the main stream's queue and the step serialised, +1.0 ms).
+                # The range is final once BOTH queues have reached this point -- weight gradients here, dbias / dgamma / dbeta / head
+                # gradients on the main stream; that event carries the system-scope fence
                 if self.ar_buckets > 1:
-                    self._wait_stream(ch, mh, fenced=True)
                     if two:
-                        self._wait_stream(ch, sh_, fenced=True)
+                        self._wait_stream(sh_, mh, fenced=True)
                     lo, hi = self.grad_buckets()[i]
-                    L.dc_comm_all_reduce_sum(comm, _ptr(self.gflat, lo), hi - lo, ch)
+                    L.dc_comm_all_reduce_sum(comm, _ptr(self.gflat, lo), hi - lo, sh_)
                 return
             if bucket_cb is None:
                 return
@@ -1608,14 +1629,23 @@ class UNetEngine(object):
                 kn = g_next()
                 block_bwd(la, _ptr(A['pool%d' % (lvl - 1)]), _ptr(gb[ko]), c, _ptr(gb[kn]), fused=fa, da_g=ko)
                 state['g'] = kn
-        if two and self._tail is None:
-            self._wait_stream(mh, sh_, fenced=bucket_cb is not None)    # gflat is complete once both streams have drained
         if comm is not None:
             # the last range (the encoder's: 15 % of the bytes, the only exposed part) -- or, with one bucket, everything
-            self._wait_stream(ch, mh, fenced=True)
+            probe = getattr(self, 'ar_probe', None) if not L.recording() else None
+            if probe is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+            if two:
+                self._wait_stream(sh_, mh, fenced=True)
             lo, hi = self.grad_buckets()[-1] if self.ar_buckets > 1 else (0, self.n_train)
-            L.dc_comm_all_reduce_sum(comm, _ptr(self.gflat, lo), hi - lo, ch)
-            self._wait_stream(mh, ch, fenced=True)      # Adam (main stream) reads the reduced gradient
+            L.dc_comm_all_reduce_sum(comm, _ptr(self.gflat, lo), hi - lo, sh_)
+            if two:
+                self._wait_stream(mh, sh_, fenced=True)      # Adam (main stream) reads the reduced gradient
+            if probe is not None:
+                e1.record(main)
+                probe.append((e0, e1))
+        elif two and self._tail is None:
+            self._wait_stream(mh, sh_, fenced=bucket_cb is not None)    # gflat is complete once both streams have drained
 
     def _join_side(self):
         side = getattr(self, '_side_stream', None)

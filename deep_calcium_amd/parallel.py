@@ -144,8 +144,20 @@ def shard_slice(global_batch, r=None, ws=None):
 
 
 def all_reduce_sum(t):
-    if exchange_active():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    """In-place sum over the ranks, ordered on the CURRENT stream of t's device: through dc_comm_all_reduce_sum[_f64] (RCCL behind
+    the C ABI) for contiguous fp32 / fp64 device tensors when the native communicator is up, else torch.distributed."""
+    if not exchange_active():
+        return t
+    if t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.float64) and t.numel() > 0:
+        comm = native_comm(t.device)
+        if comm is not None:
+            from ._lib import lib
+            L = lib()
+            with torch.cuda.device(t.device):
+                st = torch.cuda.current_stream(t.device).cuda_stream
+                (L.dc_comm_all_reduce_sum if t.dtype == torch.float32 else L.dc_comm_all_reduce_sum_f64)(comm, t.data_ptr(), t.numel(), st)
+            return t
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
@@ -188,7 +200,7 @@ def sync_moving_stats(sflat):
     the collective, the 1/G a libdcunet launch (no torch arithmetic on device tensors in the product path; a CPU tensor --
     the gloo plumbing test -- is scaled in place)."""
     if exchange_active():
-        dist.all_reduce(sflat, op=dist.ReduceOp.SUM)
+        all_reduce_sum(sflat)
         if sflat.is_cuda:
             from ._lib import lib
             with torch.cuda.device(sflat.device):

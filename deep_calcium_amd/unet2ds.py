@@ -591,12 +591,30 @@ class UNet2DSummary(object):
                 items[i] = (offs[k] + y0 * wk + x0, wk, (max(y1 - y0, 0) << 32) | max(x1 - x0, 0), _D4_BITS[id(_compose_six(augs))])
             yield DeviceBatch(items, hw)
 
+    _PREDICT_CACHE_MAX = 2
+
+    def _predict_model(self, model_path, window_shape):
+        """The inference model of predict(): the reference re-reads the model file on every call (unet_2d_summary.py:560-561);
+        here the loaded model -- parsed weights, device buffers, folded BatchNorm, the resident TTA gather maps -- is kept per
+        (file identity, window) and reused while the file is unchanged (same path, size and modification time).  predict() never
+        changes a model's weights, so a cached one IS what a fresh load would give."""
+        st = os.stat(model_path)
+        key = (os.path.realpath(model_path), st.st_mtime_ns, st.st_size, tuple(window_shape))
+        cache = self.__dict__.setdefault('_predict_models', [])
+        for i, (k, m) in enumerate(cache):
+            if k == key:
+                cache.append(cache.pop(i))            # most recently used last
+                return m
+        model = load_model_with_new_input_shape(model_path, window_shape, compile=False, custom_objects=self.custom_objects)
+        cache.append((key, model))
+        del cache[:-self._PREDICT_CACHE_MAX]
+        return model
+
     def predict(self, dataset_paths, model_path, window_shape=(512, 512), print_scores=False, save=False,
                 augmentation=False, threshold=0.5):
         """unet_2d_summary.py:532-625.  Returns (Mp: list of uint8 masks, names)."""
         logger = logging.getLogger('UNet2DSummary.predict')
-        model = load_model_with_new_input_shape(model_path, window_shape, compile=False,
-                                                custom_objects=self.custom_objects)
+        model = self._predict_model(model_path, window_shape)
         assert tuple(window_shape) == (512, 512), 'TODO: implement variable window sizes.'   # as the reference (:565)
         _, hw, ww = model.input_shape
         Mp, names = [], []

@@ -468,6 +468,13 @@ int dc_scale_flat(float* p, long n, float s, dc_stream_t stream);
  * these wrap hipEventCreate/Record/Synchronize/ElapsedTime on the given stream (so bench.py measures on the
  * stream the kernels are launched on). */
 int dc_event_create(void** ev);
+/* measurement hook (bench.py's per-kernel timer): the NEXT conv3x3 weight-gradient / joint-backward entry point called from THIS host
+ * thread records ev_before right in front of its matrix kernel and ev_after right behind it, on the launch stream -- i.e. without
+ * the slab-reduction launches that follow inside the same entry point (what rocprofv3 reports for that kernel symbol).  One shot. */
+int dc_bracket_next_launch(void* ev_before, void* ev_after);
+/* the kernel symbol (as rocprofv3 prints it, template arguments included) a conv3x3 weight-gradient launch of this shape runs:
+ * dzin != 0 for dc_conv3x3_wgrad_dzin_f16x3, else dc_conv3x3_wgrad_f16x3 / _bnin.  Routing only, no launch. */
+const char* dc_conv3x3_wgrad_kernel_name(int N, int H, int W, int Cin, int Cout, int dzin);
 /* an event for stream ordering on ONE device only (hipEventDisableTiming | hipEventDisableSystemFence): what the engine's two-stream
  * backward hands between its streams.  Not for host synchronisation (no system-scope fence at the marker). */
 int dc_event_create_sync(void** ev);

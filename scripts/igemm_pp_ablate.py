@@ -21,12 +21,15 @@ def build(mask):
     return lib
 
 
-def make_run(L, variant, HW, Ci, Co, N=16):
+def make_run(L, variant, HW, Ci, Co, N=16, presplit=False):
     """One conv3x3 launch of the role-split kernel as a closure: variant 0 forward without BatchNorm partials (<*,*,0>), 3 forward
     with per-workgroup partial rows (<*,*,3>), 1 data gradient that also emits BatchNorm-backward sums (<*,*,1>).  Returns
     (run, keep-alive tensors)."""
     import torch
     x = torch.randn(N, HW, HW, Ci, device='cuda')
+    if presplit:                       # -DDC_PP_ABL=32: the same values stored as fp16 (hi, lo) pairs
+        from scripts._presplit import presplit_pack
+        x = presplit_pack(x)
     K = torch.randn(3, 3, Ci, Co, device='cuda') * 0.05
     wp16 = torch.empty(L.dc_pack_weights_f16x3_floats(9, Ci, Co), device='cuda')
     L.dc_pack_weights_f16x3(K.data_ptr(), wp16.data_ptr(), 9, Ci, Co, Ci * Co, Co, 1, 0, None)
@@ -61,7 +64,7 @@ def worker(lib_path, HW, Ci, Co, mask=0, variant=3):
     from deep_calcium_amd._lib import lib
     L = lib()
     N = 16
-    run, keep = make_run(L, variant, HW, Ci, Co, N)
+    run, keep = make_run(L, variant, HW, Ci, Co, N, presplit=bool(mask & 32))
     trace = torch.zeros(8 * 3 * 512, dtype=torch.int64, device='cuda')
     fn = L.cdll.dc_debug_set_pp_trace
     fn.argtypes = [ctypes.c_void_p]
@@ -123,10 +126,10 @@ if __name__ == '__main__':
     HW, Ci, Co, variant = sys.argv[1:5]
     masks = [int(m) for m in sys.argv[5:]] or [0, 2, 4, 8, 10, 14, 16]
     names = {0: 'full kernel', 1: 'no epilogue', 2: 'no split / LDS writes', 4: 'fragments read once per step', 8: 'no global loads',
-             16: 'detail stamps'}
+             16: 'detail stamps', 32: 'raw bits instead of the fp16 split (a pre-split operand)'}
     for m in masks:
         lib = build(m)
-        label = ' + '.join(names[b] for b in (1, 2, 4, 8, 16) if m & b) or names[0]
-        print('%-60s' % label, end=' ', flush=True)
+        label = ' + '.join(names[b] for b in (1, 2, 4, 8, 16, 32) if m & b) or names[0]
+        print('%-60s' % label, flush=True)
         subprocess.run([sys.executable, os.path.abspath(__file__), '--worker', lib, HW, Ci, Co, str(m), variant], check=True,
                        env=dict(os.environ, DC_LIB_PATH=lib))      # read when the package is imported

@@ -82,18 +82,21 @@ def main():
         import os
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
         import bench
-        kname = bench.KernelTimer.KERNELS['f16x3'][0]
-        r = [r for r in rows if r['kernel'].replace(' ', '') == kname.replace(' ', '')]
-        if not r:
-            raise SystemExit('kernel %s not in the trace' % kname)
-        r = r[0]
-        out = dict(kernel=kname, kernel_source_sha=bench.kernel_source_sha(),
-                   bytes_per_launch=int((r['fetch_MB'] + r['write_MB']) * 1e6), fetch_bytes_per_launch=int(r['fetch_MB'] * 1e6),
-                   write_bytes_per_launch=int(r['write_MB'] * 1e6), launches=r['launches'], mean_us=r['mean_us'],
-                   mfma_busy_frac=r['mfma_util'],
+        # every kernel bench.py's timer may name as the dominant one (it reports the symbol with the largest total time of ITS run):
+        # the role-split conv instantiations, the weight gradients, the joint backward kernels
+        want = [r for r in rows if r['kernel'].startswith(('igemm_pp_kernel', 'wgrad_f16x3_kernel', 'bwd_joint', 'igemm_kernel', 'conv_c1_wgrad'))]
+        if not want:
+            raise SystemExit('no matrix kernel in the trace')
+        kern = {}
+        for r in want:
+            kern[r['kernel'].replace(' ', '')] = dict(
+                bytes_per_launch=int((r['fetch_MB'] + r['write_MB']) * 1e6), fetch_bytes_per_launch=int(r['fetch_MB'] * 1e6),
+                write_bytes_per_launch=int(r['write_MB'] * 1e6), launches=r['launches'], mean_us=r['mean_us'],
+                mfma_busy_frac=r['mfma_util'])
+        out = dict(kernel=want[0]['kernel'].replace(' ', ''), kernel_source_sha=bench.kernel_source_sha(), kernels=kern,
                    method='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (scripts/pmc_passes.sh); KiB counters; '
                           'FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md '
-                          'section HBM); WRITE_SIZE as is',
+                          'section HBM); WRITE_SIZE as is; single stream, one train step per pass',
                    source=root)
         json.dump(out, open(sys.argv[sys.argv.index('--traffic') + 1], 'w'), indent=1)
 

@@ -41,10 +41,11 @@ class Probe(Callback):
     def on_epoch_end(self, epoch, logs=None):
         torch.cuda.synchronize()
         now = time.time()
-        print('epoch %d: %.1f steps/s incl. validation (%.2f ms/step: steps %.1f ms + epoch end %.1f ms), loss %.4f F1 %.3f val_nf_f1 %.3f | device %.2f GB allocated, %.2f GB reserved, host RSS %.2f GB'
+        rss_now = int(open('/proc/self/statm').read().split()[1]) * os.sysconf('SC_PAGE_SIZE') / 2 ** 30     # CURRENT resident set
+        print('epoch %d: %.1f steps/s incl. validation (%.2f ms/step: steps %.1f ms + epoch end %.1f ms), loss %.4f F1 %.3f val_nf_f1 %.3f | device %.2f GB allocated, %.2f GB reserved, host RSS now %.3f GB (peak %.2f GB)'
               % (epoch, steps / (now - self.t), (now - self.t) / steps * 1e3, (self.t_steps - self.t) * 1e3, (now - self.t_steps) * 1e3,
                  logs['loss'], logs['F1'], logs.get('val_nf_f1_mean', float('nan')),
-                 torch.cuda.memory_allocated() / 2 ** 30, torch.cuda.memory_reserved() / 2 ** 30,
+                 torch.cuda.memory_allocated() / 2 ** 30, torch.cuda.memory_reserved() / 2 ** 30, rss_now,
                  resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20), flush=True)
 
 

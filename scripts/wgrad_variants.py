@@ -19,6 +19,7 @@ VARIANTS = [
     ('abl_loads_alone', ['-DDC_WG_ABL=5']),
     ('abl_noslab', ['-DDC_WG_ABL=8']),
     ('abl_mfma_only', ['-DDC_WG_ABL=11']),
+    ('abl_presplit', ['-DDC_WG_ABL=16']),
     ('prio1', ['-DDC_WG_PRIO=1']),
     ('prio3', ['-DDC_WG_PRIO=3']),
     ('depth2', ['-DDC_WG_DEPTH=2']),
@@ -46,6 +47,9 @@ def worker(tag):
         g = torch.Generator(device='cuda'); g.manual_seed(HW * 7 + Ci)
         x = torch.randn(N, HW, HW, Ci, device='cuda', generator=g)
         dz = torch.randn(N, HW, HW, Co, device='cuda', generator=g)
+        if tag == 'abl_presplit':       # the same VALUES, stored pre-split: the kernel's MFMA operands (and dW) are those of the base run
+            from scripts._presplit import presplit_pack
+            x, dz = presplit_pack(x), presplit_pack(dz)
         dw = torch.empty(3, 3, Ci, Co, device='cuda')
         ws = torch.empty(L.dc_conv3x3_wgrad_ws_floats(N, HW, HW, Ci, Co), device='cuda')
         run = lambda: L.dc_conv3x3_wgrad_f16x3(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), None, None, N, HW, HW, Ci, Co, None)
@@ -62,18 +66,18 @@ def worker(tag):
         st = (ctypes.c_ulonglong * 4)()
         fn(ctypes.addressof(st))
         cyc, rt, nt, groups = [int(v) for v in st]
-        clock = cyc / (rt * 10.0) if rt else 0.0                 # s_memrealtime ticks at 100 MHz: MHz = cycles / (ticks * 10 ns) ...
+        clock = cyc / (rt * 10.0) if rt else 0.0                 # GHz: s_memrealtime ticks every 10 ns
         busy = nt * groups * 3 * 32.0 / cyc if cyc else 0.0
         ref = os.path.join('/tmp', 'wg_ref_%d_%d_%d.npy' % (HW, Ci, Co))
         d = dw.cpu().numpy()
         if tag == 'base': np.save(ref, d)
         err = ''
-        if os.path.exists(ref) and not tag.startswith('abl'):
+        if os.path.exists(ref) and (not tag.startswith('abl') or tag == 'abl_presplit'):
             r = np.load(ref)
             err = 'max|d-base|/max|base| %.1e' % (np.abs(d - r).max() / np.abs(r).max())
         tf = 2.0 * 9 * Ci * Co * N * HW * HW / us / 1e6
         out.append('%4d^2 %3d->%3d: %7.1f us %6.1f TF/s-alg | loop %8d cyc, clock %5.2f GHz, MFMA issue %4.1f %% of the loop | %s'
-                   % (HW, Ci, Co, us, tf, cyc, clock / 100.0, 100 * busy, err))
+                   % (HW, Ci, Co, us, tf, cyc, clock, 100 * busy, err))
     print('%-22s' % tag + ('\n' + ' ' * 22).join(out), flush=True)
 
 

@@ -264,3 +264,38 @@ def test_pipelined_predict_equals_one_by_one(aug, monkeypatch):
             p = ref_eng.forward_infer_checked(torch.from_numpy(im[None]).cuda()).cpu().numpy()[0, :hs, :ws]
             assert np.array_equal(got[i], (p > thr).astype(np.uint8))
     assert eng.tta_begin(0, table).finish() == []
+
+
+def test_predict_reuses_the_loaded_model_until_the_file_changes(tmp_path):
+    """predict() (unet_2d_summary.py:560-561 re-reads the model file on every call) keeps the loaded model per (path, size,
+    modification time, window): repeated calls give the same masks from the SAME engine with its forward replayed from a tape, a
+    rewritten file is loaded afresh, and taped forwards equal launch-by-launch ones bit for bit."""
+    import time
+    from deep_calcium_amd import UNet2DSummary
+    from deep_calcium_amd.model import Model
+    paths = _make_datasets(tmp_path, n=3)
+    api = UNet2DSummary(cpdir=str(tmp_path))
+    m = Model((512, 512), 8)
+    mp = str(tmp_path / 'm.hdf5')
+    m.save(mp, include_optimizer=False)
+    first, _ = api.predict(paths, mp, augmentation=True)
+    eng = api._predict_models[-1][1].engine
+    for _ in range(3):
+        again, _ = api.predict(paths, mp, augmentation=True)
+        assert api._predict_models[-1][1].engine is eng and len(api._predict_models) == 1
+        assert all(np.array_equal(a, b) for a, b in zip(first, again))
+    assert eng.tape_replays > 0                                    # 12 batch-8 forwards: two recordings, the rest replayed
+    eng.use_tapes = False
+    untaped, _ = api.predict(paths, mp, augmentation=True)
+    assert all(np.array_equal(a, b) for a, b in zip(first, untaped))
+    # another set of weights under the same path: picked up (size / mtime differ), and the masks change
+    W = m.get_weights()
+    m.set_weights([w + np.float32(0.05) * np.sign(w) if w.ndim == 4 else w for w in W])
+    time.sleep(0.02)
+    m.save(mp, include_optimizer=False)
+    os.utime(mp, ns=(time.time_ns(), time.time_ns()))
+    changed, _ = api.predict(paths, mp, augmentation=True)
+    assert api._predict_models[-1][1].engine is not eng
+    fresh, _ = UNet2DSummary(cpdir=str(tmp_path)).predict(paths, mp, augmentation=True)
+    assert all(np.array_equal(a, b) for a, b in zip(changed, fresh))
+    assert any(not np.array_equal(a, b) for a, b in zip(changed, first))

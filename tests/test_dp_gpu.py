@@ -209,7 +209,10 @@ def test_bench_default_line_schema():
     # 2 instrumented steps x the 12 launches per step that dispatch igemm_pp_kernel<2,2,0,false>: the 7 training-forward convolutions
     # of levels 3-4 with > 32 output columns and >= 64 input channels + the 5 plain data gradients (round 5: the 7 forward
     # convolutions of levels 1-2 merge their BatchNorm partials per workgroup: instantiation <2,2,3,false>, tallied separately)
-    assert rf['kernel'] == 'igemm_pp_kernel<2,2,0,false>' and rf['launches'] == 2 * 12, rf
+    # round 6: the weight gradients are timed too -- 13 launches per step of wgrad_f16x3_kernel<3,3,1,1,16,4,2,2,1,false,false> (every
+    # conv3x3 layer with Cin, Cout > 32), the trace's #1 symbol; the line names whichever symbol took more time on this box
+    assert (rf['kernel'], rf['launches']) in (('igemm_pp_kernel<2,2,0,false>', 2 * 12),
+                                              ('wgrad_f16x3_kernel<3,3,1,1,16,4,2,2,1,false,false>', 2 * 13)), rf
     assert 1.0e8 < rf['algorithmic_bytes_per_launch'] < 3.3e8
     cb = out['cpu_baseline']
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):

@@ -13,7 +13,7 @@ torch = pytest.importorskip('torch')
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SWITCHES = [('DC_MFMA', 'f32'), ('DC_STREAMS', '1'), ('DC_IGEMM_PP', '0'), ('DC_IGEMM_PP', '2'), ('DC_BNIN', '0'), ('DC_DZIN', '0'),
-            ('DC_DZIN', 'all'), ('DC_BN_MODE', 'sync'), ('DC_INFER_GUARD', '1'), ('DC_AR_BUCKETS', '1'), ('DC_TAPES', '0'), ('DC_EVENT_SYSTEM_FENCE', '1'),
+            ('DC_DZIN', 'all'), ('DC_BN_MODE', 'sync'), ('DC_INFER_GUARD', '1'), ('DC_AR_BUCKETS', '1'), ('DC_COMM', 'torch'), ('DC_TAPES', '0'), ('DC_EVENT_SYSTEM_FENCE', '1'),
             ('DC_TAIL_MAIN', '0'), ('DC_STATS_FOLD_MIN', '0'), ('DC_STATS_FOLD_MIN', '4')]
 
 
@@ -21,7 +21,7 @@ SWITCHES = [('DC_MFMA', 'f32'), ('DC_STREAMS', '1'), ('DC_IGEMM_PP', '0'), ('DC_
 def test_train_step_parity_under_switch(name, value):
     env = dict(os.environ)
     env[name] = value
-    if name == 'DC_AR_BUCKETS':          # the exchange path: a one-rank RCCL group, one blocking all-reduce
+    if name in ('DC_AR_BUCKETS', 'DC_COMM'):          # the exchange path: a one-rank RCCL group (one blocking all-reduce / torch.distributed's)
         env.update(DC_DIST_FORCE='1', DC_DIST_BACKEND='nccl', MASTER_ADDR='127.0.0.1', MASTER_PORT='29571', HSA_ENABLE_IPC_MODE_LEGACY='0')
     sel = 'test_train_forward_backward_matches_oracle and f16x3 and (2-32-32-32 or 2-64-64-32)'
     files = [os.path.join(HERE, 'test_engine_gpu.py')]
