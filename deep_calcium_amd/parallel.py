@@ -82,7 +82,8 @@ def shutdown():
         try:
             from ._lib import lib
             for h in _NATIVE.values():
-                lib().cdll.dc_comm_destroy(ctypes_void(h))
+                if h:
+                    lib().cdll.dc_comm_destroy(ctypes_void(h))
         except Exception:
             pass
         _NATIVE.clear()
@@ -105,25 +106,48 @@ def native_comm(device):
         return None
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    h = _NATIVE.get(idx)
-    if h is None:
+    h = _NATIVE.get(idx, 0)
+    if h == 0:
         import ctypes
-        from ._lib import lib, DcunetError
+        from ._lib import lib
         L = lib()
         nbytes = 128                      # DC_COMM_ID_BYTES
         buf = ctypes.create_string_buffer(nbytes)
-        if rank() == 0:
-            L.dc_comm_unique_id(buf)
-        box = [buf.raw]
+        ok, why = 1, ''
+        # can THIS rank load RCCL at all?  (an empty group start / end resolves the library; agreed on by all ranks BEFORE any of
+        # them enters the collective communicator set-up, which would otherwise wait forever for the one that cannot)
+        if L.cdll.dc_comm_group_start() != 0 or L.cdll.dc_comm_group_end() != 0:
+            ok, why = 0, L.cdll.dc_last_error().decode()
+        pre = torch.tensor([ok], dtype=torch.int32, device=torch.device('cuda', idx))
+        if world_size() > 1:
+            dist.all_reduce(pre, op=dist.ReduceOp.MIN)
+        can = int(pre.item()) == 1
+        if can and rank() == 0 and L.cdll.dc_comm_unique_id(buf) != 0:
+            ok, why = 0, L.cdll.dc_last_error().decode()
+        box = [buf.raw, ok if can else 0]
         if world_size() > 1:
             dist.broadcast_object_list(box, 0)
-        ident = ctypes.create_string_buffer(box[0], nbytes)
         comm = ctypes.c_void_p()
-        with torch.cuda.device(idx):
-            rc = L.cdll.dc_comm_init_rank(ctypes.byref(comm), ident, world_size(), rank())
-        if rc != 0:
-            raise DcunetError('dc_comm_init_rank failed (%d): %s' % (rc, L.cdll.dc_last_error().decode()))
-        h = _NATIVE[idx] = comm.value
+        if box[1]:
+            ident = ctypes.create_string_buffer(box[0], nbytes)
+            with torch.cuda.device(idx):
+                if L.cdll.dc_comm_init_rank(ctypes.byref(comm), ident, world_size(), rank()) != 0:
+                    ok, why = 0, L.cdll.dc_last_error().decode()
+        else:
+            ok = 0
+        # every rank takes the SAME path: one that cannot bring its communicator up sends all of them to torch.distributed
+        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device('cuda', idx))
+        if world_size() > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm.value:
+                L.cdll.dc_comm_destroy(comm)
+            import warnings
+            warnings.warn('dc_comm_* (RCCL through the C ABI) is not available on every rank%s: the gradient exchange goes through '
+                          'torch.distributed' % ((': ' + why) if why else ''))
+            _NATIVE[idx] = h = None
+        else:
+            h = _NATIVE[idx] = comm.value
     return h
 
 
