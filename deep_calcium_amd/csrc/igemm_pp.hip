@@ -30,6 +30,16 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #ifndef DC_PP_ABL
 #define DC_PP_ABL 0
 #endif
+// DC_PP_PF = 1 (round 6, built, bit-identical, measured, NOT adopted): the consumers take a step's barrier BEFORE its last tap (every
+// fragment of the stage is in registers by then) and, when the next step belongs to the same tile, request that step's first four
+// fragments from the other stage under the last tap's MFMAs -- meant to cover the ~350 cycles of LDS latency in front of a step's first
+// MFMA (profiles/r06_pp_ablation.txt).  Measured (profiles/r06_ab.txt): step period 4 520 -> 5 116 cycles, step 17.26 -> 17.49 ms,
+// forward only 3 412 -> 3 366 images/s.  The four fragments (16 VGPRs live across the step boundary) push the 768-thread workgroup's
+// 168-VGPR budget over the edge (3-5 registers to scratch, reloaded inside the MFMA block), and a barrier in the middle of the MFMA
+// stream stalls the pipe for the whole wait.  Round 4 had reached the same wall from the other side.
+#ifndef DC_PP_PF
+#define DC_PP_PF 0
+#endif
 #ifdef DC_PP_TIMELINE
 // per workgroup: s_memrealtime (the chip-wide 100 MHz counter) at kernel entry, barrier 0 passed, last MFMA step done, exit
 __device__ unsigned long long g_pp_timeline[1024 * 4];
@@ -115,6 +125,7 @@ struct Item {          // one output tile x column block (wave-uniform)
 template <int MB_, int NB_, int VARIANT = 0, bool DZIN = false>
 __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p) {
   constexpr bool BNRED = VARIANT == 1, POOL = VARIANT == 2, PERWG = VARIANT == 3;
+  constexpr bool PF = DC_PP_PF && !POOL;     // (the pooled-epilogue instantiation sits at the 168-VGPR budget: 34 spills with it)
   using namespace pp;
   using C = Cfg<MB_, NB_>;
   constexpr int MB = C::MB, NB = C::NB, RPM = C::RPM, TH = C::TH, BN = C::BN, THI = C::THI, TWI = C::TWI, NPIXH = C::NPIXH;
@@ -408,7 +419,10 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
   Item cur = {0, 0, 0, 0, 0}, pend = {0, 0, 0, 0, 0};
   bool pending = false;
 
-  auto mfma_block = [&](const char* st) __attribute__((always_inline)) {
+  // DC_PP_PF: the first four fragments of the NEXT step (tap 0, block (0, 0)), requested under this step's last tap
+  f16x8 pf_ah, pf_al, pf_bh, pf_bl;
+  bool have_pf = false;
+  auto mfma_block = [&](const char* st, const char* st_next, bool want_pf) __attribute__((always_inline)) {
     const u32x4* ldsA = reinterpret_cast<const u32x4*>(st);
     const u32x4* ldsB = ldsA + A_SLOTS;
     f16x8 ah[2][MB], al[2][MB], bh[2][NB], bl[2][NB];
@@ -426,7 +440,21 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
         bl[buf][nb] = __builtin_bit_cast(f16x8, ldsB[b_base + boff + BN + nb * 32]);
       }
     };
-    fetch(0, 0);
+    if (PF && have_pf) {              // block (0, 0) of tap 0 is in registers; the rest of the tap's fragments are requested now
+      ah[0][0] = pf_ah; al[0][0] = pf_al; bh[0][0] = pf_bh; bl[0][0] = pf_bl;
+#pragma unroll
+      for (int mb = 1; mb < MB; ++mb) {
+        al[0][mb] = __builtin_bit_cast(f16x8, ldsA[a_base[mb] + G8 * PS]);
+        ah[0][mb] = __builtin_bit_cast(f16x8, ldsA[a_base[mb]]);
+      }
+#pragma unroll
+      for (int nb = 1; nb < NB; ++nb) {
+        bh[0][nb] = __builtin_bit_cast(f16x8, ldsB[b_base + nb * 32]);
+        bl[0][nb] = __builtin_bit_cast(f16x8, ldsB[b_base + BN + nb * 32]);
+      }
+    } else {
+      fetch(0, 0);
+    }
     if (DC_PP_ABL & 4) fetch(0, 1);
     if (DC_PP_ABL & 16) { __builtin_amdgcn_s_waitcnt(0xc07f); PP_TRACE(); }    // detail stamp 2: first fragments landed (lgkmcnt 0)
     // Hand-ordered schedule (every statement pinned by sched_barrier): the 8 fragment reads of tap t+1 go one per gap
@@ -443,6 +471,21 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
       const int toff = ((tap + 1) / KW) * TWI + ((tap + 1) % KW);
       const int boff = ((tap + 1) * G8) * 2 * BN;
       PP_SB();
+      if (PF && tap == TAPS - 1) {
+        // every fragment of this stage has been requested (tap 8's during tap 7): once they have landed the stage may be overwritten,
+        // and the producers have completed the other one -- the step's barrier, one tap early
+        __syncthreads();
+        PP_SB();
+        if (want_pf) {
+          const u32x4* nA = reinterpret_cast<const u32x4*>(st_next);
+          const u32x4* nB = nA + A_SLOTS;
+          pf_al = __builtin_bit_cast(f16x8, nA[a_base[0] + G8 * PS]);
+          pf_bh = __builtin_bit_cast(f16x8, nB[b_base]);
+          pf_ah = __builtin_bit_cast(f16x8, nA[a_base[0]]);
+          pf_bl = __builtin_bit_cast(f16x8, nB[b_base + BN]);
+          PP_SB();
+        }
+      }
       if constexpr (MB == 2) {          // 2 x 2 blocks: 8 reads in the first 8 gaps
         PP_MFMA(0, 0, al, bh); PP_RA(al, 0, G8 * PS);
         PP_MFMA(0, 0, ah, bl); PP_RB(bh, 0, 0);
@@ -475,6 +518,7 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
 #undef PP_RB
 #undef PP_MFMA
 #undef PP_SB
+    have_pf = PF && want_pf;
   };
 
   // One 32x32 accumulator block (mb, nb) of the pending tile per slice: bias, BatchNorm partials (mode 1), inference flag
@@ -694,6 +738,7 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
   int j = 0, c = 0;
   for (int k = 0; k < K + 5; ++k) {                             // + 5: the last tile's 4 epilogue slices and its merge
     if (k == K) PP_TL(2);
+    bool did_barrier = false;                                   // DC_PP_PF: an MFMA step takes the step's barrier inside mfma_block
     if (merge_pending) epi_merge();                             // partials written one step ago (a barrier in between)
     if (k < K && (j & 1) == role) {
       if (c == 0) {
@@ -707,16 +752,22 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
       }
       if (DC_PP_ABL & 16) PP_TRACE();                           // detail stamp 1: tile setup done
       __builtin_amdgcn_s_setprio(3);                            // the wave that feeds the matrix pipe goes first
-      mfma_block(smem + (k & 1) * STAGE_BYTES);
+      mfma_block(smem + (k & 1) * STAGE_BYTES, smem + ((k + 1) & 1) * STAGE_BYTES, (c + 1 < nch) && (k + 1 < K));
       __builtin_amdgcn_s_setprio(0);
+      did_barrier = PF;
       if (c == nch - 1) { pend = cur; pending = true; }
     } else {
+      if (PF) {       // never live across an epilogue step (the next MFMA step of this set starts a tile): tell the register allocator
+        const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        pf_ah = z8; pf_al = z8; pf_bh = z8; pf_bl = z8;
+        have_pf = false;
+      }
       if (DC_PP_ABL & 16) { PP_TRACE(); PP_TRACE(); }
       if (pending && !(DC_PP_ABL & 1)) epi_slice(c);
     }
     if (++c == nch) { c = 0; ++j; }
     PP_TRACE();
-    __syncthreads();
+    if (!did_barrier) __syncthreads();
     PP_TRACE();
   }
   if constexpr (PERWG)

@@ -42,7 +42,14 @@
 #define DC_WG_PRIO 0        // s_setprio of the consumer waves
 #endif
 #ifndef DC_WG_DEPTH
-#define DC_WG_DEPTH 1       // (k-step, tap) groups the A fragments are requested ahead of their MFMAs
+#define DC_WG_DEPTH 1       // (k-step, tap) groups the A fragments are requested ahead of their MFMAs (DC_WG_XTILE=0 only)
+#endif
+#ifndef DC_WG_XTILE
+// 1: the consumers' fragments run ahead ACROSS tiles (barrier two groups before the end of a tile, the next tile's first fragments
+// requested behind it).  Built, bit-identical, measured in round 6 and NOT adopted: the loop takes MORE cycles (265 000 against
+// 258 000 per 64 tiles) and the step 17.20-17.27 against 17.10-17.18 ms -- the producers are co-critical in this kernel (their own
+// loop is 85 % of the full one), so a consumer that reaches the barrier earlier only waits there (profiles/r06_wgrad_ablation.txt).
+#define DC_WG_XTILE 0
 #endif
 #ifdef DC_WG_CLOCK
 __device__ unsigned long long g_wg_stamps[4];
@@ -391,6 +398,79 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
   unsigned long long t0c = 0, t0r = 0;
   if (blockIdx.x == 0 && tid == 0) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
 #endif
+#if DC_WG_XTILE
+  // Fragments run AHEAD ACROSS TILES.  A tile's last reads are issued RING - 1 groups before its end; the tile barrier sits right
+  // there -- "my reads of this image set have landed, the producers have finished the other set" -- and the groups that remain
+  // (their fragments already in registers) cover the LDS latency of the NEXT tile's first fragments, which are requested from the
+  // other set straight behind the barrier.  The earlier loop took the barrier at the very end of a tile and started the next one
+  // with a burst of reads nothing covered: ~350 of a tile's ~3 800 cycles (profiles/r06_wgrad_ablation.txt: consumers alone 90.7 %).
+  // Same MFMAs on the same fragments in the same order: bit-identical results.
+  constexpr int RING = (GROUPS % 3 == 0) ? 3 : ((GROUPS % 4 == 0) ? 4 : 2), DEPTH = RING - 1;
+  static_assert(GROUPS % RING == 0 && GROUPS > 2 * DEPTH, "the fragment ring must come round once per tile");
+  static_assert(KSTEPS % 2 == 0 || KSTEPS == 1, "the B fragment double buffer must come round once per tile");
+  static_assert(DEPTH <= TAPS, "the next tile's B fragments go to buffer 0: its last reader (k-step KSTEPS - 2) must be done");
+  f16x8 ah[RING], al[RING], bh[2][NBW], bl[2][NBW];
+  if (!(DC_WG_ABL & 4)) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      ah[d] = tr_frag(smem, offA[0] + a_off(d), offA[1] + a_off(d));
+      al[d] = tr_frag(smem + A_IMG, offA[0] + a_off(d), offA[1] + a_off(d));
+    }
+#pragma unroll
+    for (int w = 0; w < NBW; ++w) {
+      bh[0][w] = tr_frag(smem, offB[0] + b_off(0, w), offB[1] + b_off(0, w));
+      bl[0][w] = tr_frag(smem + B_IMG, offB[0] + b_off(0, w), offB[1] + b_off(0, w));
+    }
+  }
+  for (int i = 0; i < nt; ++i) {
+    const char* cur = smem + (i & 1) * SET;
+    const char* nxt = smem + ((i + 1) & 1) * SET;
+    const bool more = i + 1 < nt;
+    if (DC_WG_ABL & 4) { __syncthreads(); continue; }
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+      const int ca = g % RING, ks = g / TAPS, tap = g % TAPS, cbuf = (KSTEPS == 1) ? 0 : (ks & 1);
+      if (g == GROUPS - DEPTH) __syncthreads();     // every read of this set has been issued (and is waited for here)
+      const int gn = g + DEPTH;
+      if (gn < GROUPS) {
+        ah[gn % RING] = tr_frag(cur, offA[0] + a_off(gn), offA[1] + a_off(gn));
+        al[gn % RING] = tr_frag(cur + A_IMG, offA[0] + a_off(gn), offA[1] + a_off(gn));
+      } else if (more) {                            // the next tile's first groups, from the other image set
+        ah[gn % RING] = tr_frag(nxt, offA[0] + a_off(gn - GROUPS), offA[1] + a_off(gn - GROUPS));
+        al[gn % RING] = tr_frag(nxt + A_IMG, offA[0] + a_off(gn - GROUPS), offA[1] + a_off(gn - GROUPS));
+      }
+      if (KSTEPS > 1 && tap == 0 && ks + 1 < KSTEPS) {           // the next k-step's B fragments: the other buffer is free
+#pragma unroll
+        for (int w = 0; w < NBW; ++w) {
+          bh[cbuf ^ 1][w] = tr_frag(cur, offB[0] + b_off(ks + 1, w), offB[1] + b_off(ks + 1, w));
+          bl[cbuf ^ 1][w] = tr_frag(cur + B_IMG, offB[0] + b_off(ks + 1, w), offB[1] + b_off(ks + 1, w));
+        }
+      }
+      if (KSTEPS > 1 && g == GROUPS - DEPTH && more) {           // the next tile's k-step 0 (buffer 0: k-step KSTEPS - 2 is long done)
+#pragma unroll
+        for (int w = 0; w < NBW; ++w) {
+          bh[0][w] = tr_frag(nxt, offB[0] + b_off(0, w), offB[1] + b_off(0, w));
+          bl[0][w] = tr_frag(nxt + B_IMG, offB[0] + b_off(0, w), offB[1] + b_off(0, w));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int w = 0; w < NBW; ++w) {
+        acc[w][tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ca], bh[cbuf][w], acc[w][tap], 0, 0, 0);
+        acc[w][tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cbuf][w], acc[w][tap], 0, 0, 0);
+        acc[w][tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cbuf][w], acc[w][tap], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (KSTEPS == 1 && more) {                      // one k-step per tile: its only B buffer is free only now
+#pragma unroll
+      for (int w = 0; w < NBW; ++w) {
+        bh[0][w] = tr_frag(nxt, offB[0] + b_off(0, w), offB[1] + b_off(0, w));
+        bl[0][w] = tr_frag(nxt + B_IMG, offB[0] + b_off(0, w), offB[1] + b_off(0, w));
+      }
+    }
+  }
+#else
   constexpr int DEPTH = DC_WG_DEPTH, RING = DEPTH + 1;
   for (int i = 0; i < nt; ++i) {
     char* cur = smem + (i & 1) * SET;
@@ -435,6 +515,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16x3_kernel(WgradHParams hp) {
     }
     __syncthreads();   // this set may be overwritten, the other one is complete
   }
+#endif
   if (DC_WG_PRIO) __builtin_amdgcn_s_setprio(0);
   WG_TL(2);
 #ifdef DC_WG_CLOCK

@@ -17,13 +17,24 @@ src, tag = sys.argv[1], sys.argv[2]
 P = os.path.join(ROOT, 'profiles')
 bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
 infer = json.loads(open(os.path.join(src, 'bench_infer.json')).read().strip().splitlines()[-1])
-stats_csv = os.path.join(src, 'stats', 'p_kernel_stats.csv')
+def _find(root, name):
+    for d, _, files in os.walk(root):
+        if name in files:
+            return os.path.join(d, name)
+    return os.path.join(root, name)
+
+
+stats_csv = _find(os.path.join(src, 'stats'), 'p_kernel_stats.csv')
 shutil.copy(stats_csv, os.path.join(P, tag + '_bench_train_b16_kernel_stats.csv'))
 rows = list(csv.DictReader(open(stats_csv)))
 pmc_json = os.path.join(P, tag + '_pmc_per_kernel.json')
 # pmc_traffic.json = what bench.py's roofline.traffic reports, stamped with the kernel-source fingerprint it was measured on
 table = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'pmc_table.py'), os.path.join(src, 'pmc'), '--json', pmc_json,
                         '--traffic', os.path.join(P, 'pmc_traffic.json')], capture_output=True, text=True, check=True).stdout
+# make_profiles.sh stamps pmc_traffic.json ON THE BOX, before the bench line is taken (so the line carries its own traffic figure):
+# that copy is the one to keep
+if os.path.exists(os.path.join(src, 'pmc_traffic.json')):
+    shutil.copy(os.path.join(src, 'pmc_traffic.json'), os.path.join(P, 'pmc_traffic.json'))
 traffic = json.load(open(os.path.join(P, 'pmc_traffic.json')))
 traffic['source'] = tag + '_pmc_per_kernel.json'
 json.dump(traffic, open(os.path.join(P, 'pmc_traffic.json'), 'w'), indent=1)
@@ -31,12 +42,18 @@ for name, dst in (('FETCH_SIZE', 'pmc_fetch_size'), ('WRITE_SIZE', 'pmc_write_si
     f = os.path.join(src, 'pmc', name, 'p_counter_collection.csv')
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, '%s_%s.csv' % (tag, dst)))
-for name in ('bench.json', 'bench_infer.json', 'bench_tta.json'):
+for name in ('bench.json', 'bench_infer.json', 'bench_tta.json', 'bench_w128.json', 'bench_w96.json', 'bench_f32.json'):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(P, '%s_%s' % (tag, name)))
-si = os.path.join(src, 'stats_infer', 'p_kernel_stats.csv')
+si = _find(os.path.join(src, 'stats_infer'), 'p_kernel_stats.csv')
 if os.path.exists(si):
     shutil.copy(si, os.path.join(P, tag + '_bench_infer_b8_kernel_stats.csv'))
+st = _find(os.path.join(src, 'stats_tta'), 'p_kernel_stats.csv')
+if os.path.exists(st):
+    shutil.copy(st, os.path.join(P, tag + '_bench_tta_kernel_stats.csv'))
+if os.path.exists(os.path.join(src, 'infer_pmc_per_kernel.json')):      # review item 5: the forward-only command under the three PMC passes
+    shutil.copy(os.path.join(src, 'infer_pmc_per_kernel.json'), os.path.join(P, tag.replace('_final', '') + '_infer_pmc_per_kernel.json'))
+    shutil.copy(os.path.join(src, 'infer_pmc_table.md'), os.path.join(P, tag.replace('_final', '') + '_infer_pmc_table.md'))
 
 steps = 11   # bench.py --steps 5 --warmup 2 + 4 instrumented steps (2 with, 2 without the side stream)
 out = io.StringIO()

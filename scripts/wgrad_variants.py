@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = [
     ('base', []),
+    ('xtile0', ['-DDC_WG_XTILE=0']),
     ('abl_nostage', ['-DDC_WG_ABL=1']),
     ('abl_noload', ['-DDC_WG_ABL=2']),
     ('abl_consumers_alone', ['-DDC_WG_ABL=3']),
