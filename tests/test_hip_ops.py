@@ -1016,6 +1016,8 @@ def test_split_k_workspace_is_caller_owned_one_per_stream(dclib):
         tiles = L.dc_conv3x3_tiles(N, H, W, Co)
         z = torch.full((N, H, W, Co), float('nan'), device='cuda')
         stats = torch.full((tiles * Co * 2,), float('nan'), device='cuda', dtype=torch.float64)
+        if stream is not None:          # the NaN fills run on the current stream; torch's pool streams do not synchronise with it implicitly
+            stream.wait_stream(torch.cuda.current_stream())
         L.dc_conv3x3_fwd_f16x3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), z.data_ptr(), Co, stats.data_ptr(), 0, None, None, 0,
                                None, 0, None, 0, ws.data_ptr(), N, H, W, Ci, Co, stream.cuda_stream if stream is not None else None)
         return z, stats
