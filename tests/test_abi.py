@@ -128,3 +128,20 @@ def test_role_split_kernels_stay_below_the_sgpr_spill_cliff(tmp_path):
     assert len(spills) >= 4 and len(set(names)) >= 4, (names, spills)
     assert max(spills) <= 72, spills            # verified good at 53-64; broken at 186-196
     assert all(s == 0 for s in scratch), scratch
+
+
+def test_library_loads_without_rccl_and_says_so_when_asked(dclib):
+    """librccl is resolved with dlopen at the first dc_comm_* call (csrc/comm.cpp): the library itself carries no link-time dependency on it
+    (a box with nothing that links RCCL must still run every other entry point), and the collective entry points exist in the ABI."""
+    import subprocess
+    from deep_calcium_amd import _build, _lib
+    out = subprocess.run(['readelf', '-d', _build.LIB], capture_output=True, text=True).stdout
+    needed = [l.split('[')[-1].rstrip(']') for l in out.splitlines() if 'NEEDED' in l]
+    assert needed and not [n for n in needed if 'rccl' in n.lower() or 'nccl' in n.lower()], needed
+    protos = _lib.parse_header()
+    for name in ('dc_comm_unique_id', 'dc_comm_init_rank', 'dc_comm_all_reduce_sum', 'dc_comm_all_reduce_sum_f64', 'dc_comm_group_start',
+                 'dc_comm_group_end', 'dc_comm_destroy', 'dc_event_create_fenced', 'dc_bracket_next_launch'):
+        assert name in protos and hasattr(dclib.cdll, name), name
+    # bad arguments are rejected before RCCL is even looked for
+    assert dclib.cdll.dc_comm_all_reduce_sum(None, None, 0, None) == -1
+    assert b'dc_comm_all_reduce_sum' in dclib.cdll.dc_last_error()

@@ -37,6 +37,8 @@ def _worker(rank, world, port, out_dir):
     from deep_calcium_amd.model import metrics_from_sums
     r, w = parallel.init_from_env(backend='gloo')
     assert (r, w) == (rank, world) and parallel.world_size() == world
+    # over gloo the exchange stays with torch.distributed: the RCCL communicator behind the C ABI (dc_comm_*) is for backend nccl only
+    assert parallel.native_comm('cuda:0') is None and not parallel.native_comm_active('cuda:0')
     x, y = on.synthetic_batch(N, H, W)                      # every rank draws the SAME global batch
     masks = on.make_drop_masks(NFB, N, H, W)
     sl = parallel.shard_slice(N)
