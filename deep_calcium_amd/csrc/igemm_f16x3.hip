@@ -363,8 +363,13 @@ __global__ __launch_bounds__(256, 2) void igemm_f16x3_kernel(IgemmParams p) {
             if (p.scale) v = v * sc + sh;
             if (p.relu) v = fmaxf(v, 0.f);
             if constexpr (TRACK) amax = fmaxf(amax, fabsf(v));
+#if defined(DC_F_ABL) && (DC_F_ABL & 1)
+            // ablation (garbage results): no output stores -- one conditional store keeps the values alive
+            if (v == 12345.678f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, base, 0, 0);
+#else
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, base,
                                                   (rowc * sy + colc * sx) * 4, 0);      // scalar addend
+#endif
           } else {
             const bool ok = n_ok && (oyb + rowc) < p.Hout && (oxb + colc) < p.Wout;
             if constexpr (STATS) {

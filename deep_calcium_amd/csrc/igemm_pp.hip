@@ -24,7 +24,8 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // first wave stores s_memtime when its work of a step is done and again when the step's barrier has released it.
 // DC_PP_ABL (debug builds only, scripts/igemm_pp_ablate.py): bit 0 no epilogue work (the compiler then drops the MFMAs
 // too: unusable), bit 1 producers do not split / write LDS, bit 2 consumers read their fragments once per step, bit 3
-// producers do not load, bit 4 two more stamps per consumer step (tile setup done, first fragments landed), bit 5 the producers
+// producers do not load, bit 4 two more stamps per consumer step (tile setup done, first fragments landed), bit 6 interior tiles issue
+// no output stores (scripts/level0_store_ablate.py), bit 5 the producers
 // write the raw fp32 bits instead of the fp16 split (the LDS traffic of a PRE-SPLIT operand, none of its VALU).  Results are
 // garbage for bits 0-3 and 5.
 #ifndef DC_PP_ABL
@@ -572,7 +573,11 @@ __global__ __launch_bounds__(pp::THREADS, 1) void igemm_pp_kernel(IgemmParams p)
         if (p.scale) v = v * sc + sh;
         if (p.relu) v = fmaxf(v, 0.f);
         if constexpr (MODE == 2) amax = fmaxf(amax, fabsf(v));
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, base, (rowc * sy + colc * sx) * 4, 0);
+        if (DC_PP_ABL & 64) {     // ablation (garbage results): no output stores -- one conditional store keeps the values alive
+          if (v == 12345.678f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, base, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcO, base, (rowc * sy + colc * sx) * 4, 0);
+        }
       } else {
         const bool ok = n_ok && (oyb + rowc) < p.Hout && (oxb + colc) < p.Wout;
         if (m_stats) { e_s1 += ok ? d : 0.f; e_s2 += ok ? d * d : 0.f; e_cnt += ok ? 1.f : 0.f; }
