@@ -145,3 +145,19 @@ def test_library_loads_without_rccl_and_says_so_when_asked(dclib):
     # bad arguments are rejected before RCCL is even looked for
     assert dclib.cdll.dc_comm_all_reduce_sum(None, None, 0, None) == -1
     assert b'dc_comm_all_reduce_sum' in dclib.cdll.dc_last_error()
+
+
+def test_import_raises_the_hardware_queue_count_only_when_unset():
+    """deep_calcium_amd/__init__.py sets GPU_MAX_HW_QUEUES=8 as a DEFAULT (with HIP's 4 queues a data-parallel rank's
+    weight-gradient stream can land on the main stream's hardware queue and the two-stream backward serialises); an explicit value wins."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, deep_calcium_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    for given, want in ((None, '8'), ('4', '4'), ('16', '16')):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop('GPU_MAX_HW_QUEUES', None)
+        if given is not None:
+            env['GPU_MAX_HW_QUEUES'] = given
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and out.stdout.strip() == want, (given, out.stdout, out.stderr[-300:])
