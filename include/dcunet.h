@@ -489,6 +489,8 @@ int dc_event_destroy(void* ev);
 
 /* ---- collectives: the data-parallel gradient exchange (SURVEY 8b "call librccl.so ... directly via ctypes or a 3-function
  * dc_comm_* wrapper", 8e: one ncclAllReduce(sum, fp32) over the flat gradient buffer, optionally in buckets) ---------------
+ * No reference counterpart: the reference trains on ONE device (README.md:23 pins CUDA_VISIBLE_DEVICES="0"; its step is the
+ * model.fit_generator -> train_on_batch of unet_2d_summary.py:429-430); what is exchanged here is that step's flat gradient.
  * RCCL (librccl.so.1) is resolved with dlopen at the first dc_comm_* call -- the copy the process already holds (PyTorch-ROCm's)
  * when there is one; every other entry point works without it (DC_EUNSUP + message from these when it cannot be loaded).
  *   dc_comm_unique_id: HOST buffer of DC_COMM_ID_BYTES, filled by ONE rank and handed to the others out of band (the binding
