@@ -295,6 +295,7 @@ class UNetEngine(object):
         self.tail_main = os.environ.get('DC_TAIL_MAIN', '1') == '1'      # the step's last weight gradient on the main stream (A/B: 0)
         self.stats_per_wg = True          # BatchNorm partials: one row per (workgroup, consumer set) of the role-split kernel (A/B: False)
         self.use_tapes = os.environ.get('DC_TAPES', '1') != '0'
+        self.tape_verify = int(os.environ.get('DC_TAPE_VERIFY', '0'))     # debug: every K-th replay re-records and compares
         self.ar_buckets = 1 if os.environ.get('DC_AR_BUCKETS', '3') == '1' else 3      # gradient exchange: one all-reduce or three ranges
         self._tapes = {}
         self._tape_epoch = 0
@@ -520,6 +521,18 @@ class UNetEngine(object):
         ent = self._tapes.get(key)
         if ent is not None and ent['tape'] is not None:
             self.tape_replays += 1
+            if self.tape_verify and self.tape_replays % self.tape_verify == 0:
+                # debug hook (DC_TAPE_VERIFY=K): every K-th replay is a fresh recording instead -- the launches go out one by one --
+                # and must equal what the tape holds; a difference means engine state changed without dropping the tapes
+                self.L.record_begin()
+                try:
+                    ret = body()
+                finally:
+                    ops = self.L.record_end()
+                if not ops_equal(ent['ops'], ops):
+                    raise DcunetError('launch tape %r no longer matches the sequence the engine issues (DC_TAPE_VERIFY): some state '
+                                      'the recorded phase depends on changed without invalidate_tapes()' % (key[0],))
+                return ret
             ent['tape'].replay(values(), on_mark)
             for a, v in ent['post'].items():
                 setattr(self, a, v)

@@ -157,3 +157,25 @@ def test_engine_state_change_drops_the_tapes_and_the_run_stays_the_untaped_one()
     assert len(a.engine._tapes) == n             # a NEW buffer moves nothing
     a.engine.buf('tape_test_scratch', 1 << 20)
     assert not a.engine._tapes
+
+
+def test_tape_verify_rerecords_and_catches_a_stale_tape():
+    """DC_TAPE_VERIFY=K (UNetEngine.tape_verify): every K-th replay is issued launch by launch under a fresh recording and compared
+    with the tape -- the run stays the untaped one bit for bit, and a tape that no longer matches what the engine issues raises."""
+    from deep_calcium_amd._lib import DcunetError
+    a, b = _pair(32, 8)
+    a.engine.tape_verify = 2
+    data = _batches(2, 4, 32, 3)
+    for step in range(8):
+        x, y = data[step % 2]
+        for m in (a, b):
+            m.train_on_device_batch(x, y)
+    torch.cuda.synchronize()
+    assert a.engine.tape_replays >= 12
+    assert torch.equal(a.engine.pflat, b.engine.pflat) and torch.equal(a.engine.mflat, b.engine.mflat)
+    # a tape whose recording no longer equals the live sequence (simulated: one recorded op dropped) is reported, not replayed
+    key = [k for k in a.engine._tapes if k[0] == 'fwd'][0]
+    a.engine._tapes[key]['ops'] = a.engine._tapes[key]['ops'][:-1]
+    a.engine.tape_verify = 1
+    with pytest.raises(DcunetError, match='no longer matches'):
+        a.train_on_device_batch(*data[0])
